@@ -1,0 +1,588 @@
+"""CPU oracle for the bundle-adjustment hot path of `modules/pix2world.py` (`p2w`).
+
+TEST INFRASTRUCTURE ONLY.  This module is the checker the HIP path is compared
+against.  It may be imported from `tests/`, from `__graft_entry__.smoke()` and
+from the `cpu_baseline` leg of `bench.py`, and from nowhere else: the product
+package never imports it and has no CPU fallback.
+
+It restates the reference's algorithm on the visibility set only (O(|V|) work and
+memory instead of the reference's dense O(N*K)), in float64 NumPy, following the
+reference's own formulas line by line (including the way it rebuilds Rx/Ry/Rz
+from the entries of R after the first iteration).  Parity is PINNED: the golden
+vectors under `tests/golden/` were produced by importing the reference itself
+(`oracle/capture_golden.py`) and `tests/test_oracle_golden.py` checks this file
+against every one of them.
+
+Every function cites the reference lines it follows.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+__all__ = [
+    "visibility_coo", "rx", "ry", "rz", "ryxz", "get_rotations", "align_scene",
+    "normalize_scene", "sgd", "gd_adam", "GD_FUNCS", "lr_manager", "form_params_dict",
+    "forward_obs", "energy_and_gradients", "fit_scene", "transform_obs", "transform_dense",
+    "error", "count_components", "dense_jacobian", "camera_rotation_tables",
+]
+
+
+# --------------------------------------------------------------------------- #
+# visibility set  (p2w:506-508, 531)
+# --------------------------------------------------------------------------- #
+def visibility_coo(X_pix):
+    """COO form of `X_visible = X_pix[:,:,0] >= 0` (p2w:506) in the C order NumPy's boolean
+    mask indexing walks (i-major, j ascending), and the pixel centres
+    `X_pix[X_visible] + 0.5` (p2w:531).  Returns (i int32[V], j int32[V], uv float64[V,2])."""
+    X_pix = np.asarray(X_pix)
+    vis = X_pix[:, :, 0] >= 0
+    i, j = np.nonzero(vis)
+    uv = X_pix[vis] + 0.5
+    return i.astype(np.int32), j.astype(np.int32), np.ascontiguousarray(uv, dtype=np.float64)
+
+
+def count_components(i, j, N, K):
+    """Number of connected components of the bipartite visibility graph on N+K nodes
+    (p2w:519-525 builds the dense (N+K)^2 adjacency; only the count matters)."""
+    parent = np.arange(N + K)
+
+    def find(a):
+        while parent[a] != a:
+            parent[a] = parent[parent[a]]
+            a = parent[a]
+        return a
+
+    for a, b in zip(np.asarray(i).tolist(), (np.asarray(j) + N).tolist()):
+        ra, rb = find(a), find(b)
+        if ra != rb:
+            parent[max(ra, rb)] = min(ra, rb)
+    return len({find(a) for a in range(N + K)})
+
+
+# --------------------------------------------------------------------------- #
+# rotations  (p2w:114-140, 254-267)
+# --------------------------------------------------------------------------- #
+def rx(theta):
+    """p2w:114-120."""
+    theta = np.asarray(theta, dtype=np.float64).ravel()
+    R = np.zeros((theta.size, 3, 3))
+    c, s = np.cos(theta), np.sin(theta)
+    R[:, 0, 0] = 1.0
+    R[:, 1, 1] = c
+    R[:, 2, 2] = c
+    R[:, 2, 1] = s
+    R[:, 1, 2] = -s
+    return R
+
+
+def ry(theta):
+    """p2w:122-128."""
+    theta = np.asarray(theta, dtype=np.float64).ravel()
+    R = np.zeros((theta.size, 3, 3))
+    c, s = np.cos(theta), np.sin(theta)
+    R[:, 1, 1] = 1.0
+    R[:, 0, 0] = c
+    R[:, 2, 2] = c
+    R[:, 0, 2] = s
+    R[:, 2, 0] = -s
+    return R
+
+
+def rz(theta):
+    """p2w:130-136."""
+    theta = np.asarray(theta, dtype=np.float64).ravel()
+    R = np.zeros((theta.size, 3, 3))
+    c, s = np.cos(theta), np.sin(theta)
+    R[:, 2, 2] = 1.0
+    R[:, 0, 0] = c
+    R[:, 1, 1] = c
+    R[:, 1, 0] = s
+    R[:, 0, 1] = -s
+    return R
+
+
+def ryxz(Theta):
+    """R = Ry(theta_y) Rx(theta_x) Rz(theta_z)  (p2w:138-140; Theta columns are x, y, z)."""
+    Theta = np.asarray(Theta, dtype=np.float64)
+    return ry(Theta[:, 1]) @ rx(Theta[:, 0]) @ rz(Theta[:, 2])
+
+
+def get_rotations(R):
+    """Inverse of `ryxz` by atan2 extraction (p2w:254-267)."""
+    C_x = np.sqrt(R[:, 1, 0] ** 2 + R[:, 1, 1] ** 2)
+    S_x = -R[:, 1, 2]
+    C_y, S_y = R[:, 2, 2] / C_x, R[:, 0, 2] / C_x
+    C_z, S_z = R[:, 1, 1] / C_x, R[:, 1, 0] / C_x
+    return np.column_stack((np.arctan2(S_x, C_x), np.arctan2(S_y, C_y), np.arctan2(S_z, C_z)))
+
+
+# --------------------------------------------------------------------------- #
+# gauge fix  (p2w:270-333)
+# --------------------------------------------------------------------------- #
+def align_scene(X, C, Theta=None, R=None, ret_R=False):
+    """Move camera 0 to the origin with identity rotation (p2w:270-303)."""
+    if Theta is None and R is None:
+        raise ValueError('Expected Theta or R to be passed')
+    if Theta is not None and R is not None:
+        raise ValueError('Expected only Theta or R to be passed, not both')
+    X_new = X - C[0]
+    C_new = C - C[0]
+    if Theta is not None:
+        R_zero = ryxz(Theta[0, :].reshape(1, -1))[0].T
+    else:
+        R_zero = R[0].T
+    X_new = X_new @ R_zero.T
+    C_new = C_new @ R_zero.T
+    R_new = R_zero @ (ryxz(Theta) if Theta is not None else R)
+    Theta_new = get_rotations(R_new)
+    if not ret_R:
+        return X_new, C_new, Theta_new
+    return X_new, C_new, Theta_new, R_new
+
+
+def normalize_scene(X, C, main_indexes=None, dist_scale=1.0, ret_j=False):
+    """Scale so that the longest baseline from camera 0 has length `dist_scale` (p2w:306-333)."""
+    if main_indexes is None:
+        j0 = 0
+        j1 = 1 + np.argmax(np.linalg.norm(C[1:] - C[0], axis=1))
+    else:
+        j0, j1 = main_indexes
+    dist = np.linalg.norm(C[j1] - C[j0])
+    factor = dist_scale / dist
+    out = [X * factor, C * factor]
+    if ret_j:
+        out.append(j1)
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# optimiser core  (p2w:336-477)
+# --------------------------------------------------------------------------- #
+def sgd(x, grad_x, lr):
+    """p2w:336-342."""
+    return x - lr * grad_x, {}
+
+
+def gd_adam(x, grad_x, lr, s, r, t, rho_1=0.9, rho_2=0.999):
+    """Adam with bias correction and eps = 1e-12 outside the square root (p2w:344-360)."""
+    s_new = rho_1 * s + (1.0 - rho_1) * grad_x
+    r_new = rho_2 * r + (1.0 - rho_2) * grad_x ** 2
+    s_corr = s_new / (1.0 - rho_1 ** t)
+    r_corr = r_new / (1.0 - rho_2 ** t)
+    x_new = x - lr * s_corr / (1e-12 + np.sqrt(r_corr))
+    return x_new, {'s': s_new, 'r': r_new, 't': t + 1}
+
+
+GD_FUNCS = {'SGD': sgd, 'Adam': gd_adam}     # p2w:362
+
+
+def form_params_dict(params, optimizer, ret_all_iters, max_iters):
+    """Per-group optimiser state: release snapshot, gd / gd_temp / gd_init (p2w:457-477)."""
+    for val in params.values():
+        val['release'] = val['main'].copy()
+        val['gd'], val['gd_temp'], val['gd_init'] = {}, {}, {}
+    if optimizer == 'Adam':
+        for val in params.values():
+            for slot in ('gd', 'gd_temp', 'gd_init'):
+                val[slot]['s'] = np.zeros_like(val['main'])
+                val[slot]['r'] = np.zeros_like(val['main'])
+                val[slot]['t'] = np.array([1])
+    if ret_all_iters:
+        for val in params.values():
+            val['all_iters'] = max_iters * [None]
+
+
+def lr_manager(lr, iters, E, E_min, E_min_temp, patience_timer, success_timer,
+               began_decreasing, increased, patience, factor, params, ret_all_iters,
+               recompute, log=None):
+    """LR schedule / snapshot / rollback state machine (p2w:365-454).
+
+    `recompute()` stands for `func(*func_args, **func_kwargs)` (p2w:436); its result is
+    returned in a list of length <= 1.  `log`, when given, collects the two event lines
+    the reference prints (p2w:405, 430)."""
+    results = []
+    lr_, iters_, E_min_, E_min_temp_ = lr, iters, E_min, E_min_temp
+    pt, st, began, inc = patience_timer, success_timer, began_decreasing, increased
+    if iters_ == 0:
+        E_min_ = E[iters]
+    elif E[iters] < E_min_:
+        E_min_ = E[iters]
+        began = True
+        for val in params.values():
+            val['release'] = val['main'].copy()
+        pt = patience
+        if st > 0:
+            st -= 1
+        else:
+            if log is not None:
+                log.append(f'{iters_} : Icrease LR to {lr_ * factor}')
+            lr_ *= factor
+            st = patience
+            inc = True
+            E_min_temp_ = E_min_
+            for val in params.values():
+                for key in val['gd']:
+                    val['gd_temp'][key] = val['gd'][key].copy()
+                    val['gd'][key] = val['gd_init'][key].copy()
+    elif E[iters] > E_min_:
+        if inc:
+            pt = 0
+            iters_ -= 1
+        st = patience
+        if pt > 0:
+            pt -= 1
+        else:
+            if began:
+                pt = patience
+            else:
+                iters_ -= 1
+            if log is not None:
+                log.append(f'{iters_} : Decrease LR to {lr_ / factor}')
+            lr_ /= factor
+            for val in params.values():
+                val['main'][:] = val['release']
+            results.append(recompute())
+            if (not inc) or (inc and E_min_temp_ > E_min_):
+                for val in params.values():
+                    for key in val['gd']:
+                        val['gd'][key] = val['gd_init'][key].copy()
+            else:
+                for val in params.values():
+                    for key in val['gd']:
+                        val['gd'][key] = val['gd_temp'][key].copy()
+                inc = False
+    if ret_all_iters:
+        for val in params.values():
+            val['all_iters'][iters] = val['main'].copy()
+    return (lr_, iters_, E_min_, E_min_temp_, pt, st, began, inc), results
+
+
+# --------------------------------------------------------------------------- #
+# per-observation forward model and gradient  (p2w:544-575, 612, 654-702)
+# --------------------------------------------------------------------------- #
+def forward_obs(X, C, R, f, W, H, i, j, uv):
+    """`inner_transform` restricted to the visible pairs (p2w:555-573):
+    d = X_i - C_j, q = R_j^T d, model = f q_xy / q_z + (W/2, H/2), residual = model - uv.
+    Returns (residual [V,2], q [V,3], d [V,3])."""
+    d = X[i] - C[j]
+    q = np.einsum('vl,vlk->vk', d, R[j])
+    model = f * q[:, :2] / q[:, 2:3] + np.array([W, H]) / 2.0
+    return model - uv, q, d
+
+
+def camera_rotation_tables(Theta=None, R=None, Theta_for_sign=None):
+    """Rx, Ry, Rz factor matrices.  From angles (p2w:557) when `Theta` is given; otherwise
+    recovered from the entries of a gauge-fixed R exactly as p2w:665-676 does."""
+    if Theta is not None:
+        return rx(Theta[:, 0]), ry(Theta[:, 1]), rz(Theta[:, 2])
+    K = R.shape[0]
+    Rx_, Ry_, Rz_ = rx(np.zeros(K)), ry(np.zeros(K)), rz(np.zeros(K))
+    cx = np.sign(np.pi - (Theta_for_sign[:, 0] + np.pi / 2.0) % (2.0 * np.pi)) \
+        * np.sqrt(R[:, 1, 0] ** 2 + R[:, 1, 1] ** 2)
+    Rx_[:, 1, 1] = Rx_[:, 2, 2] = cx
+    Rx_[:, 1, 2] = R[:, 1, 2]
+    Rx_[:, 2, 1] = -Rx_[:, 1, 2]
+    Ry_[:, 0, 0] = Ry_[:, 2, 2] = R[:, 2, 2] / cx
+    Ry_[:, 0, 2] = R[:, 0, 2] / cx
+    Ry_[:, 2, 0] = -Ry_[:, 0, 2]
+    Rz_[:, 0, 0] = Rz_[:, 1, 1] = R[:, 1, 1] / cx
+    Rz_[:, 1, 0] = R[:, 1, 0] / cx
+    Rz_[:, 0, 1] = -Rz_[:, 1, 0]
+    return Rx_, Ry_, Rz_
+
+
+def _d_R_d_theta(Rx_, Ry_, Rz_):
+    """dR/dtheta_l for l = x, y, z stacked on the last axis (p2w:678-692)."""
+    K = Rx_.shape[0]
+    D_Rx, D_Ry, D_Rz = np.zeros((3, K, 3, 3))
+    D_Rx[:, 1, 1] = D_Rx[:, 2, 2] = Rx_[:, 1, 2]
+    D_Rx[:, 2, 1] = Rx_[:, 1, 1]
+    D_Rx[:, 1, 2] = -D_Rx[:, 2, 1]
+    D_Ry[:, 0, 0] = D_Ry[:, 2, 2] = Ry_[:, 2, 0]
+    D_Ry[:, 0, 2] = Ry_[:, 0, 0]
+    D_Ry[:, 2, 0] = -D_Ry[:, 0, 2]
+    D_Rz[:, 0, 0] = D_Rz[:, 1, 1] = Rz_[:, 0, 1]
+    D_Rz[:, 1, 0] = Rz_[:, 0, 0]
+    D_Rz[:, 0, 1] = -D_Rz[:, 1, 0]
+    D = np.zeros((K, 3, 3, 3))
+    D[:, :, :, 0] = Ry_ @ D_Rx @ Rz_
+    D[:, :, :, 1] = D_Ry @ Rx_ @ Rz_
+    D[:, :, :, 2] = Ry_ @ Rx_ @ D_Rz
+    return D
+
+
+def _segment_sum(idx, vals, n):
+    out = np.zeros((n, vals.shape[1]))
+    for k in range(vals.shape[1]):
+        out[:, k] = np.bincount(idx, weights=vals[:, k], minlength=n)
+    return out
+
+
+def jacobian_blocks(X, C, R, Rx_, Ry_, Rz_, f, phi_x, W, H, i, j, uv):
+    """Per-observation residual and Jacobian blocks (p2w:654-657, 694-695, 701):
+    r [V,2], J_X [V,2,3] (J_C = -J_X), J_Theta [V,2,3], J_phi [V,2]."""
+    r, q, d = forward_obs(X, C, R, f, W, H, i, j, uv)
+    V = i.size
+    A = np.zeros((V, 2, 3))
+    A[:, 0, 0] = A[:, 1, 1] = f / q[:, 2]
+    A[:, :, 2] = -f / q[:, 2:3] ** 2 * q[:, :2]
+    J_X = A @ R[j].transpose(0, 2, 1)
+    D_R = _d_R_d_theta(Rx_, Ry_, Rz_)
+    D_rot = np.einsum('vnkl,vn->vkl', D_R[j], d)
+    J_Theta = A @ D_rot
+    J_phi = -f / np.sin(phi_x) * q[:, :2] / q[:, 2:3]
+    return r, J_X, J_Theta, J_phi
+
+
+def energy_and_gradients(X, C, Theta, phi_x, W, H, i, j, uv, R=None, factors=None, f=None,
+                         n_visible=None):
+    """E (p2w:612) and dE/dX, dE/dC, dE/dTheta, dE/dphi_x (p2w:659-702) on the visible pairs.
+
+    `R` / `factors=(Rx,Ry,Rz)` default to the values built from `Theta` (what the reference
+    uses at iteration 0 and after a rollback); pass them to reproduce the later iterations,
+    where R comes from `align_scene` and the factors are recovered from its entries."""
+    N, K = X.shape[0], C.shape[0]
+    phi = float(np.asarray(phi_x).ravel()[0])
+    if factors is None:
+        factors = camera_rotation_tables(Theta=Theta)
+    if R is None:
+        R = factors[1] @ factors[0] @ factors[2]
+    if f is None:
+        f = W / 2.0 / np.tan(phi / 2.0)
+    nv = i.size if n_visible is None else n_visible
+    r, J_X, J_Theta, J_phi = jacobian_blocks(X, C, R, *factors, f, phi, W, H, i, j, uv)
+    E = np.dot(r.ravel(), r.ravel()) / (2 * nv)
+    w = r / nv
+    gx_obs = np.einsum('vl,vlk->vk', w, J_X)
+    gth_obs = np.einsum('vl,vlk->vk', w, J_Theta)
+    gX = _segment_sum(i, gx_obs, N)
+    gC = -_segment_sum(j, gx_obs, K)
+    gTheta = _segment_sum(j, gth_obs, K)
+    gphi = np.array([np.dot(w.ravel(), J_phi.ravel())])
+    return E, gX, gC, gTheta, gphi
+
+
+def dense_jacobian(X, C, Theta, phi_x, W, H, i, j, uv):
+    """Dense Jacobian of the stacked residual vector (2V rows; columns X (3N), C (3K),
+    Theta (3K), phi_x (1)) assembled from the same blocks as the gradient; used to pin the
+    J^T J quantities, which have no counterpart in the reference."""
+    N, K, V = X.shape[0], C.shape[0], i.size
+    phi = float(np.asarray(phi_x).ravel()[0])
+    factors = camera_rotation_tables(Theta=Theta)
+    R = factors[1] @ factors[0] @ factors[2]
+    f = W / 2.0 / np.tan(phi / 2.0)
+    r, J_X, J_Theta, J_phi = jacobian_blocks(X, C, R, *factors, f, phi, W, H, i, j, uv)
+    J = np.zeros((2 * V, 3 * N + 6 * K + 1))
+    rows = np.arange(V)
+    for a in range(2):
+        for b in range(3):
+            J[2 * rows + a, 3 * i + b] = J_X[:, a, b]
+            J[2 * rows + a, 3 * N + 3 * j + b] = -J_X[:, a, b]
+            J[2 * rows + a, 3 * N + 3 * K + 3 * j + b] = J_Theta[:, a, b]
+        J[2 * rows + a, -1] = J_phi[:, a]
+    return r.ravel(), J
+
+
+# --------------------------------------------------------------------------- #
+# fit_scene  (p2w:480-726)
+# --------------------------------------------------------------------------- #
+def fit_scene(i, j, uv, N, K, W, H, lr, max_iters, X_0, C_0, Theta_0, phi_x_0,
+              X_mask=True, C_Theta_mask=True, phi_x_mask=True, optimizer='Adam',
+              patience=1000, factor=2.0, stop_value=0.0, stop_diff=1e-12,
+              ret_all_iters=False, log=None, grad_log=None):
+    """`fit_scene` on the COO visibility set: same loop, same update order, same gauge fix,
+    same stopping rules and the same return packing as p2w:480-726.  Input checks
+    (p2w:501-528) are the caller's business here.  `log` collects the LR-event and
+    stop-reason lines; `grad_log` collects (group name, parameters, gradient) per step."""
+    nv = i.size
+    WH = (W, H)
+    X, C, Theta = X_0.copy(), C_0.copy(), Theta_0.copy()
+    phi_x = np.array([phi_x_0], dtype=np.float64)
+    if X_mask and C_Theta_mask:
+        X[:], C[:], Theta[:] = align_scene(X, C, Theta=Theta)
+        X[:], C[:] = normalize_scene(X, C)
+
+    state = {}
+
+    def inner_transform(calc_Rs, R=None, f=None):
+        # p2w:544-575 on the visible pairs
+        out = {}
+        if calc_Rs:
+            out['Rx'], out['Ry'], out['Rz'] = camera_rotation_tables(Theta=Theta)
+        if R is None:
+            Rx_, Ry_, Rz_ = (out['Rx'], out['Ry'], out['Rz']) if calc_Rs else state['factors']
+            R_ = Ry_ @ Rx_ @ Rz_
+            out['R'] = R_
+        else:
+            R_ = R
+        if f is None:
+            f_ = W / 2.0 / np.tan(phi_x / 2.0)
+            out['f'] = f_
+        else:
+            f_ = f
+        r, q, d = forward_obs(X, C, R_, f_, WH[0], WH[1], i, j, uv)
+        return (r, q, d), out
+
+    f = None
+    if not phi_x_mask:
+        f = W / 2.0 / np.tan(phi_x / 2.0)
+
+    names = []
+    if X_mask:
+        names.append('X')
+    if C_Theta_mask:
+        names.extend(['C', 'Theta'])
+    if phi_x_mask:
+        names.append('phi_x')
+    params = {name: {} for name in names}
+    if X_mask:
+        params['X']['main'] = X
+    if C_Theta_mask:
+        params['C']['main'], params['Theta']['main'] = C, Theta
+    if phi_x_mask:
+        params['phi_x']['main'] = phi_x
+    form_params_dict(params, optimizer, ret_all_iters, max_iters)
+
+    E = np.zeros(max_iters)
+    E_min = E_min_temp = np.inf
+    patience_timer, success_timer = 0, patience
+    began_decreasing = increased = False
+    R = None
+    iters = 0
+    while iters < max_iters:
+        calculate_R = (iters == 0 and X_mask) or not X_mask
+        kw = {}
+        if not calculate_R:
+            kw['R'] = R
+        if not phi_x_mask:
+            kw['f'] = f
+        calculate_Rs = iters == 0 or not X_mask
+        (r, q, d), out = inner_transform(calculate_Rs, **kw)
+        if calculate_Rs:
+            state['factors'] = (out['Rx'], out['Ry'], out['Rz'])
+        if calculate_R:
+            R = out['R']
+        if phi_x_mask:
+            f = out['f']
+
+        E[iters] = np.dot(r.ravel(), r.ravel()) / (2 * nv)
+
+        kw = {}
+        if not C_Theta_mask:
+            kw['R'] = R
+        if not phi_x_mask:
+            kw['f'] = f
+        res, recomputed = lr_manager(lr, iters, E, E_min, E_min_temp, patience_timer,
+                                     success_timer, began_decreasing, increased, patience,
+                                     factor, params, ret_all_iters,
+                                     recompute=lambda: inner_transform(C_Theta_mask, **kw),
+                                     log=log)
+        (lr, iters, E_min, E_min_temp, patience_timer, success_timer,
+         began_decreasing, increased) = res
+
+        if lr == 0.0:
+            if log is not None:
+                log.append(f'{iters} : Reached lr = 0.0')
+            break
+        if stop_diff > 0.0 and iters > 2 * patience:
+            E_min_diff = E[:iters - 2 * patience].min() - E_min
+            if 0.0 < E_min_diff < stop_diff:
+                if log is not None:
+                    log.append(f'{iters} : Reached stopping difference: {E_min_diff} < {stop_diff}')
+                break
+        if E[iters] < stop_value:
+            if log is not None:
+                log.append(f'{iters} : Reached stopping value: {E[iters]} < {stop_value}')
+            break
+        if iters == max_iters - 1:
+            if log is not None:
+                log.append(f'{iters} : Reached maximum iterations')
+            break
+
+        if recomputed:
+            (r, q, d), out = recomputed[0]
+            if C_Theta_mask:
+                state['factors'] = (out['Rx'], out['Ry'], out['Rz'])
+                R = out['R']
+            if phi_x_mask:
+                f = out['f']
+
+        # p2w:654-702 on the visible pairs
+        A = np.zeros((nv, 2, 3))
+        A[:, 0, 0] = A[:, 1, 1] = f / q[:, 2]
+        A[:, :, 2] = -f / q[:, 2:3] ** 2 * q[:, :2]
+        J_X = A @ R[j].transpose(0, 2, 1)
+        w = r / nv
+        gx_obs = np.einsum('vl,vlk->vk', w, J_X)
+        grads = {}
+        if X_mask:
+            grads['X'] = _segment_sum(i, gx_obs, N)
+        if C_Theta_mask:
+            if not calculate_Rs and not recomputed:
+                state['factors'] = camera_rotation_tables(R=R, Theta_for_sign=Theta)
+            D_R = _d_R_d_theta(*state['factors'])
+            D_rot = np.einsum('vnkl,vn->vkl', D_R[j], d)
+            J_Theta = A @ D_rot
+            grads['C'] = -_segment_sum(j, gx_obs, K)
+            grads['Theta'] = _segment_sum(j, np.einsum('vl,vlk->vk', w, J_Theta), K)
+        if phi_x_mask:
+            J_phi = -f / np.sin(phi_x) * q[:, :2] / q[:, 2:3]
+            grads['phi_x'] = np.array([np.dot(w.ravel(), J_phi.ravel())])
+
+        for key, val in params.items():
+            if grad_log is not None:
+                grad_log.append((key, val['main'].copy(), grads[key].copy()))
+            new, new_state = GD_FUNCS[optimizer](val['main'], grads[key], lr, **val['gd'])
+            val['main'][:] = new
+            for k1, v1 in val['gd'].items():
+                v1[:] = new_state[k1]
+
+        if X_mask and C_Theta_mask:
+            X[:], C[:], Theta[:], R = align_scene(X, C, Theta=Theta, ret_R=True)
+            X[:], C[:] = normalize_scene(X, C)
+        iters += 1
+
+    if phi_x_mask:
+        params['phi_x']['main'] = params['phi_x']['main'][0]
+        if ret_all_iters:
+            params['phi_x']['all_iters'] = [p[0] for p in params['phi_x']['all_iters']]
+    returns = [*[val['main'] for val in params.values()], E[:iters + 1]]
+    if ret_all_iters:
+        returns.extend([np.array(val['all_iters']) for val in params.values()])
+    return returns
+
+
+# --------------------------------------------------------------------------- #
+# scoring helpers  (p2w:192-216, 98-111)
+# --------------------------------------------------------------------------- #
+def transform_obs(X, C, Theta, phi_x, W, H, i, j, delete_back_points=True,
+                  delete_boundary_points=False):
+    """`transform` (p2w:192-216) evaluated on the pairs (i, j) only: model pixels [V,2] with
+    NaN behind the camera and, optionally, outside the frame."""
+    R = ryxz(Theta)
+    d = X[i] - C[j]
+    q = np.einsum('vl,vlk->vk', d, R[j])
+    if delete_back_points:
+        q[q[:, 2] <= 0] = np.nan
+    with np.errstate(divide='ignore', invalid='ignore'):
+        model = (W / np.tan(phi_x / 2.0) * q[:, :2] / q[:, 2:3] + np.array([W, H])) / 2.0
+    if delete_boundary_points:
+        out = (model[:, 0] < 0) | (model[:, 0] >= W) | (model[:, 1] < 0) | (model[:, 1] >= H)
+        model[out] = np.nan
+    return model
+
+
+def transform_dense(X, C, Theta, phi_x, W, H, delete_back_points=True,
+                    delete_boundary_points=False):
+    """`transform` (p2w:192-216) for all N*K pairs, shape (N, K, 2)."""
+    N, K = X.shape[0], C.shape[0]
+    ii, jj = np.divmod(np.arange(N * K), K)
+    return transform_obs(X, C, Theta, phi_x, W, H, ii, jj, delete_back_points,
+                         delete_boundary_points).reshape(N, K, 2)
+
+
+def error(X_pix, X_model):
+    """Energy on the pairs visible in both the data and the model (p2w:98-111)."""
+    vis = (X_pix[:, :, 0] >= 0) & ~np.isnan(X_model[:, :, 0])
+    diff = X_model[vis].ravel() - (X_pix[vis].ravel() + 0.5)
+    return np.dot(diff, diff) / (2 * vis.sum())

@@ -1,0 +1,343 @@
+"""Generate the golden vectors under tests/golden/ by running the reference itself.
+
+Runs ONLY in the build container (it imports /root/reference/modules/pix2world.py, which
+never travels to the GPU box).  What is committed is data: inputs and the reference's
+outputs, as .npz / .json.  Nothing of the reference's source is written anywhere.
+
+    MPLBACKEND=Agg python oracle/capture_golden.py [--out tests/golden]
+
+Capture hooks (no reference source is touched):
+  * `gd_func_dict[optimizer]` is looked up by name on every step (p2w:705): a recording
+    wrapper placed in that registry sees (parameters, gradient) of every group in the order
+    X, C, Theta, phi_x and forwards to the original update rule;
+  * the module-level name `lr_manager` (called at p2w:617) is wrapped to record the iteration
+    counter on entry/exit and whether a rollback happened;
+  * stdout is captured for the LR-event / stop-reason lines (p2w:405, 430, 626-641).
+"""
+from __future__ import annotations
+
+import argparse
+import contextlib
+import io
+import json
+import os
+import pickletools
+import sys
+
+import numpy as np
+
+REF_DIR = '/root/reference'
+sys.path.insert(0, os.path.join(REF_DIR, 'modules'))
+os.environ.setdefault('MPLBACKEND', 'Agg')
+import pix2world as p  # noqa: E402  (the reference)
+
+
+# --------------------------------------------------------------------------- #
+def make_scene(N, K, seed, vis_frac=1.0, W=1920, H=1080, phi_x=1.2):
+    """Synthetic scene from the reference's own generators (p2w:2338-2427) plus a visibility
+    drop mask and a noisy initial guess."""
+    C, R = p.generate_cameras(K, r_min=4, r_max=6, theta_min=np.pi / 3, theta_max=2 * np.pi / 3,
+                              seed=seed)
+    Theta = p.get_rotations(R)
+    AR, ARC = p.form_view_matrices(C, R, W=W, H=H, phi_x=phi_x)
+    vb = p.find_bounding_box(AR.reshape(-1, 3), ARC.ravel())
+    X = p.generate_points(N, AR, ARC, vb, np.array([[-10, 10]] * 3, dtype=float), seed=seed + 1)
+    model = p.transform(X, C, Theta, phi_x, W, H, delete_boundary_points=True)
+    X_pix = np.where(np.isnan(model), -1, np.floor(model)).astype(np.int32)
+    if vis_frac < 1.0:
+        drop = np.random.default_rng(seed + 2).random((N, K)) > vis_frac
+        X_pix[drop] = -1
+    rng = np.random.default_rng(5)
+    X0 = X + rng.normal(0, 0.05, X.shape)
+    C0 = C + rng.normal(0, 0.05, C.shape)
+    Th0 = Theta + rng.normal(0, 0.01, Theta.shape)
+    return dict(X_pix=X_pix, W=W, H=H, X_true=X, C_true=C, Theta_true=Theta, phi_true=phi_x,
+                X_0=X0, C_0=C0, Theta_0=Th0, phi_x_0=phi_x * 1.02)
+
+
+def run_reference(scene, lr, max_iters, optimizer='Adam', masks=(True, True, True), **kw):
+    """Run p.fit_scene with the recording hooks installed; returns a dict of arrays."""
+    steps = []          # one entry per executed update: {'X':(x,g), 'C':..., ...}
+    cur = {}
+    names = []
+    if masks[0]:
+        names.append('X')
+    if masks[1]:
+        names.extend(['C', 'Theta'])
+    if masks[2]:
+        names.append('phi_x')
+    orig_update = p.gd_func_dict[optimizer]
+    orig_manager = p.lr_manager
+    manager_calls = []
+
+    def rec_update(x, grad, lr_, **state):
+        name = names[len(cur)]
+        cur[name] = (np.array(x, dtype=np.float64).copy(), np.array(grad, dtype=np.float64).copy())
+        if len(cur) == len(names):
+            steps.append(dict(cur))
+            cur.clear()
+        return orig_update(x, grad, lr_, **state)
+
+    def rec_manager(lr_, iters, *a, **k):
+        res = orig_manager(lr_, iters, *a, **k)
+        manager_calls.append((iters, res[0][1], len(res[1]), float(res[0][0])))
+        return res
+
+    p.gd_func_dict[optimizer] = rec_update
+    p.lr_manager = rec_manager
+    out = io.StringIO()
+    try:
+        with contextlib.redirect_stdout(out):
+            ret = p.fit_scene(scene['X_pix'], scene['W'], scene['H'], lr, max_iters,
+                              scene['X_0'], scene['C_0'], scene['Theta_0'], scene['phi_x_0'],
+                              X_mask=masks[0], C_Theta_mask=masks[1], phi_x_mask=masks[2],
+                              optimizer=optimizer, **kw)
+    finally:
+        p.gd_func_dict[optimizer] = orig_update
+        p.lr_manager = orig_manager
+    res = {'E': np.asarray(ret[len(names)]), 'log': out.getvalue().splitlines(),
+           'manager_calls': np.array(manager_calls, dtype=np.float64).reshape(-1, 4)}
+    for n, v in zip(names, ret[:len(names)]):
+        res['final_' + n] = np.asarray(v, dtype=np.float64)
+    for n in names:
+        res['step_' + n] = np.array([s[n][0] for s in steps])
+        res['grad_' + n] = np.array([s[n][1] for s in steps])
+    return res
+
+
+def save_npz(path, **arrays):
+    clean = {}
+    for k, v in arrays.items():
+        if isinstance(v, (list, tuple)) and v and isinstance(v[0], str):
+            v = np.array(v)
+        clean[k] = v
+    np.savez_compressed(path, **clean)
+    print('wrote', path, f'{os.path.getsize(path) / 1024:.1f} KiB')
+
+
+# --------------------------------------------------------------------------- #
+def capture_f1(out):
+    """Tiny dense-API scene, every mask combination x {Adam, SGD}, 4 iterations."""
+    sc = make_scene(60, 15, seed=3, vis_frac=0.6)
+    arrays = {k: sc[k] for k in ('X_pix', 'X_0', 'C_0', 'Theta_0')}
+    arrays['W'], arrays['H'], arrays['phi_x_0'] = sc['W'], sc['H'], sc['phi_x_0']
+    combos = [(a, b, c) for a in (True, False) for b in (True, False) for c in (True, False)
+              if a or b or c]
+    for opt in ('Adam', 'SGD'):
+        lr = 1e-3 if opt == 'Adam' else 1e-7
+        for m in combos:
+            tag = f"{opt}_{''.join('1' if t else '0' for t in m)}"
+            r = run_reference(sc, lr=lr, max_iters=5, optimizer=opt, masks=m)
+            for k, v in r.items():
+                if k != 'log':
+                    arrays[f'{tag}__{k}'] = v
+            arrays[f'{tag}__log'] = np.array(r['log'])
+    arrays['combos'] = np.array(combos)
+    save_npz(os.path.join(out, 'f1_tiny_masks.npz'), **arrays)
+
+
+def moscow_init(X_pix, W, H):
+    """Deterministic initial guess for the moscow_ride tracks: cameras on a line along z,
+    identity rotations, phi_x = 1.7, every point on the ray through its first visible pixel
+    at depth 5 (direction from the reference's reverse_project, p2w:164-189)."""
+    N, K = X_pix.shape[:2]
+    C0 = np.zeros((K, 3))
+    C0[:, 2] = 0.01 * np.arange(K)
+    Th0 = np.zeros((K, 3))
+    phi0 = 1.7
+    rays = p.reverse_project(X_pix, C0, Th0, phi0, W, H, dir_only=True)
+    first = np.argmax(X_pix[:, :, 0] >= 0, axis=1)
+    X0 = C0[first] + 5.0 * rays[np.arange(N), first]
+    return X0, C0, Th0, phi0
+
+
+def read_tracks_pickle(path):
+    """Read the demo's `(X_pix ndarray, W, H)` pickle WITHOUT unpickling it: the opcode stream
+    is only disassembled (pickletools.genops executes nothing) and the array is rebuilt from
+    its shape tuple, dtype string and raw byte payload."""
+    with open(path, 'rb') as fh:
+        data = fh.read()
+    ints, strs, payload, shape = [], [], None, None
+    for op, arg, _ in pickletools.genops(data):
+        if op.name in ('BININT', 'BININT1', 'BININT2', 'LONG1'):
+            ints.append(int(arg))
+        elif op.name in ('SHORT_BINUNICODE', 'BINUNICODE'):
+            strs.append(arg)
+        elif op.name in ('BINBYTES', 'BINBYTES8') and payload is None:
+            payload = arg
+            after_payload = len(ints)
+        elif op.name == 'TUPLE3' and shape is None and len(ints) >= 4:
+            shape = tuple(ints[-3:])       # first 3-tuple of ints after the class triple
+    allowed = {'numpy.core.multiarray', 'numpy._core.multiarray', '_reconstruct', 'numpy',
+               'ndarray', 'dtype', 'i4', '<'}
+    if payload is None or shape is None or not set(strs) <= allowed or 'i4' not in strs:
+        raise ValueError('unexpected pickle layout in ' + path)
+    X_pix = np.frombuffer(payload, dtype='<i4').reshape(shape).copy()
+    W, H = ints[after_payload:after_payload + 2]
+    return X_pix, W, H
+
+
+def capture_f2(out):
+    """moscow_ride demo tracks (the reference's only real data set)."""
+    X_pix, W, H = read_tracks_pickle(os.path.join(REF_DIR, 'demo_examples/moscow_ride/input.txt'))
+    X0, C0, Th0, phi0 = moscow_init(X_pix, W, H)
+    sc = dict(X_pix=X_pix, W=W, H=H, X_0=X0, C_0=C0, Theta_0=Th0, phi_x_0=phi0)
+    vis = X_pix[:, :, 0] >= 0
+    ii, jj = np.nonzero(vis)
+    short = run_reference(sc, lr=1e-3, max_iters=51, patience=1000)
+    long_ = run_reference(sc, lr=1e-3, max_iters=300, patience=1000)
+    arrays = dict(N=X_pix.shape[0], K=X_pix.shape[1], W=W, H=H,
+                  obs_i=ii.astype(np.int32), obs_j=jj.astype(np.int32),
+                  obs_xy=X_pix[vis].astype(np.int32),
+                  X_0=X0, C_0=C0, Theta_0=Th0, phi_x_0=phi0)
+    for k, v in short.items():
+        arrays['tf__' + k] = np.array(v) if k == 'log' else v
+    for k in ('E', 'final_X', 'final_C', 'final_Theta', 'final_phi_x', 'manager_calls'):
+        arrays['free__' + k] = long_[k]
+    arrays['free__log'] = np.array(long_['log'])
+    save_npz(os.path.join(out, 'f2_moscow_ride.npz'), **arrays)
+
+
+def capture_f3(out):
+    """LR-event run: small patience so that increases / decreases / rollbacks all fire."""
+    sc = make_scene(50, 12, seed=7, vis_frac=1.0)
+    r = run_reference(sc, lr=1e-3, max_iters=200, patience=20)
+    arrays = {k: sc[k] for k in ('X_pix', 'X_0', 'C_0', 'Theta_0')}
+    arrays['W'], arrays['H'], arrays['phi_x_0'] = sc['W'], sc['H'], sc['phi_x_0']
+    for k, v in r.items():
+        arrays[k] = np.array(v) if k == 'log' else v
+    save_npz(os.path.join(out, 'f3_lr_events.npz'), **arrays)
+
+
+def capture_f4(out):
+    """lr_manager on scripted energy sequences with a counting recompute function."""
+    rng = np.random.default_rng(11)
+    cases = []
+    for case in range(40):
+        n = int(rng.integers(5, 60))
+        patience = int(rng.integers(0, 5))
+        factor = float(rng.choice([2.0, 3.0, 1.5]))
+        kind = case % 4
+        if kind == 0:
+            E = np.cumsum(rng.normal(-0.1, 1.0, n)) + 50.0
+        elif kind == 1:
+            E = 100.0 * np.exp(-0.1 * np.arange(n)) * (1 + 0.3 * rng.random(n))
+        elif kind == 2:
+            E = rng.integers(0, 6, n).astype(float)          # many exact ties
+        else:
+            E = 10.0 + np.abs(rng.normal(0, 1, n)).cumsum()  # never improves
+        params = {'a': {'main': np.zeros(3)}, 'b': {'main': np.zeros(1)}}
+        p.form_params_dict(params, 'Adam', True, 4 * n + 8)
+        calls = [0]
+
+        def func(tag, calls=calls):
+            calls[0] += 1
+            return (tag,), {}
+
+        lr, iters = 1.0, 0
+        E_arr = np.zeros(4 * n + 8)
+        E_min = E_min_temp = np.inf
+        pt, st, began, inc = 0, patience, False, False
+        trace = []
+        out_io = io.StringIO()
+        with contextlib.redirect_stdout(out_io):
+            for step in range(n):
+                E_arr[iters] = E[step]
+                # emulate the optimiser touching the state between calls
+                for val in params.values():
+                    val['main'] += 1.0
+                    val['gd']['s'] += 0.5
+                    val['gd']['t'] += 1
+                tup, lst = p.lr_manager(lr, iters, E_arr, E_min, E_min_temp, pt, st, began, inc,
+                                        patience, factor, params, True, func, ('x',), {})
+                lr, iters, E_min, E_min_temp, pt, st, began, inc = tup
+                trace.append(dict(lr=float(lr), iters=int(iters), E_min=float(E_min),
+                                  E_min_temp=float(E_min_temp), patience_timer=int(pt),
+                                  success_timer=int(st), began=bool(began), increased=bool(inc),
+                                  recomputed=len(lst),
+                                  main_a=params['a']['main'].tolist(),
+                                  release_a=params['a']['release'].tolist(),
+                                  s_a=params['a']['gd']['s'].tolist(),
+                                  t_a=int(params['a']['gd']['t'][0])))
+                iters += 1
+        cases.append(dict(E=E.tolist(), patience=patience, factor=factor, trace=trace,
+                          log=out_io.getvalue().splitlines(), recompute_calls=calls[0]))
+    path = os.path.join(out, 'f4_lr_manager.json')
+    with open(path, 'w') as fh:
+        json.dump(cases, fh)
+    print('wrote', path, f'{os.path.getsize(path) / 1024:.1f} KiB')
+
+
+def capture_f5(out):
+    """Gauge / rotation / optimiser / scoring functions called stand-alone."""
+    rng = np.random.default_rng(21)
+    K, N = 9, 14
+    Theta = rng.uniform(-1.2, 1.2, (K, 3))
+    X = rng.normal(0, 3, (N, 3))
+    C = rng.normal(0, 2, (K, 3))
+    R = p.ryxz(Theta)
+    Xa, Ca, Tha, Ra = p.align_scene(X, C, Theta=Theta, ret_R=True)
+    Xn, Cn, j1 = p.normalize_scene(Xa, Ca, ret_j=True)
+    x = rng.normal(0, 1, (N, 3))
+    g = rng.normal(0, 1, (N, 3))
+    s = rng.normal(0, 0.1, (N, 3))
+    r = rng.random((N, 3))
+    xa, st = p.gd_adam(x, g, 1e-2, s, r, np.array([3]))
+    xs, _ = p.sgd(x, g, 1e-2)
+    # transform / error on a scene with points behind cameras and outside the frame
+    W, H, phi = 640, 480, 1.1
+    Xt = rng.normal(0, 4, (N, 3))
+    Ct = rng.normal(0, 1, (K, 3))
+    T1 = p.transform(Xt, Ct, Theta, phi, W, H)
+    T2 = p.transform(Xt, Ct, Theta, phi, W, H, delete_boundary_points=True)
+    T3 = p.transform(Xt, Ct, Theta, phi, W, H, delete_back_points=False)
+    Xp = np.where(np.isnan(T2), -1, np.floor(T2)).astype(np.int32)
+    Xp[rng.random((N, K)) > 0.8] = -1
+    err1 = p.error(Xp, T1)
+    err2 = p.error(Xp, p.transform(Xt + 0.01, Ct, Theta, phi, W, H))
+    save_npz(os.path.join(out, 'f5_gauge_funcs.npz'),
+             Theta=Theta, X=X, C=C, R=R, Rx=p.rx(Theta[:, 0]), Ry=p.ry(Theta[:, 1]),
+             Rz=p.rz(Theta[:, 2]), Theta_back=p.get_rotations(R),
+             align_X=Xa, align_C=Ca, align_Theta=Tha, align_R=Ra,
+             norm_X=Xn, norm_C=Cn, norm_j1=j1,
+             adam_x=x, adam_g=g, adam_s=s, adam_r=r, adam_x_new=xa, adam_s_new=st['s'],
+             adam_r_new=st['r'], adam_t_new=st['t'], sgd_x_new=xs,
+             tr_X=Xt, tr_C=Ct, tr_W=W, tr_H=H, tr_phi=phi, tr_default=T1, tr_boundary=T2,
+             tr_keep_back=T3, err_X_pix=Xp, err_value=err1, err_value_shifted=err2)
+
+
+def capture_f6(out):
+    """Medium scene, 500 free-running iterations with LR events (patience 100)."""
+    sc = make_scene(2000, 40, seed=13, vis_frac=0.5)
+    r = run_reference(sc, lr=1e-3, max_iters=500, patience=100)
+    vis = sc['X_pix'][:, :, 0] >= 0
+    ii, jj = np.nonzero(vis)
+    keep = [0, 1, 2, 3, 50, 150, 300, 498]
+    arrays = dict(N=2000, K=40, W=sc['W'], H=sc['H'], obs_i=ii.astype(np.int32),
+                  obs_j=jj.astype(np.int32), obs_xy=sc['X_pix'][vis].astype(np.int32),
+                  X_0=sc['X_0'], C_0=sc['C_0'], Theta_0=sc['Theta_0'], phi_x_0=sc['phi_x_0'],
+                  E=r['E'], log=np.array(r['log']), manager_calls=r['manager_calls'],
+                  final_X=r['final_X'], final_C=r['final_C'], final_Theta=r['final_Theta'],
+                  final_phi_x=r['final_phi_x'], keep=np.array(keep))
+    for n in ('X', 'C', 'Theta', 'phi_x'):
+        arrays['step_' + n] = r['step_' + n][keep]
+        arrays['grad_' + n] = r['grad_' + n][keep]
+    save_npz(os.path.join(out, 'f6_medium.npz'), **arrays)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--out', default=os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden'))
+    ap.add_argument('--only', default='')
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    todo = dict(f1=capture_f1, f2=capture_f2, f3=capture_f3, f4=capture_f4, f5=capture_f5,
+                f6=capture_f6)
+    for name, fn in todo.items():
+        if a.only and name not in a.only.split(','):
+            continue
+        fn(a.out)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,39 @@
+"""Shared test plumbing: path set-up, the `gpu` marker, golden-file access."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+@pytest.fixture(scope='session')
+def golden():
+    cache = {}
+
+    def load(name):
+        if name not in cache:
+            cache[name] = np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+        return cache[name]
+    return load
+
+
+@pytest.fixture(scope='session')
+def ba():
+    """The product package (its directory name starts with a digit, hence importlib)."""
+    return importlib.import_module('3d_reconstruction_amd')
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    scale = max(np.abs(b).max(), 1e-300)
+    return np.abs(a - b).max() / scale

@@ -1,0 +1,209 @@
+"""Pins the CPU oracle (oracle/ba_oracle.py) against vectors captured from the reference
+itself (oracle/capture_golden.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, rel_err
+from oracle import ba_oracle as orc
+
+TOL = 1e-9       # per-iteration energy / gradient contract (relative, max-norm)
+
+
+def test_f5_rotations_gauge_adam(golden):
+    g = golden('f5_gauge_funcs.npz')
+    Th = g['Theta']
+    assert np.array_equal(orc.rx(Th[:, 0]), g['Rx'])
+    assert np.array_equal(orc.ry(Th[:, 1]), g['Ry'])
+    assert np.array_equal(orc.rz(Th[:, 2]), g['Rz'])
+    assert np.array_equal(orc.ryxz(Th), g['R'])
+    assert np.array_equal(orc.get_rotations(g['R']), g['Theta_back'])
+    Xa, Ca, Tha, Ra = orc.align_scene(g['X'], g['C'], Theta=Th, ret_R=True)
+    for a, b in ((Xa, g['align_X']), (Ca, g['align_C']), (Tha, g['align_Theta']), (Ra, g['align_R'])):
+        assert np.array_equal(a, b)
+    Xn, Cn, j1 = orc.normalize_scene(Xa, Ca, ret_j=True)
+    assert j1 == int(g['norm_j1'])
+    assert np.array_equal(Xn, g['norm_X']) and np.array_equal(Cn, g['norm_C'])
+    xa, st = orc.gd_adam(g['adam_x'], g['adam_g'], 1e-2, g['adam_s'], g['adam_r'], np.array([3]))
+    assert np.array_equal(xa, g['adam_x_new'])
+    assert np.array_equal(st['s'], g['adam_s_new']) and np.array_equal(st['r'], g['adam_r_new'])
+    assert int(st['t'][0]) == int(g['adam_t_new'][0])
+    assert np.array_equal(orc.sgd(g['adam_x'], g['adam_g'], 1e-2)[0], g['sgd_x_new'])
+
+
+def test_f5_transform_and_error(golden):
+    g = golden('f5_gauge_funcs.npz')
+    W, H, phi = int(g['tr_W']), int(g['tr_H']), float(g['tr_phi'])
+    args = (g['tr_X'], g['tr_C'], g['Theta'], phi, W, H)
+    for kw, key in ((dict(), 'tr_default'), (dict(delete_boundary_points=True), 'tr_boundary'),
+                    (dict(delete_back_points=False), 'tr_keep_back')):
+        got, want = orc.transform_dense(*args, **kw), g[key]
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        assert np.allclose(got, want, rtol=1e-12, atol=1e-9, equal_nan=True)
+    assert orc.error(g['err_X_pix'], g['tr_default']) == pytest.approx(float(g['err_value']), rel=1e-13)
+    shifted = orc.transform_dense(g['tr_X'] + 0.01, g['tr_C'], g['Theta'], phi, W, H)
+    assert orc.error(g['err_X_pix'], shifted) == pytest.approx(float(g['err_value_shifted']), rel=1e-12)
+
+
+def test_visibility_indexing_bit_exact(golden):
+    g = golden('f2_moscow_ride.npz')
+    N, K = int(g['N']), int(g['K'])
+    X_pix = np.full((N, K, 2), -1, dtype=np.int32)
+    X_pix[g['obs_i'], g['obs_j']] = g['obs_xy']
+    i, j, uv = orc.visibility_coo(X_pix)
+    assert np.array_equal(i, g['obs_i']) and np.array_equal(j, g['obs_j'])
+    assert np.array_equal(uv, g['obs_xy'] + 0.5)
+    assert i.size == 7933
+    assert orc.count_components(i, j, N, K) == 1
+
+
+def test_f4_lr_manager_scripted():
+    with open(os.path.join(GOLDEN, 'f4_lr_manager.json')) as fh:
+        cases = json.load(fh)
+    for case in cases:
+        E, patience, factor = np.array(case['E']), case['patience'], case['factor']
+        n = E.size
+        params = {'a': {'main': np.zeros(3)}, 'b': {'main': np.zeros(1)}}
+        orc.form_params_dict(params, 'Adam', True, 4 * n + 8)
+        calls = [0]
+
+        def recompute():
+            calls[0] += 1
+            return ('x',), {}
+
+        lr, iters = 1.0, 0
+        E_arr = np.zeros(4 * n + 8)
+        E_min = E_min_temp = np.inf
+        pt, st, began, inc = 0, patience, False, False
+        log = []
+        for step in range(n):
+            E_arr[iters] = E[step]
+            for val in params.values():
+                val['main'] += 1.0
+                val['gd']['s'] += 0.5
+                val['gd']['t'] += 1
+            tup, lst = orc.lr_manager(lr, iters, E_arr, E_min, E_min_temp, pt, st, began, inc,
+                                      patience, factor, params, True, recompute, log=log)
+            lr, iters, E_min, E_min_temp, pt, st, began, inc = tup
+            want = case['trace'][step]
+            got = dict(lr=float(lr), iters=int(iters), E_min=float(E_min),
+                       E_min_temp=float(E_min_temp), patience_timer=int(pt), success_timer=int(st),
+                       began=bool(began), increased=bool(inc), recomputed=len(lst),
+                       main_a=params['a']['main'].tolist(), release_a=params['a']['release'].tolist(),
+                       s_a=params['a']['gd']['s'].tolist(), t_a=int(params['a']['gd']['t'][0]))
+            assert got == want, (step, got, want)
+            iters += 1
+        assert log == case['log']
+        assert calls[0] == case['recompute_calls']
+
+
+def _coo(X_pix):
+    return orc.visibility_coo(X_pix)
+
+
+@pytest.mark.parametrize('opt', ['Adam', 'SGD'])
+def test_f1_all_mask_combinations(golden, opt):
+    g = golden('f1_tiny_masks.npz')
+    X_pix = g['X_pix']
+    N, K = X_pix.shape[:2]
+    i, j, uv = _coo(X_pix)
+    W, H = int(g['W']), int(g['H'])
+    lr = 1e-3 if opt == 'Adam' else 1e-7
+    for m in g['combos']:
+        m = tuple(bool(t) for t in m)
+        tag = f"{opt}_{''.join('1' if t else '0' for t in m)}"
+        glog, log = [], []
+        out = orc.fit_scene(i, j, uv, N, K, W, H, lr, 5, g['X_0'], g['C_0'], g['Theta_0'],
+                            float(g['phi_x_0']), X_mask=m[0], C_Theta_mask=m[1], phi_x_mask=m[2],
+                            optimizer=opt, log=log, grad_log=glog)
+        names = (['X'] if m[0] else []) + (['C', 'Theta'] if m[1] else []) + (['phi_x'] if m[2] else [])
+        assert len(out) == len(names) + 1
+        assert rel_err(out[-1], g[f'{tag}__E']) < TOL
+        for n, v in zip(names, out):
+            assert np.abs(np.asarray(v) - g[f'{tag}__final_{n}']).max() < 1e-9, (tag, n)
+        per_step = len(names)
+        for s in range(len(glog) // per_step):
+            for k, n in enumerate(names):
+                name, x, grad = glog[s * per_step + k]
+                assert name == n
+                assert np.abs(x - g[f'{tag}__step_{n}'][s]).max() < 1e-9
+                assert rel_err(grad, g[f'{tag}__grad_{n}'][s]) < TOL, (tag, n, s)
+        assert log == [ln for ln in g[f'{tag}__log'].tolist() if 'Reached' in ln]
+
+
+def test_f2_moscow_teacher_forced(golden):
+    g = golden('f2_moscow_ride.npz')
+    W, H = int(g['W']), int(g['H'])
+    i, j = g['obs_i'], g['obs_j']
+    uv = g['obs_xy'] + 0.5
+    steps = g['tf__step_X'].shape[0]
+    assert steps == 50
+    worst = 0.0
+    for s in range(steps):
+        E, gX, gC, gT, gp = orc.energy_and_gradients(
+            g['tf__step_X'][s], g['tf__step_C'][s], g['tf__step_Theta'][s], g['tf__step_phi_x'][s],
+            W, H, i, j, uv)
+        errs = (abs(E - g['tf__E'][s]) / g['tf__E'][s], rel_err(gX, g['tf__grad_X'][s]),
+                rel_err(gC, g['tf__grad_C'][s]), rel_err(gT, g['tf__grad_Theta'][s]),
+                rel_err(gp, g['tf__grad_phi_x'][s]))
+        worst = max(worst, *errs)
+    assert worst < TOL, worst
+
+
+def test_f2_moscow_free_run_300(golden):
+    g = golden('f2_moscow_ride.npz')
+    W, H = int(g['W']), int(g['H'])
+    log = []
+    X, C, Th, phi, E = orc.fit_scene(g['obs_i'], g['obs_j'], g['obs_xy'] + 0.5, int(g['N']), int(g['K']),
+                                     W, H, 1e-3, 300, g['X_0'], g['C_0'], g['Theta_0'],
+                                     float(g['phi_x_0']), patience=1000, log=log)
+    assert E.shape == g['free__E'].shape
+    assert rel_err(E, g['free__E']) < 1e-8
+    assert np.abs(X - g['free__final_X']).max() < 1e-6
+    assert np.abs(C - g['free__final_C']).max() < 1e-6
+    assert np.abs(Th - g['free__final_Theta']).max() < 1e-6
+    assert abs(phi - float(g['free__final_phi_x'])) < 1e-6
+    assert log == ['299 : Reached maximum iterations']
+
+
+def test_f3_lr_events(golden):
+    g = golden('f3_lr_events.npz')
+    X_pix = g['X_pix']
+    N, K = X_pix.shape[:2]
+    i, j, uv = _coo(X_pix)
+    log, glog = [], []
+    out = orc.fit_scene(i, j, uv, N, K, int(g['W']), int(g['H']), 1e-3, 200, g['X_0'], g['C_0'],
+                        g['Theta_0'], float(g['phi_x_0']), patience=20, log=log, grad_log=glog)
+    want = [ln for ln in g['log'].tolist() if ('LR' in ln or 'Reached' in ln)]
+    assert log == want
+    assert len(glog) // 4 == g['step_X'].shape[0]       # same number of executed updates
+    E = out[-1]
+    assert E.shape == g['E'].shape
+    assert rel_err(E[:100], g['E'][:100]) < 1e-8
+    # teacher-forced gradients at the reference's own iterates, rollback steps included
+    for s in range(0, g['step_X'].shape[0], 7):
+        _, gX, gC, gT, gp = orc.energy_and_gradients(g['step_X'][s], g['step_C'][s], g['step_Theta'][s],
+                                                     g['step_phi_x'][s], int(g['W']), int(g['H']), i, j, uv)
+        assert rel_err(gX, g['grad_X'][s]) < TOL and rel_err(gC, g['grad_C'][s]) < TOL
+        assert rel_err(gT, g['grad_Theta'][s]) < TOL and rel_err(gp, g['grad_phi_x'][s]) < TOL
+
+
+def test_f6_medium_scene(golden):
+    g = golden('f6_medium.npz')
+    i, j = g['obs_i'], g['obs_j']
+    uv = g['obs_xy'] + 0.5
+    W, H = int(g['W']), int(g['H'])
+    for n, s in enumerate(g['keep']):
+        E, gX, gC, gT, gp = orc.energy_and_gradients(g['step_X'][n], g['step_C'][n], g['step_Theta'][n],
+                                                     g['step_phi_x'][n], W, H, i, j, uv)
+        assert rel_err(gX, g['grad_X'][n]) < TOL and rel_err(gC, g['grad_C'][n]) < TOL
+        assert rel_err(gT, g['grad_Theta'][n]) < TOL and rel_err(gp, g['grad_phi_x'][n]) < TOL
+    log = []
+    out = orc.fit_scene(i, j, uv, int(g['N']), int(g['K']), W, H, 1e-3, 500, g['X_0'], g['C_0'],
+                        g['Theta_0'], float(g['phi_x_0']), patience=100, log=log)
+    want = [ln for ln in g['log'].tolist() if ('LR' in ln or 'Reached' in ln)]
+    assert log == want
+    assert rel_err(out[-1][:100], g['E'][:100]) < 1e-8
+    assert np.abs(out[0] - g['final_X']).max() < 1e-3      # 500 free iterations with 8 LR events
