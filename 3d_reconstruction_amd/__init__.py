@@ -1,0 +1,13 @@
+"""MI355X-native bundle adjustment behind the entry points of OlegRokin/3D_reconstruction's
+`modules/pix2world.py` (fit_scene path).  The directory name starts with a digit; import it as
+
+    ba = importlib.import_module('3d_reconstruction_amd')
+
+The compute path needs libba_mi355x.so (built in-tree by `__graft_entry__.build()`) and a GPU;
+there is no CPU fallback."""
+from .pix2world import (error, fit_scene, fit_scene_sparse, gd_func_dict, transform,  # noqa: F401
+                        validate_scene_parameters)
+from .fit_loop import SceneFit  # noqa: F401
+from . import engine, scenes, sharding  # noqa: F401
+
+__version__ = '0.1.0'

@@ -1,0 +1,79 @@
+"""ctypes binding of libba_mi355x.so (declarations: include/ba_mi355x.h).
+
+There is no fallback: if the library has not been built, importing the compute path raises.
+`import torch` happens first on purpose so that the HIP runtime the library binds to is the
+one PyTorch already loaded (both carry the soname libamdhip64.so.7)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede the library load, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libba_mi355x.so')
+
+# enum ba_eval_flags
+EVAL_GRAD_X, EVAL_GRAD_CAM, EVAL_GRAD_PHI, EVAL_JTJ, EVAL_CAM_ATOMICS, EVAL_TIMED = 1, 2, 4, 8, 16, 32
+
+_p = C.c_void_p
+_i64 = C.c_int64
+_dbl = C.c_double
+_int = C.c_int
+
+# name -> (restype, argtypes); every symbol include/ba_mi355x.h declares
+SIGNATURES = {
+    'ba_last_error': (C.c_char_p, []),
+    'ba_version': (_int, []),
+    'ba_device_info': (_int, [_int, C.POINTER(_int), C.POINTER(_int)]),
+    'ba_visibility_count': (_int, [_p, _i64, _i64, _p, C.POINTER(_i64), _p]),
+    'ba_visibility_fill': (_int, [_p, _i64, _i64, _p, _p, _p, _p, _p]),
+    'ba_problem_create': (_int, [_i64, _i64, _i64, _p, _p, _p, _dbl, _dbl, _int, C.POINTER(_p)]),
+    'ba_problem_destroy': (_int, [_p]),
+    'ba_eval': (_int, [_p, _p, _p, _p, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    'ba_eval_timing': (_int, [_p, C.POINTER(C.c_float), _int, C.POINTER(_int)]),
+    'ba_adam_step': (_int, [_i64, _p, _p, _p, _p, _dbl, _dbl, _dbl, _dbl, _p]),
+    'ba_sgd_step': (_int, [_i64, _p, _p, _dbl, _dbl, _p]),
+    'ba_gauge_fix': (_int, [_i64, _i64, _p, _p, _p, _p, _p, _p]),
+    'ba_project': (_int, [_i64, _i64, _i64, _p, _p, _p, _p, _p, _dbl, _dbl, _dbl, _int, _int, _p, _p]),
+    'ba_reprojection_error': (_int, [_i64, _p, _p, _p, _p]),
+}
+
+_lib = None
+
+
+class BAError(RuntimeError):
+    """A call into libba_mi355x.so returned a negative status."""
+
+
+def load():
+    """Load the library (once) and declare every entry point's signature."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f'{LIB_PATH} is missing: build it first (python -c "import __graft_entry__ as g; g.build()" '
+            f'or make -C {os.path.dirname(LIB_PATH)}). There is no CPU fallback.')
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != 0:
+        msg = load().ba_last_error()
+        raise BAError(f'libba_mi355x status {status}: {msg.decode() if msg else "?"}')
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,71 @@
+// Shared declarations of the MI355X bundle-adjustment engine (internal; the public C ABI is
+// include/ba_mi355x.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "ba_mi355x.h"
+
+namespace ba {
+
+// One row of the per-camera table (16 doubles = one 128-byte L2 line):
+//   [0..8]  R = Ry(theta_y) Rx(theta_x) Rz(theta_z), row-major      (p2w:138-140)
+//   [9..11] camera centre C
+//   [12]    cos(theta_z)   [13] sin(theta_z)   (rotation axis of theta_x in the camera frame)
+//   [14..15] unused
+constexpr int CAM_ROW = 16;
+
+// Device-resident scalars shared by the kernels of one evaluation.
+//   [0] f = W / (2 tan(phi_x / 2))   (p2w:567)
+//   [1] W/2   [2] H/2
+//   [3] -f / sin(phi_x)              (p2w:701)
+constexpr int SC_F = 0, SC_CX = 1, SC_CY = 2, SC_DPHI = 3, SC_COUNT = 8;
+
+constexpr int EVAL_BLOCK = 1024;          // threads per workgroup of the observation pass
+constexpr int EVAL_WAVES = EVAL_BLOCK / 64;
+constexpr int TIMING_RING = 256;          // event pairs kept for ba_eval_timing
+
+void set_error(const std::string &msg);
+int hip_fail(hipError_t e, const char *what, const char *file, int line);
+
+}  // namespace ba
+
+#define BA_HIP(expr)                                                        \
+    do {                                                                    \
+        hipError_t _e = (expr);                                             \
+        if (_e != hipSuccess) return ba::hip_fail(_e, #expr, __FILE__, __LINE__); \
+    } while (0)
+
+#define BA_REQUIRE(cond, msg)                                               \
+    do {                                                                    \
+        if (!(cond)) { ba::set_error(msg); return BA_ERR_ARG; }             \
+    } while (0)
+
+struct ba_problem {
+    int device = 0;
+    int64_t N = 0, K = 0, nV = 0;
+    double W = 0, H = 0;
+    int compute_units = 0;
+    int lds_limit = 0;            // bytes of LDS one workgroup may use
+    // observation list, point-major (device)
+    int32_t *oi = nullptr, *oj = nullptr;
+    double2 *ouv = nullptr;
+    // per-wave chunk boundaries aligned to point starts (device, n_chunks + 1 entries)
+    int32_t *chunk_begin = nullptr;
+    int n_chunks = 0;
+    int grid = 0;                 // workgroups of the observation pass
+    int64_t n_points_seen = 0;    // points with at least one observation
+    // scratch owned by the handle (device)
+    double *cam_table = nullptr;  // K x CAM_ROW
+    double *cam_sums = nullptr;   // 6 x K camera-frame sums (SoA: component-major)
+    double *partials = nullptr;   // grid*EVAL_WAVES x 2 per-wave partial sums
+    double *scalars = nullptr;    // SC_COUNT
+    int *flag = nullptr;          // 1 int, validation
+    // timing ring
+    std::vector<hipEvent_t> ev_begin, ev_end;
+    int ev_count = 0;
+};

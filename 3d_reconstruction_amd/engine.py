@@ -1,0 +1,170 @@
+"""Device-side state of one bundle-adjustment shard and the kernels that act on it.
+
+PyTorch is used for device memory, streams and (multi-GPU) `torch.distributed`; every
+computation goes through the C ABI of libba_mi355x.so."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr
+from .sharding import allreduce_sum_
+
+F64 = torch.float64
+
+
+def _dev_tensor(a, dtype, device):
+    if isinstance(a, torch.Tensor):
+        return a.to(device=device, dtype=dtype).contiguous()
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device=device, dtype=dtype)
+
+
+def visibility_coo(X_pix, device):
+    """Visibility set of a dense (N,K,2) integer track array, extracted on the GPU in the
+    order `numpy.nonzero(X_pix[:,:,0] >= 0)` produces (p2w:506-508, 531).
+    Returns device tensors (i int32[V], j int32[V], uv float64[V,2])."""
+    lib = _lib.load()
+    pix = _dev_tensor(X_pix, torch.int32, device)
+    N, K = int(pix.shape[0]), int(pix.shape[1])
+    row_ptr = torch.empty(N + 1, dtype=torch.int64, device=device)
+    nV = C.c_int64(0)
+    with torch.cuda.device(device):
+        check(lib.ba_visibility_count(ptr(pix), N, K, ptr(row_ptr), C.byref(nV), stream_ptr()))
+        n = int(nV.value)
+        oi = torch.empty(n, dtype=torch.int32, device=device)
+        oj = torch.empty(n, dtype=torch.int32, device=device)
+        uv = torch.empty((n, 2), dtype=F64, device=device)
+        check(lib.ba_visibility_fill(ptr(pix), N, K, ptr(row_ptr), ptr(oi), ptr(oj), ptr(uv), stream_ptr()))
+    return oi, oj, uv, row_ptr
+
+
+class Shard:
+    """One GPU's share of a scene: a contiguous range of points with all their observations,
+    and a replica of every camera.
+
+    Parameter storage: X (N,3); cam = [C (3K) | Theta (3K) | phi_x (1)] in one buffer so that the
+    camera-side update is one launch.  Reduction buffer: red = [gC (3K) | gTheta (3K) | gphi (1) |
+    sum r^2 (1)], the only thing that crosses GPUs (one all-reduce per evaluation)."""
+
+    def __init__(self, oi, oj, uv, N, K, W, H, device, n_visible_total=None, group=None):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        self.N, self.K, self.W, self.H = int(N), int(K), float(W), float(H)
+        oi = _dev_tensor(oi, torch.int32, self.device)
+        oj = _dev_tensor(oj, torch.int32, self.device)
+        uv = _dev_tensor(uv, F64, self.device)
+        self.nV_local = int(oi.numel())
+        self.nV = int(n_visible_total) if n_visible_total is not None else self.nV_local
+        self.group = group
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(self.lib.ba_problem_create(self.N, self.K, self.nV_local, ptr(oi), ptr(oj), ptr(uv), self.W,
+                                             self.H, self.device.index or 0, C.byref(handle)))
+        self.handle = handle
+        K3 = 3 * self.K
+        z = lambda *s: torch.zeros(*s, dtype=F64, device=self.device)
+        self.X = z(self.N, 3)
+        self.cam = z(2 * K3 + 1)
+        self.C = self.cam[:K3].view(self.K, 3)
+        self.Theta = self.cam[K3:2 * K3].view(self.K, 3)
+        self.phi = self.cam[2 * K3:]
+        self.gX = z(self.N, 3)
+        self.red = z(2 * K3 + 2)
+        self.gC = self.red[:K3].view(self.K, 3)
+        self.gTheta = self.red[K3:2 * K3].view(self.K, 3)
+        self.gphi = self.red[2 * K3:2 * K3 + 1]
+        self.E_sum = self.red[2 * K3 + 1:]
+        self.gauge = z(16)
+        self.R_gauge = z(self.K, 9)
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            self.lib.ba_problem_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- parameters -------------------------------------------------------------------------
+    def set_params(self, X, C_, Theta, phi_x):
+        self.X.copy_(_dev_tensor(X, F64, self.device))
+        self.C.copy_(_dev_tensor(C_, F64, self.device))
+        self.Theta.copy_(_dev_tensor(Theta, F64, self.device))
+        self.phi.fill_(float(phi_x))
+
+    # ---- kernels ----------------------------------------------------------------------------
+    def eval(self, grad_x=True, grad_cam=True, grad_phi=True, timed=False, cam_atomics=False):
+        """One fused observation pass at the current parameters.  Leaves un-normalised gradients
+        in gX / red and returns nothing; `energy()` reads the scalar back."""
+        flags = (_lib.EVAL_GRAD_X if grad_x else 0) | (_lib.EVAL_GRAD_CAM if grad_cam else 0) | \
+                (_lib.EVAL_GRAD_PHI if grad_phi else 0) | (_lib.EVAL_TIMED if timed else 0) | \
+                (_lib.EVAL_CAM_ATOMICS if cam_atomics else 0)
+        with torch.cuda.device(self.device):
+            check(self.lib.ba_eval(self.handle, ptr(self.X), ptr(self.C), ptr(self.Theta), ptr(self.phi), flags,
+                                   ptr(self.E_sum), ptr(self.gX), ptr(self.gC), ptr(self.gTheta), ptr(self.gphi),
+                                   None, None, None, None, stream_ptr()))
+        allreduce_sum_(self.red, self.group)
+
+    def energy(self):
+        """E = sum r^2 / (2|V|) (p2w:612).  One 8-byte device-to-host copy (synchronises)."""
+        return float(self.E_sum.item()) / (2 * self.nV)
+
+    def eval_kernel_ms(self):
+        buf = (C.c_float * 256)()
+        n = C.c_int(0)
+        check(self.lib.ba_eval_timing(self.handle, buf, 256, C.byref(n)))
+        return [buf[k] for k in range(n.value)]
+
+    def adam(self, x, g, s, r, lr, bc1, bc2):
+        with torch.cuda.device(self.device):
+            check(self.lib.ba_adam_step(x.numel(), ptr(x), ptr(g), ptr(s), ptr(r), float(lr), 1.0 / self.nV,
+                                        float(bc1), float(bc2), stream_ptr()))
+
+    def sgd(self, x, g, lr):
+        with torch.cuda.device(self.device):
+            check(self.lib.ba_sgd_step(x.numel(), ptr(x), ptr(g), float(lr), 1.0 / self.nV, stream_ptr()))
+
+    def gauge_fix(self):
+        """align_scene + normalize_scene in place (p2w:710-712)."""
+        with torch.cuda.device(self.device):
+            check(self.lib.ba_gauge_fix(self.N, self.K, ptr(self.X), ptr(self.C), ptr(self.Theta),
+                                        ptr(self.R_gauge), ptr(self.gauge), stream_ptr()))
+
+
+def project(X, C_, Theta, phi_x, W, H, i=None, j=None, delete_back_points=True, delete_boundary_points=False,
+            device='cuda:0'):
+    """Model pixels for a list of (i, j) pairs, or for the dense N x K grid when i is None."""
+    lib = _lib.load()
+    dev = torch.device(device)
+    Xd, Cd, Td = (_dev_tensor(a, F64, dev) for a in (X, C_, Theta))
+    N, K = int(Xd.shape[0]), int(Cd.shape[0])
+    if i is None:
+        n, id_, jd = N * K, None, None
+    else:
+        id_, jd = _dev_tensor(i, torch.int32, dev), _dev_tensor(j, torch.int32, dev)
+        n = int(id_.numel())
+    out = torch.empty((n, 2), dtype=F64, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.ba_project(N, K, n, ptr(id_), ptr(jd), ptr(Xd), ptr(Cd), ptr(Td), float(phi_x), float(W),
+                             float(H), int(bool(delete_back_points)), int(bool(delete_boundary_points)),
+                             ptr(out), stream_ptr()))
+    return out
+
+
+def reprojection_error(pix_xy, model, device='cuda:0'):
+    """(sum of squared pixel differences, number of pairs) over pairs visible in both."""
+    lib = _lib.load()
+    dev = torch.device(device)
+    pix = _dev_tensor(pix_xy, torch.int32, dev).view(-1, 2)
+    mod = _dev_tensor(model, F64, dev).view(-1, 2)
+    sums = torch.zeros(2, dtype=F64, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.ba_reprojection_error(int(pix.shape[0]), ptr(pix), ptr(mod), ptr(sums), stream_ptr()))
+    s = sums.cpu().numpy()
+    return float(s[0]), int(s[1])

@@ -1,0 +1,241 @@
+"""Drop-in entry points for the bundle-adjustment path of the reference's `modules/pix2world.py`
+("p2w"): same names, same arguments, same return packing, same error messages, with the
+arithmetic on an MI355X through libba_mi355x.so.
+
+    fit_scene(...)           p2w:480-726   dense (N,K,2) integer tracks, as the reference takes them
+    fit_scene_sparse(...)    —             same optimisation on a COO observation list (O(|V|) input)
+    transform(...)           p2w:192-216
+    error(...)               p2w:98-111
+    validate_scene_parameters(...)  p2w:21-95
+    gd_func_dict             p2w:362       optimiser names accepted by `optimizer=`
+
+Inputs are never modified; returned arrays are fresh NumPy arrays owned by the caller."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import engine
+from .fit_loop import SceneFit, gd_func_dict  # noqa: F401  (gd_func_dict re-exported)
+from .sharding import partition_points, connected_components_count
+
+__all__ = ['fit_scene', 'fit_scene_sparse', 'transform', 'error', 'validate_scene_parameters', 'gd_func_dict']
+
+
+# --------------------------------------------------------------------------------------------- #
+# validation (p2w:21-95): same checks in the same order with the same messages
+# --------------------------------------------------------------------------------------------- #
+def _check_matrix(name, a):
+    if a.ndim != 2:
+        raise ValueError(f'Expected {name} to have ndim = 2, got {a.ndim}')
+    if a.shape[1] != 3:
+        raise ValueError(f'Expected {name} to have shape[1] = 3, got {a.shape[1]}')
+    if np.isnan(a).any() or np.isinf(a).any():
+        raise ValueError(f'Expected {name} not to have nan or inf values')
+
+
+def validate_scene_parameters(X=None, C=None, Theta=None, R=None, X_pix=None, phi_x=None, ret_shapes=False):
+    N = K = None
+    if X is not None:
+        _check_matrix('X', X)
+        if ret_shapes or X_pix is not None:
+            N = X.shape[0]
+    if C is not None:
+        _check_matrix('C', C)
+        if ret_shapes or Theta is not None or R is not None or X_pix is not None:
+            K = C.shape[0]
+    if Theta is not None:
+        _check_matrix('Theta', Theta)
+        if K is not None and Theta.shape[0] != K:
+            raise ValueError(f'Expected Theta to have shape[0] = {K}, got {Theta.shape[0]}')
+        elif ret_shapes or R is not None or X_pix is not None:
+            K = Theta.shape[0]
+    if R is not None:
+        if R.ndim != 3:
+            raise ValueError(f'Expected R to have ndim = 3, got {R.ndim}')
+        if R.shape[1:] != (3, 3):
+            raise ValueError(f'Expected R to have shape[1:] = (3, 3), got {R.shape[1:]}')
+        if np.isnan(R).any() or np.isinf(R).any():
+            raise ValueError('Expected R not to have nan or inf values')
+        if (np.abs(R.transpose(0, 2, 1) @ R - np.eye(3)) > 1e-9).any():
+            raise ValueError('Expected R[i] @ R[i].T must be approximately equal to eye(3) for all i,'
+                             'you may try orthogonolize_matrix(R) to fix it.')
+        if (np.abs(np.linalg.det(R) - 1.0) > 1e-9).any():
+            raise ValueError('Expected R[i] to have determinant approximately 1.0 for all i,'
+                             'you may try R *= np.sign(np.linalg.det(R))[:,np.newaxis,np.newaxis] to fix it.')
+        if K is not None and R.shape[0] != K:
+            raise ValueError(f'Expected R to have shape[0] = {K}, got {R.shape[0]}')
+        elif ret_shapes or X_pix is not None:
+            K = R.shape[0]
+    if X_pix is not None:
+        if X_pix.ndim != 3:
+            raise ValueError(f'Expected X_pix to have ndim = 3, got {X_pix.ndim}')
+        if X_pix.shape[2] != 2:
+            raise ValueError(f'Expected X_pix to have shape[2] = 2, got {X_pix.shape[2]}')
+        if N is not None and X_pix.shape[0] != N:
+            raise ValueError(f'Expected X_pix to have shape[0] = {N}, got {X_pix.shape[0]}')
+        elif ret_shapes:
+            N = X_pix.shape[0]
+        if K is not None and X_pix.shape[1] != K:
+            raise ValueError(f'Expected X_pix to have shape[1] = {K}, got {X_pix.shape[1]}')
+        elif ret_shapes:
+            K = X_pix.shape[1]
+    if phi_x is not None:
+        if phi_x <= 0.0 or phi_x >= np.pi:
+            raise ValueError(f'Expected phi_x to have a value within (0.0, pi), got {phi_x}')
+    if ret_shapes:
+        return N, K
+
+
+def check_solvable(n_visible, N, K, X_mask, C_Theta_mask, phi_x_mask):
+    """Mask sanity and the equations-vs-unknowns count (p2w:503-517)."""
+    if not X_mask and not C_Theta_mask and not phi_x_mask:
+        raise ValueError('At least one of X_mask, C_Theta_mask or phi_x_mask have to be true')
+    dof = 0
+    if X_mask:
+        dof += 3 * N
+    if C_Theta_mask:
+        dof += 6 * K
+    if X_mask and C_Theta_mask:
+        dof -= 7
+    if phi_x_mask:
+        dof += 1
+    if 2 * n_visible < dof:
+        raise ValueError('Unable to solve the problem, the number of equations is smaller than the number of '
+                         'degrees of freedom')
+
+
+def check_connected(i, j, N, K):
+    """The bipartite visibility graph must be one component (p2w:519-525)."""
+    n = connected_components_count(i, j, N, K)
+    if n > 1:
+        raise ValueError('Unable to solve the problem, expected the number of connected components of '
+                         f'visibility graph to be 1, got {n}')
+
+
+# --------------------------------------------------------------------------------------------- #
+def _default_device():
+    if not torch.cuda.is_available():
+        raise RuntimeError('3d_reconstruction_amd needs an MI355X visible to PyTorch-ROCm; there is no CPU path')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def _pack_results(fit, shard, masks, gather_X=None):
+    """Return list as the reference builds it (p2w:718-726)."""
+    X_mask, C_Theta_mask, phi_x_mask = masks
+    out = []
+    if X_mask:
+        X = shard.X if gather_X is None else gather_X(shard.X)
+        out.append(X.cpu().numpy().copy())
+    if C_Theta_mask:
+        out.append(shard.C.cpu().numpy().copy())
+        out.append(shard.Theta.cpu().numpy().copy())
+    if phi_x_mask:
+        out.append(np.float64(shard.phi.item()))
+    out.append(fit.energies())
+    if fit.ret_all_iters:
+        hist = fit.history()
+        K3 = 3 * shard.K
+        g = 0
+        if X_mask:
+            out.append(np.array([h.reshape(-1, 3) for h in hist[g]]))
+            g += 1
+        if C_Theta_mask:
+            out.append(np.array([h[:K3].reshape(-1, 3) for h in hist[g]]))
+            out.append(np.array([h[K3:2 * K3].reshape(-1, 3) for h in hist[g]]))
+        if phi_x_mask:
+            out.append(np.array([h[-1] for h in hist[g]]))
+    return out
+
+
+def fit_scene_sparse(i, j, uv, N, K, W, H, lr, max_iters, X_0, C_0, Theta_0, phi_x_0,
+                     X_mask=True, C_Theta_mask=True, phi_x_mask=True, optimizer='Adam',
+                     patience=1000, factor=2.0, stop_value=0.0, stop_diff=1e-12, print_step=1000,
+                     ret_all_iters=False, device=None, check_connectivity=True, _validate=True):
+    """`fit_scene` on a COO observation list: `i`, `j` int arrays (sorted by point, then camera,
+    i.e. the order numpy.nonzero gives on the dense visibility mask) and `uv` = pixel centres
+    (pixel + 0.5), shape (|V|, 2).  Same optimisation, same returns as `fit_scene`.
+
+    When torch.distributed is initialised with more than one rank, every rank passes the whole
+    problem; points (with their observations) are split into contiguous ranges balanced by
+    observation count, cameras are replicated, and one all-reduce per evaluation adds the
+    camera-side sums.  Every rank returns the full result."""
+    X_0, C_0, Theta_0 = (np.asarray(a, dtype=np.float64) for a in (X_0, C_0, Theta_0))
+    if _validate:
+        n_, k_ = validate_scene_parameters(X=X_0, C=C_0, Theta=Theta_0, phi_x=phi_x_0, ret_shapes=True)
+        if n_ != N or k_ != K:
+            raise ValueError(f'Expected X_0, C_0 to have shape[0] = {N}, {K}, got {n_}, {k_}')
+    dev = torch.device(device) if device is not None else _default_device()
+    as_t = lambda a, dt: a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
+    i_t, j_t, uv_t = as_t(i, None), as_t(j, None), as_t(uv, None)
+    nV = int(i_t.numel())
+    check_solvable(nV, N, K, X_mask, C_Theta_mask, phi_x_mask)
+    if X_mask and C_Theta_mask and check_connectivity:
+        check_connected(i_t.cpu().numpy(), j_t.cpu().numpy(), N, K)
+    if optimizer not in gd_func_dict:
+        raise ValueError(f'Unkown name of the optmizer, choose one from {[key for key in gd_func_dict]}')
+
+    world = torch.distributed.get_world_size() if (torch.distributed.is_available()
+                                                   and torch.distributed.is_initialized()) else 1
+    gather_X = None
+    if world > 1:
+        rank = torch.distributed.get_rank()
+        bounds, obs_bounds = partition_points(i_t.cpu().numpy(), N, world)
+        p0, p1 = bounds[rank], bounds[rank + 1]
+        e0, e1 = obs_bounds[rank], obs_bounds[rank + 1]
+        i_loc = (i_t[e0:e1].to(torch.int64) - p0).to(torch.int32)
+        shard = engine.Shard(i_loc, j_t[e0:e1], uv_t[e0:e1], p1 - p0, K, W, H, dev, n_visible_total=nV)
+        shard.set_params(X_0[p0:p1], C_0, Theta_0, phi_x_0)
+
+        def gather_X(x_local):
+            from .sharding import all_gather_rows
+            return all_gather_rows(x_local, bounds)
+    else:
+        shard = engine.Shard(i_t, j_t, uv_t, N, K, W, H, dev)
+        shard.set_params(X_0, C_0, Theta_0, phi_x_0)
+    try:
+        fit = SceneFit(shard, lr, max_iters, X_mask, C_Theta_mask, phi_x_mask, optimizer, patience, factor,
+                       stop_value, stop_diff, print_step, ret_all_iters)
+        fit.run()
+        return _pack_results(fit, shard, (X_mask, C_Theta_mask, phi_x_mask), gather_X)
+    finally:
+        shard.close()
+
+
+def fit_scene(X_pix, W, H, lr, max_iters, X_0, C_0, Theta_0, phi_x_0, X_mask=True, C_Theta_mask=True,
+              phi_x_mask=True, optimizer='Adam', patience=1000, factor=2.0, stop_value=0.0, stop_diff=1e-12,
+              print_step=1000, ret_all_iters=False, device=None):
+    """Bundle adjustment of points X, camera centres C, Euler angles Theta and the shared
+    horizontal field of view phi_x on the visible entries of the integer track array
+    X_pix (N,K,2) — signature and return value of the reference's fit_scene (p2w:480-500):
+    `[X?, C?, Theta?, phi_x?, E[:iters+1]]` followed, with ret_all_iters, by the per-iteration
+    history of each free group; a group is present only if its mask is True."""
+    N, K = validate_scene_parameters(X=X_0, C=C_0, Theta=Theta_0, phi_x=phi_x_0, X_pix=X_pix, ret_shapes=True)
+    if not X_mask and not C_Theta_mask and not phi_x_mask:
+        raise ValueError('At least one of X_mask, C_Theta_mask or phi_x_mask have to be true')
+    dev = torch.device(device) if device is not None else _default_device()
+    oi, oj, uv, _ = engine.visibility_coo(np.asarray(X_pix), dev)
+    return fit_scene_sparse(oi, oj, uv, N, K, W, H, lr, max_iters, X_0, C_0, Theta_0, phi_x_0, X_mask,
+                            C_Theta_mask, phi_x_mask, optimizer, patience, factor, stop_value, stop_diff,
+                            print_step, ret_all_iters, device=dev, _validate=False)
+
+
+def transform(X, C, Theta, phi_x, W, H, delete_back_points=True, delete_boundary_points=False, _validate=True,
+              device=None):
+    """Model pixels of every point in every camera, shape (N,K,2), NaN behind the camera and
+    (optionally) outside the frame (p2w:192-216)."""
+    if _validate:
+        validate_scene_parameters(X=X, C=C, Theta=Theta, phi_x=phi_x)
+    dev = torch.device(device) if device is not None else _default_device()
+    out = engine.project(X, C, Theta, phi_x, W, H, None, None, delete_back_points, delete_boundary_points, dev)
+    return out.view(X.shape[0], C.shape[0], 2).cpu().numpy()
+
+
+def error(X_pix, X_model, device=None):
+    """Mean squared reprojection error over pairs visible in both arrays, halved (p2w:98-111)."""
+    validate_scene_parameters(X_pix=X_pix)
+    if X_model.shape != X_pix.shape:
+        raise ValueError(f'Expected X_pix and X_model to have the same shape, got {X_pix.shape} != {X_model.shape}')
+    dev = torch.device(device) if device is not None else _default_device()
+    s, n = engine.reprojection_error(np.asarray(X_pix), np.asarray(X_model), dev)
+    return np.float64(s) / (2 * n)

@@ -1,0 +1,118 @@
+/*
+ * ba_mi355x.h — C ABI of libba_mi355x.so, the MI355X (gfx950) bundle-adjustment engine.
+ *
+ * The reference (modules/pix2world.py, "p2w" below) is pure Python/NumPy and has no FFI
+ * layer; its boundary for this path is the Python function fit_scene (p2w:480-500) and
+ * the optimiser registry gd_func_dict (p2w:362).  The entry points declared here are what a
+ * ctypes binding of that path calls: each one names the reference lines it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name starts with h_;
+ *   - every function returns 0 on success or a negative ba_status; ba_last_error() returns
+ *     the message of the calling thread's last failure; nothing throws;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *   - one ba_problem belongs to one GPU; a handle is not thread-safe, independent handles are;
+ *   - all floating point is IEEE binary64, indices are int32, observation counts int64;
+ *   - sums returned by ba_eval are UN-normalised (no 1/|V| factor) so that partial results of
+ *     several GPUs can be added before scaling.
+ */
+#ifndef BA_MI355X_H
+#define BA_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ba_problem ba_problem;
+
+enum ba_status {
+    BA_OK = 0,
+    BA_ERR_ARG = -1,        /* bad argument (null pointer, negative size, unsorted input) */
+    BA_ERR_HIP = -2,        /* a HIP runtime call failed */
+    BA_ERR_STATE = -3,      /* call not valid for this handle */
+    BA_ERR_NUMERIC = -4     /* factorisation met a non-positive pivot */
+};
+
+/* flags of ba_eval */
+enum ba_eval_flags {
+    BA_EVAL_GRAD_X = 1,     /* write gX                     (p2w:661-662) */
+    BA_EVAL_GRAD_CAM = 2,   /* write gC, gTheta             (p2w:664-698) */
+    BA_EVAL_GRAD_PHI = 4,   /* write gphi                   (p2w:700-702) */
+    BA_EVAL_JTJ = 8,        /* also write V, B, bphi, hphi (Gauss-Newton blocks; no reference counterpart) */
+    BA_EVAL_CAM_ATOMICS = 16, /* force the global-atomic camera reduction (default: LDS-private when it fits) */
+    BA_EVAL_TIMED = 32      /* record HIP events around the observation-pass kernel (see ba_eval_timing) */
+};
+
+const char *ba_last_error(void);
+int ba_version(void);
+
+/* Number of compute units / bytes of LDS per workgroup of `device` (launch sizing). */
+int ba_device_info(int device, int *compute_units, int *lds_bytes);
+
+/* ---- visibility set: X_visible = X_pix[:,:,0] >= 0, X_pix[X_visible] + 0.5 (p2w:506-508, 531)
+ * X_pix is the dense (N,K,2) int32 track array in C order.  ba_visibility_count writes the
+ * per-point counts' exclusive prefix sum row_ptr[N+1] (int64) and returns |V| in *h_nV;
+ * ba_visibility_fill then writes the COO list in the order numpy.nonzero walks it
+ * (i-major, j ascending): i[|V|], j[|V|], uv[|V|][2] = pixel + 0.5. */
+int ba_visibility_count(const int32_t *X_pix, int64_t N, int64_t K, int64_t *row_ptr,
+                        int64_t *h_nV, void *stream);
+int ba_visibility_fill(const int32_t *X_pix, int64_t N, int64_t K, const int64_t *row_ptr,
+                       int32_t *i, int32_t *j, double *uv, void *stream);
+
+/* ---- problem handle: the observation list of one GPU's shard (its points, all cameras).
+ * Observations must be sorted by point (i non-decreasing); the arrays are copied.
+ * Replaces the dense (N,K) temporaries fit_scene allocates at p2w:538-542, 555-573. */
+int ba_problem_create(int64_t N, int64_t K, int64_t nV, const int32_t *i, const int32_t *j,
+                      const double *uv, double W, double H, int device, ba_problem **out);
+int ba_problem_destroy(ba_problem *p);
+
+/* ---- fused per-observation pass: inner_transform (p2w:544-575), energy (p2w:612) and the
+ * analytic gradient (p2w:654-702) on the visible pairs only.
+ *   X[N][3], C[K][3], Theta[K][3] (columns theta_x, theta_y, theta_z), phi[1]
+ *   E_sum[1]  : sum of squared residuals (E = E_sum / (2|V|))
+ *   gX[N][3], gC[K][3], gTheta[K][3], gphi[1] : un-normalised gradients (multiply by 1/|V|)
+ *   with BA_EVAL_JTJ: V[N][6] (upper triangle of sum J_X^T J_X per point, order xx,xy,xz,yy,yz,zz),
+ *   B[K][21] (upper triangle, row-major, of the 6x6 block over (C,Theta) per camera),
+ *   bphi[K][6] (cross term camera x phi_x), hphi[1] (phi_x x phi_x).
+ * Outputs not selected by `flags` may be NULL. */
+int ba_eval(ba_problem *p, const double *X, const double *C, const double *Theta, const double *phi,
+            int flags, double *E_sum, double *gX, double *gC, double *gTheta, double *gphi,
+            double *V, double *B, double *bphi, double *hphi, void *stream);
+
+/* Durations in milliseconds of the observation-pass kernel of the ba_eval calls made with
+ * BA_EVAL_TIMED since the last call of this function (at most 256 are kept), measured with HIP
+ * events recorded on the launch stream around that kernel.  Synchronises on the events. */
+int ba_eval_timing(ba_problem *p, float *h_ms, int capacity, int *h_count);
+
+/* ---- update rules (p2w:336-360), in place, n doubles; g is multiplied by gscale (= 1/|V|) first.
+ * Adam: s = rho1 s + (1-rho1) g; r = rho2 r + (1-rho2) g^2;
+ *       x -= lr (s/bc1) / (1e-12 + sqrt(r/bc2)),  bc1 = 1-rho1^t, bc2 = 1-rho2^t (host supplies). */
+int ba_adam_step(int64_t n, double *x, const double *g, double *s, double *r, double lr,
+                 double gscale, double bc1, double bc2, void *stream);
+int ba_sgd_step(int64_t n, double *x, const double *g, double lr, double gscale, void *stream);
+
+/* ---- gauge fix: align_scene + normalize_scene (p2w:270-333) in place.
+ * Camera 0 goes to the origin with identity rotation; the longest baseline from camera 0
+ * gets length 1.  R_out[K][9] (optional) receives R0^T R_j as align_scene(ret_R=True) does.
+ * gauge_out[16] (optional): R0 (9, row-major), C0 (3), scale factor, j1, 2 spare. */
+int ba_gauge_fix(int64_t N, int64_t K, double *X, double *C, double *Theta, double *R_out,
+                 double *gauge_out, void *stream);
+
+/* ---- transform (p2w:192-216) on a list of pairs: model pixels out[n][2], NaN behind the camera
+ * (delete_back_points) and optionally outside [0,W)x[0,H) (delete_boundary_points).
+ * i == NULL means the dense N x K grid in C order (n = N*K). */
+int ba_project(int64_t N, int64_t K, int64_t n, const int32_t *i, const int32_t *j,
+               const double *X, const double *C, const double *Theta, double phi, double W, double H,
+               int delete_back_points, int delete_boundary_points, double *out, void *stream);
+
+/* ---- error (p2w:98-111): sums[0] = sum of squared differences over pairs visible in the data
+ * (pix_xy[n][2] int32, x >= 0) whose model pixel is not NaN; sums[1] = number of such pairs. */
+int ba_reprojection_error(int64_t n, const int32_t *pix_xy, const double *model, double *sums,
+                          void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BA_MI355X_H */

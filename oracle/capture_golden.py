@@ -185,13 +185,20 @@ def capture_f2(out):
     vis = X_pix[:, :, 0] >= 0
     ii, jj = np.nonzero(vis)
     short = run_reference(sc, lr=1e-3, max_iters=51, patience=1000)
-    long_ = run_reference(sc, lr=1e-3, max_iters=300, patience=1000)
+    # Free run: the ray initialisation puts every point exactly on the ray of its first view, so
+    # some residuals (and with them camera 0's whole gradient) are rounding noise at iteration 0,
+    # and Adam's first step g / (1e-12 + |g|) turns that noise into O(lr) moves.  Any change of
+    # summation order then changes the trajectory.  The free run therefore starts from the same
+    # initialisation with the points moved off their rays by a fixed pseudo-random offset.
+    X0_free = X0 + np.random.default_rng(17).normal(0.0, 0.02, X0.shape)
+    long_ = run_reference(dict(sc, X_0=X0_free), lr=1e-3, max_iters=300, patience=1000)
     arrays = dict(N=X_pix.shape[0], K=X_pix.shape[1], W=W, H=H,
                   obs_i=ii.astype(np.int32), obs_j=jj.astype(np.int32),
                   obs_xy=X_pix[vis].astype(np.int32),
                   X_0=X0, C_0=C0, Theta_0=Th0, phi_x_0=phi0)
     for k, v in short.items():
         arrays['tf__' + k] = np.array(v) if k == 'log' else v
+    arrays['free__X_0'] = X0_free
     for k in ('E', 'final_X', 'final_C', 'final_Theta', 'final_phi_x', 'manager_calls'):
         arrays['free__' + k] = long_[k]
     arrays['free__log'] = np.array(long_['log'])

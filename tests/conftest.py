@@ -37,3 +37,20 @@ def rel_err(a, b):
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     scale = max(np.abs(b).max(), 1e-300)
     return np.abs(a - b).max() / scale
+
+
+def logs_match(got, want, rtol=1e-8):
+    """Printed lines agree: same text, every number within `rtol` (the reference prints energies
+    with full repr precision, so the last digits depend on summation order)."""
+    import re
+    num = re.compile(r'[-+]?(?:\d+\.\d*|\.\d+|\d+)(?:[eE][-+]?\d+)?')
+    if len(got) != len(want):
+        return False
+    for a, b in zip(got, want):
+        if num.sub('#', a) != num.sub('#', b):
+            return False
+        for x, y in zip(num.findall(a), num.findall(b)):
+            x, y = float(x), float(y)
+            if abs(x - y) > rtol * max(abs(y), 1e-300):
+                return False
+    return True

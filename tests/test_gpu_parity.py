@@ -1,0 +1,303 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and with the golden vectors
+captured from the reference.  Needs an MI355X: run with `-m gpu`.
+
+Tolerances (the contract): energy and gradients within 1e-9 relative per evaluation at the
+reference's own iterates (teacher-forced), final parameters within 1e-6 after a fixed free run,
+visibility indexing bit-exact."""
+import io
+import contextlib
+
+import numpy as np
+import pytest
+
+from conftest import logs_match, rel_err
+from oracle import ba_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+DEV = 'cuda:0'
+
+
+def _dense_from_coo(g):
+    N, K = int(g['N']), int(g['K'])
+    X_pix = np.full((N, K, 2), -1, dtype=np.int32)
+    X_pix[g['obs_i'], g['obs_j']] = g['obs_xy']
+    return X_pix
+
+
+# ---- H0: visibility extraction ---------------------------------------------------------------
+@pytest.mark.parametrize('shape,frac,seed', [((93, 327), 0.26, 0), ((1, 1), 1.0, 1), ((7, 64), 0.5, 2),
+                                            ((130, 65), 0.0, 3), ((257, 129), 1.0, 4), ((9000, 37), 0.3, 5)])
+def test_visibility_random_bit_exact(ba, shape, frac, seed):
+    rng = np.random.default_rng(seed)
+    N, K = shape
+    X_pix = rng.integers(0, 4000, (N, K, 2)).astype(np.int32)
+    X_pix[rng.random((N, K)) >= frac] = -1
+    oi, oj, uv, row_ptr = ba.engine.visibility_coo(X_pix, DEV)
+    i, j, uv_ref = orc.visibility_coo(X_pix)
+    assert np.array_equal(oi.cpu().numpy(), i) and np.array_equal(oj.cpu().numpy(), j)
+    assert np.array_equal(uv.cpu().numpy().reshape(-1, 2), uv_ref.reshape(-1, 2))
+    counts = (X_pix[:, :, 0] >= 0).sum(1)
+    assert np.array_equal(row_ptr.cpu().numpy(), np.concatenate([[0], np.cumsum(counts)]))
+
+
+def test_visibility_moscow_bit_exact(ba, golden):
+    g = golden('f2_moscow_ride.npz')
+    oi, oj, uv, _ = ba.engine.visibility_coo(_dense_from_coo(g), DEV)
+    assert np.array_equal(oi.cpu().numpy(), g['obs_i']) and np.array_equal(oj.cpu().numpy(), g['obs_j'])
+    assert np.array_equal(uv.cpu().numpy(), g['obs_xy'] + 0.5)
+
+
+def test_visibility_only_x_decides(ba):
+    # the rule is X_pix[:,:,0] >= 0 alone (p2w:506): a negative y with x >= 0 is visible
+    X_pix = np.array([[[5, -1], [-1, 7], [0, 0]]], dtype=np.int32)
+    oi, oj, uv, _ = ba.engine.visibility_coo(X_pix, DEV)
+    assert oj.cpu().numpy().tolist() == [0, 2]
+    assert uv.cpu().numpy().tolist() == [[5.5, -0.5], [0.5, 0.5]]
+
+
+# ---- H3/H4/H7/H8/H9: fused observation pass --------------------------------------------------
+def _eval_all(ba, sh, nv, **kw):
+    sh.eval(**kw)
+    return (sh.energy(), sh.gX.cpu().numpy() / nv, sh.gC.cpu().numpy() / nv, sh.gTheta.cpu().numpy() / nv,
+            sh.gphi.cpu().numpy() / nv)
+
+
+@pytest.mark.parametrize('cam_atomics', [False, True])
+def test_eval_teacher_forced_moscow(ba, golden, cam_atomics):
+    g = golden('f2_moscow_ride.npz')
+    W, H = int(g['W']), int(g['H'])
+    nv = g['obs_i'].size
+    sh = ba.engine.Shard(g['obs_i'], g['obs_j'], g['obs_xy'] + 0.5, int(g['N']), int(g['K']), W, H, DEV)
+    worst = 0.0
+    for s in range(g['tf__step_X'].shape[0]):
+        sh.set_params(g['tf__step_X'][s], g['tf__step_C'][s], g['tf__step_Theta'][s], g['tf__step_phi_x'][s][0])
+        E, gX, gC, gT, gp = _eval_all(ba, sh, nv, cam_atomics=cam_atomics)
+        worst = max(worst, abs(E - g['tf__E'][s]) / g['tf__E'][s], rel_err(gX, g['tf__grad_X'][s]),
+                    rel_err(gC, g['tf__grad_C'][s]), rel_err(gT, g['tf__grad_Theta'][s]),
+                    rel_err(gp, g['tf__grad_phi_x'][s]))
+    sh.close()
+    assert worst < TOL, worst
+
+
+def test_eval_teacher_forced_f3_and_f6(ba, golden):
+    for name in ('f3_lr_events.npz', 'f6_medium.npz'):
+        g = golden(name)
+        if 'obs_i' in g.files:
+            i, j, uv = g['obs_i'], g['obs_j'], g['obs_xy'] + 0.5
+            N, K = int(g['N']), int(g['K'])
+        else:
+            i, j, uv = orc.visibility_coo(g['X_pix'])
+            N, K = g['X_pix'].shape[:2]
+        sh = ba.engine.Shard(i, j, uv, N, K, int(g['W']), int(g['H']), DEV)
+        for s in range(0, g['step_X'].shape[0], 5):
+            sh.set_params(g['step_X'][s], g['step_C'][s], g['step_Theta'][s], g['step_phi_x'][s][0])
+            E, gX, gC, gT, gp = _eval_all(ba, sh, i.size)
+            assert rel_err(gX, g['grad_X'][s]) < TOL and rel_err(gC, g['grad_C'][s]) < TOL, (name, s)
+            assert rel_err(gT, g['grad_Theta'][s]) < TOL and rel_err(gp, g['grad_phi_x'][s]) < TOL, (name, s)
+        sh.close()
+
+
+def test_eval_ragged_and_empty_points(ba):
+    """Points without observations get a zero gradient; long tracks span several waves."""
+    rng = np.random.default_rng(3)
+    N, K = 500, 700
+    counts = rng.integers(0, 5, N)
+    counts[7] = 650          # one point seen by almost every camera (spans > 10 wave steps)
+    counts[8] = 0
+    counts[N - 1] = 0
+    C, Th, R = ba.scenes.orbit_cameras(K, seed=2)
+    i = np.repeat(np.arange(N), counts).astype(np.int32)
+    j = np.concatenate([np.sort(rng.choice(K, c, replace=False)) for c in counts]).astype(np.int32)
+    X = rng.normal(0, 1, (N, 3)) + np.array([0, 0, 30.0])
+    uv = rng.uniform(0, 1000, (i.size, 2))
+    sh = ba.engine.Shard(i, j, uv, N, K, 1920, 1080, DEV)
+    sh.gX.fill_(123.0)       # stale content must not survive
+    sh.set_params(X, C, Th, 1.1)
+    E, gX, gC, gT, gp = _eval_all(ba, sh, i.size)
+    E_ref, gX_r, gC_r, gT_r, gp_r = orc.energy_and_gradients(X, C, Th, np.array([1.1]), 1920, 1080, i, j, uv)
+    assert abs(E - E_ref) / E_ref < TOL
+    assert rel_err(gX, gX_r) < TOL and rel_err(gC, gC_r) < TOL and rel_err(gT, gT_r) < TOL and rel_err(gp, gp_r) < TOL
+    assert np.all(gX[counts == 0] == 0.0)
+    sh.close()
+
+
+def test_problem_create_rejects_bad_input(ba):
+    i = np.array([0, 2, 1], dtype=np.int32)
+    j = np.array([0, 1, 2], dtype=np.int32)
+    uv = np.zeros((3, 2))
+    with pytest.raises(ba.engine._lib.BAError, match='sorted'):
+        ba.engine.Shard(i, j, uv, 3, 3, 10, 10, DEV)
+    with pytest.raises(ba.engine._lib.BAError, match='out of range'):
+        ba.engine.Shard(np.array([0, 1, 5], dtype=np.int32), j, uv, 3, 3, 10, 10, DEV)
+
+
+# ---- H2 / H10: gauge fix and update rules ----------------------------------------------------
+def test_gauge_fix_matches_reference_functions(ba, golden):
+    g = golden('f5_gauge_funcs.npz')
+    N, K = g['X'].shape[0], g['C'].shape[0]
+    i = np.arange(N, dtype=np.int32)
+    sh = ba.engine.Shard(i, np.zeros(N, dtype=np.int32), np.zeros((N, 2)), N, K, 10, 10, DEV)
+    sh.set_params(g['X'], g['C'], g['Theta'], 1.0)
+    sh.gauge_fix()
+    assert np.abs(sh.X.cpu().numpy() - g['norm_X']).max() < 1e-13
+    assert np.abs(sh.C.cpu().numpy() - g['norm_C']).max() < 1e-13
+    assert np.abs(sh.Theta.cpu().numpy() - g['align_Theta']).max() < 1e-13
+    assert np.abs(sh.R_gauge.cpu().numpy().reshape(K, 3, 3) - g['align_R']).max() < 1e-13
+    gauge = sh.gauge.cpu().numpy()
+    assert int(gauge[13]) == int(g['norm_j1'])
+    sh.close()
+
+
+def test_adam_and_sgd_match_reference_functions(ba, golden):
+    import torch
+    g = golden('f5_gauge_funcs.npz')
+    N = g['adam_x'].shape[0]
+    sh = ba.engine.Shard(np.arange(N, dtype=np.int32), np.zeros(N, dtype=np.int32), np.zeros((N, 2)), N, 2, 10,
+                         10, DEV)
+    t = lambda a: torch.from_numpy(a.copy()).to(DEV).view(-1)
+    x, s, r = t(g['adam_x']), t(g['adam_s']), t(g['adam_r'])
+    grad = t(g['adam_g']) * sh.nV            # the kernel multiplies by 1/|V|
+    sh.adam(x, grad, s, r, 1e-2, 1.0 - 0.9 ** 3, 1.0 - 0.999 ** 3)
+    assert np.abs(x.cpu().numpy() - g['adam_x_new'].ravel()).max() < 1e-14
+    assert np.abs(s.cpu().numpy() - g['adam_s_new'].ravel()).max() < 1e-15
+    assert np.abs(r.cpu().numpy() - g['adam_r_new'].ravel()).max() < 1e-15
+    x2 = t(g['adam_x'])
+    sh.sgd(x2, grad, 1e-2)
+    assert np.abs(x2.cpu().numpy() - g['sgd_x_new'].ravel()).max() < 1e-15
+    sh.close()
+
+
+# ---- whole fit_scene -------------------------------------------------------------------------
+@pytest.mark.parametrize('opt', ['Adam', 'SGD'])
+def test_fit_scene_dense_api_all_masks(ba, golden, opt):
+    g = golden('f1_tiny_masks.npz')
+    lr = 1e-3 if opt == 'Adam' else 1e-7
+    for m in g['combos']:
+        m = tuple(bool(t) for t in m)
+        tag = f"{opt}_{''.join('1' if t else '0' for t in m)}"
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            out = ba.fit_scene(g['X_pix'], int(g['W']), int(g['H']), lr, 5, g['X_0'], g['C_0'], g['Theta_0'],
+                               float(g['phi_x_0']), X_mask=m[0], C_Theta_mask=m[1], phi_x_mask=m[2],
+                               optimizer=opt, ret_all_iters=True)
+        names = (['X'] if m[0] else []) + (['C', 'Theta'] if m[1] else []) + (['phi_x'] if m[2] else [])
+        assert len(out) == 2 * len(names) + 1
+        assert rel_err(out[len(names)], g[f'{tag}__E']) < TOL, tag
+        for k, n in enumerate(names):
+            assert np.abs(np.asarray(out[k]) - g[f'{tag}__final_{n}']).max() < 1e-9, (tag, n)
+            hist = out[len(names) + 1 + k]
+            assert hist.shape[0] == 5
+            want = g[f'{tag}__step_{n}']
+            got = np.asarray(hist[:want.shape[0]], dtype=np.float64).reshape(want.shape)
+            assert np.abs(got - want).max() < 1e-9, (tag, n)
+        if m[2]:
+            assert isinstance(out[len(names) - 1], np.float64)
+        assert logs_match(buf.getvalue().splitlines(), g[f'{tag}__log'].tolist()), tag
+
+
+def test_fit_scene_moscow_free_run_300(ba, golden):
+    g = golden('f2_moscow_ride.npz')
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        X, C, Th, phi, E = ba.fit_scene(_dense_from_coo(g), int(g['W']), int(g['H']), 1e-3, 300, g['free__X_0'],
+                                        g['C_0'], g['Theta_0'], float(g['phi_x_0']), patience=1000)
+    assert E.shape == g['free__E'].shape
+    assert rel_err(E, g['free__E']) < 1e-8
+    assert np.abs(X - g['free__final_X']).max() < 1e-6
+    assert np.abs(C - g['free__final_C']).max() < 1e-6
+    assert np.abs(Th - g['free__final_Theta']).max() < 1e-6
+    assert abs(phi - float(g['free__final_phi_x'])) < 1e-6
+    assert logs_match(buf.getvalue().splitlines(), g['free__log'].tolist())
+
+
+def test_fit_scene_lr_events(ba, golden):
+    g = golden('f3_lr_events.npz')
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        out = ba.fit_scene(g['X_pix'], int(g['W']), int(g['H']), 1e-3, 200, g['X_0'], g['C_0'], g['Theta_0'],
+                           float(g['phi_x_0']), patience=20)
+    events = lambda lines: [ln for ln in lines if ('LR' in ln or 'Reached' in ln)]
+    assert events(buf.getvalue().splitlines()) == events(g['log'].tolist())
+    assert out[-1].shape == g['E'].shape
+    assert rel_err(out[-1][:100], g['E'][:100]) < 1e-8
+
+
+def test_fit_scene_errors_match_reference_messages(ba, golden):
+    g = golden('f1_tiny_masks.npz')
+    args = [g['X_pix'], int(g['W']), int(g['H']), 1e-3, 5, g['X_0'], g['C_0'], g['Theta_0'], float(g['phi_x_0'])]
+    with pytest.raises(ValueError, match='At least one of X_mask'):
+        ba.fit_scene(*args, X_mask=False, C_Theta_mask=False, phi_x_mask=False)
+    with pytest.raises(ValueError, match='Unkown name of the optmizer'):
+        ba.fit_scene(*args, optimizer='LBFGS')
+    bad = list(args)
+    bad[8] = 4.0
+    with pytest.raises(ValueError, match=r'within \(0.0, pi\)'):
+        ba.fit_scene(*bad)
+    few = g['X_pix'].copy()
+    few[:, 1:] = -1
+    a2 = list(args)
+    a2[0] = few
+    with pytest.raises(ValueError, match='number of equations is smaller'):
+        ba.fit_scene(*a2)
+    split = g['X_pix'].copy()
+    split[:30, :7] = -1
+    split[30:, 7:] = -1
+    a3 = list(args)
+    a3[0] = split
+    with pytest.raises(ValueError, match='connected components of visibility graph to be 1, got 2'):
+        ba.fit_scene(*a3)
+
+
+# ---- scoring helpers -------------------------------------------------------------------------
+def test_transform_and_error(ba, golden):
+    g = golden('f5_gauge_funcs.npz')
+    W, H, phi = int(g['tr_W']), int(g['tr_H']), float(g['tr_phi'])
+    args = (g['tr_X'], g['tr_C'], g['Theta'], phi, W, H)
+    for kw, key in ((dict(), 'tr_default'), (dict(delete_boundary_points=True), 'tr_boundary'),
+                    (dict(delete_back_points=False), 'tr_keep_back')):
+        got, want = ba.transform(*args, **kw), g[key]
+        assert got.shape == want.shape
+        assert np.array_equal(np.isnan(got), np.isnan(want)), key
+        assert np.allclose(got, want, rtol=1e-12, atol=1e-9, equal_nan=True), key
+    assert ba.error(g['err_X_pix'], g['tr_default']) == pytest.approx(float(g['err_value']), rel=1e-12)
+
+
+# ---- full-size properties (N = 1 M points, K = 2 k cameras, ~10 M observations) ---------------
+def test_full_size_invariants(ba):
+    import torch
+    sc = ba.scenes.orbit_scene(N=1_000_000, K=2000, track_len=10, seed=0)
+    nv = sc['i'].size
+    assert nv > 9_000_000
+    sh = ba.engine.Shard(sc['i'], sc['j'], sc['uv'], sc['N_local'], sc['K'], sc['W'], sc['H'], DEV)
+    sh.set_params(sc['X_0'], sc['C_0'], sc['Theta_0'], sc['phi_x_0'])
+    sh.eval()
+    E1 = sh.energy()
+    gX, red = sh.gX.clone(), sh.red.clone()
+    # translation invariance of the energy: sum_i dE/dX_i + sum_j dE/dC_j = 0
+    tot = gX.sum(0) + sh.gC.sum(0)
+    assert float(tot.abs().max()) < 1e-7 * float(gX.abs().sum())
+    # LDS-private and global-atomic camera reductions agree (different summation orders)
+    sh.eval(cam_atomics=True)
+    assert abs(sh.energy() - E1) / E1 < 1e-12
+    assert float((sh.red - red).abs().max()) <= 1e-10 * float(red.abs().max())
+    assert torch.equal(sh.gX, gX)
+    # a sample of points and cameras against the oracle restricted to their observations
+    pts = np.array([0, 1, 77777, 500000, 999999])
+    sel = np.isin(sc['i'], pts)
+    _, gX_r, _, _, _ = orc.energy_and_gradients(sc['X_0'], sc['C_0'], sc['Theta_0'], np.array([sc['phi_x_0']]),
+                                                sc['W'], sc['H'], sc['i'][sel], sc['j'][sel], sc['uv'][sel],
+                                                n_visible=nv)
+    assert rel_err(gX.cpu().numpy()[pts] / nv, gX_r[pts]) < TOL
+    cams = np.array([0, 1, 999, 1999])
+    selc = np.isin(sc['j'], cams)
+    _, _, gC_r, gT_r, _ = orc.energy_and_gradients(sc['X_0'], sc['C_0'], sc['Theta_0'], np.array([sc['phi_x_0']]),
+                                                   sc['W'], sc['H'], sc['i'][selc], sc['j'][selc], sc['uv'][selc],
+                                                   n_visible=nv)
+    assert rel_err(sh.gC.cpu().numpy()[cams] / nv, gC_r[cams]) < TOL
+    assert rel_err(sh.gTheta.cpu().numpy()[cams] / nv, gT_r[cams]) < TOL
+    # the gauge fix leaves the energy unchanged (similarity invariance)
+    sh.gauge_fix()
+    sh.eval()
+    assert abs(sh.energy() - E1) / E1 < 1e-9
+    sh.close()

@@ -157,7 +157,7 @@ def test_f2_moscow_free_run_300(golden):
     W, H = int(g['W']), int(g['H'])
     log = []
     X, C, Th, phi, E = orc.fit_scene(g['obs_i'], g['obs_j'], g['obs_xy'] + 0.5, int(g['N']), int(g['K']),
-                                     W, H, 1e-3, 300, g['X_0'], g['C_0'], g['Theta_0'],
+                                     W, H, 1e-3, 300, g['free__X_0'], g['C_0'], g['Theta_0'],
                                      float(g['phi_x_0']), patience=1000, log=log)
     assert E.shape == g['free__E'].shape
     assert rel_err(E, g['free__E']) < 1e-8
