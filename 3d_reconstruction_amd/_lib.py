@@ -15,6 +15,8 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libba_mi355x.so')
 
 # enum ba_eval_flags
 EVAL_GRAD_X, EVAL_GRAD_CAM, EVAL_GRAD_PHI, EVAL_JTJ, EVAL_CAM_ATOMICS, EVAL_TIMED = 1, 2, 4, 8, 16, 32
+EVAL_UNTILED = 512
+EVAL_REUSE_TABLE = 1024
 
 _p = C.c_void_p
 _i64 = C.c_int64
@@ -32,8 +34,10 @@ SIGNATURES = {
     'ba_problem_destroy': (_int, [_p]),
     'ba_eval': (_int, [_p, _p, _p, _p, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'ba_eval_timing': (_int, [_p, C.POINTER(C.c_float), _int, C.POINTER(_int)]),
-    'ba_adam_step': (_int, [_i64, _p, _p, _p, _p, _dbl, _dbl, _dbl, _dbl, _p]),
-    'ba_sgd_step': (_int, [_i64, _p, _p, _dbl, _dbl, _p]),
+    'ba_adam_step': (_int, [_i64, _p, _p, _p, _p, _dbl, _dbl, _dbl, _dbl, _p, _p]),
+    'ba_sgd_step': (_int, [_i64, _p, _p, _dbl, _dbl, _p, _p]),
+    'ba_camera_step': (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _int, _dbl, _dbl, _dbl, _dbl, _int, _p, _p, _p]),
+    'ba_points_step': (_int, [_i64, _p, _p, _p, _p, _p, _int, _dbl, _dbl, _dbl, _dbl, _p, _p]),
     'ba_gauge_fix': (_int, [_i64, _i64, _p, _p, _p, _p, _p, _p]),
     'ba_project': (_int, [_i64, _i64, _i64, _p, _p, _p, _p, _p, _dbl, _dbl, _dbl, _int, _int, _p, _p]),
     'ba_reprojection_error': (_int, [_i64, _p, _p, _p, _p]),

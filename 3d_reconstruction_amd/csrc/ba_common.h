@@ -59,12 +59,26 @@ struct ba_problem {
     int n_chunks = 0;
     int grid = 0;                 // workgroups of the observation pass
     int64_t n_points_seen = 0;    // points with at least one observation
+    // tiled form of the observation pass (null / 0 when the scene does not tile)
+    int tiled = 0;
+    int n_tiles = 0, tile_obs_target = 0;
+    int cam_cap = 0, pt_cap = 0;  // largest camera list / point span of a tile
+    int cam_rep = 1;              // copies of the camera accumulators in LDS
+    size_t tile_lds_bytes = 0;
+    int32_t *tile_obs = nullptr;      // n_tiles + 1
+    int64_t *tile_cam_ptr = nullptr;  // n_tiles + 1
+    int32_t *cam_list = nullptr;
+    int32_t *oslot = nullptr;         // nV: camera slot within the tile's list
+    void *tile_meta = nullptr;        // n_tiles x TileMeta
     // scratch owned by the handle (device)
     double *cam_table = nullptr;  // K x CAM_ROW
     double *cam_sums = nullptr;   // 6 x K camera-frame sums (SoA: component-major)
     double *partials = nullptr;   // grid*EVAL_WAVES x 2 per-wave partial sums
     double *scalars = nullptr;    // SC_COUNT
-    int *flag = nullptr;          // 1 int, validation
+    int *flag = nullptr;          // 4 ints: validation flags, tile maxima
+    int *step_counter = nullptr;  // arrival counter of the multi-workgroup camera step (kept at 0)
+    double *step_best = nullptr;  // 2 per workgroup of that kernel
+    double *step_stage = nullptr; // 16
     // timing ring
     std::vector<hipEvent_t> ev_begin, ev_end;
     int ev_count = 0;

@@ -17,6 +17,8 @@
 #include "ba_common.h"
 
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 namespace ba {
@@ -38,6 +40,17 @@ __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
     return v;
+}
+
+// value of the lane N positions lower in the same 16-lane row (0.0 / 0 where there is none)
+template <int N>
+__device__ __forceinline__ int row_shr(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, 0x110 + N, 0xf, 0xf, true);
+}
+template <int N>
+__device__ __forceinline__ double row_shr(double v) {
+    const int lo = row_shr<N>(__double2loint(v)), hi = row_shr<N>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
 }
 
 // R = Ry(ty) Rx(tx) Rz(tz), row-major (p2w:114-140)
@@ -259,8 +272,50 @@ struct EvalArgs {
     double *gX;        // may be null
     double *cam_sums;  // 6 x K, component-major (pre-zeroed)
     double *partials;  // per-wave {sum r^2, sum m.r}
+    int debug;         // diagnostics: bit 0 skips the camera-side accumulation
 };
 
+// One observation record and the operands gathered for it.
+struct ObsRec {
+    int i, j;
+    double2 uv;
+};
+struct ObsOps {
+    double x0, x1, x2;            // X_i
+    double2 t0, t1, t2, t3, t4, t5;  // camera-table row: R (9), C (3)
+};
+
+// Lanes past the end of the chunk read the chunk's last record (always a valid address) and
+// are masked out of every sum.
+__device__ __forceinline__ ObsRec load_record(const EvalArgs &a, int e, int e_last) {
+    const int ec = e < e_last ? e : e_last;
+    ObsRec r;
+    r.i = a.oi[ec];
+    r.j = a.oj[ec];
+    r.uv = a.ouv[ec];
+    return r;
+}
+
+__device__ __forceinline__ ObsOps gather_operands(const EvalArgs &a, const ObsRec &r) {
+    ObsOps g;
+    const bool fixed = (a.debug & 4) != 0;   // diagnostics: every lane reads point 0 / camera 0
+    const double *x = a.X + 3 * (int64_t)(fixed ? 0 : r.i);
+    const double2 *t = (const double2 *)(a.T + (int64_t)(fixed ? 0 : r.j) * CAM_ROW);
+    g.x0 = x[0];
+    g.x1 = x[1];
+    g.x2 = x[2];
+    g.t0 = t[0];
+    g.t1 = t[1];
+    g.t2 = t[2];
+    g.t3 = t[3];
+    g.t4 = t[4];
+    g.t5 = t[5];
+    return g;
+}
+
+// The observation stream is software-pipelined three deep per wave: while step k is computed,
+// the gathers (X_i, camera row) of step k+1 and the record loads of step k+2 are in flight, so
+// that a wave never sits on a dependent load chain (record -> gather -> math).
 template <bool LDS_CAM>
 __global__ void __launch_bounds__(EVAL_BLOCK) k_eval(EvalArgs a) {
     extern __shared__ double lds_cam[];  // LDS_CAM: 6 x K accumulators, component-major
@@ -280,57 +335,62 @@ __global__ void __launch_bounds__(EVAL_BLOCK) k_eval(EvalArgs a) {
 
     for (int c = wave; c < a.n_chunks; c += n_waves) {
         const int e0 = a.chunk_begin[c], e1 = a.chunk_begin[c + 1];
+        if (e0 >= e1) continue;
+        const int e_last = e1 - 1;
         int carry_i = -1;
         double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+
+        ObsRec rec0 = load_record(a, e0 + lane, e_last);
+        ObsRec rec1 = load_record(a, e0 + 64 + lane, e_last);
+        ObsOps ops0 = gather_operands(a, rec0);
+
         for (int base = e0; base < e1; base += 64) {
-            const int e = base + lane;
-            const bool valid = e < e1;
-            int i = -2;
-            double g0 = 0.0, g1 = 0.0, g2 = 0.0;  // world-frame contribution to dE/dX_i
-            if (valid) {
-                i = a.oi[e];
-                const int j = a.oj[e];
-                const double2 uv = a.ouv[e];
-                const double *x = a.X + 3 * (int64_t)i;
-                const double *t = a.T + (int64_t)j * CAM_ROW;
-                const double2 t0 = *(const double2 *)(t + 0), t1 = *(const double2 *)(t + 2),
-                              t2 = *(const double2 *)(t + 4), t3 = *(const double2 *)(t + 6),
-                              t4 = *(const double2 *)(t + 8), t5 = *(const double2 *)(t + 10);
-                const double R00 = t0.x, R01 = t0.y, R02 = t1.x, R10 = t1.y, R11 = t2.x, R12 = t2.y, R20 = t3.x,
-                             R21 = t3.y, R22 = t4.x;
-                const double d0 = x[0] - t4.y, d1 = x[1] - t5.x, d2 = x[2] - t5.y;
-                const double q0 = R00 * d0 + R10 * d1 + R20 * d2;
-                const double q1 = R01 * d0 + R11 * d1 + R21 * d2;
-                const double q2 = R02 * d0 + R12 * d1 + R22 * d2;
-                const double inv = 1.0 / q2;
-                const double m0 = q0 * inv, m1 = q1 * inv;
-                const double r0 = f * m0 + pcx - uv.x;
-                const double r1 = f * m1 + pcy - uv.y;
-                esum += r0 * r0 + r1 * r1;
-                const double mr = m0 * r0 + m1 * r1;
-                psum += mr;
-                const double fi = f * inv;
-                const double a0 = fi * r0, a1 = fi * r1, a2 = -fi * mr;  // camera-frame force g
-                g0 = R00 * a0 + R01 * a1 + R02 * a2;
-                g1 = R10 * a0 + R11 * a1 + R12 * a2;
-                g2 = R20 * a0 + R21 * a1 + R22 * a2;
-                // camera-frame sums: force and torque q x g
-                const double w0 = q1 * a2 - q2 * a1, w1 = q2 * a0 - q0 * a2, w2 = q0 * a1 - q1 * a0;
-                double *acc = LDS_CAM ? lds_cam : a.cam_sums;
+            const ObsRec rec2 = load_record(a, base + 128 + lane, e_last);
+            const ObsOps ops1 = gather_operands(a, rec1);
+
+            const bool valid = base + lane < e1;
+            const int i = valid ? rec0.i : -2;
+            const int j = rec0.j;
+            const double R00 = ops0.t0.x, R01 = ops0.t0.y, R02 = ops0.t1.x, R10 = ops0.t1.y, R11 = ops0.t2.x,
+                         R12 = ops0.t2.y, R20 = ops0.t3.x, R21 = ops0.t3.y, R22 = ops0.t4.x;
+            const double d0 = ops0.x0 - ops0.t4.y, d1 = ops0.x1 - ops0.t5.x, d2 = ops0.x2 - ops0.t5.y;
+            const double q0 = R00 * d0 + R10 * d1 + R20 * d2;
+            const double q1 = R01 * d0 + R11 * d1 + R21 * d2;
+            const double q2 = R02 * d0 + R12 * d1 + R22 * d2;
+            const double inv = 1.0 / q2;
+            const double m0 = q0 * inv, m1 = q1 * inv;
+            const double r0 = valid ? f * m0 + pcx - rec0.uv.x : 0.0;
+            const double r1 = valid ? f * m1 + pcy - rec0.uv.y : 0.0;
+            esum += r0 * r0 + r1 * r1;
+            const double mr = m0 * r0 + m1 * r1;
+            psum += mr;
+            const double fi = f * inv;
+            const double a0 = fi * r0, a1 = fi * r1, a2 = -fi * mr;  // camera-frame force g
+            double g0 = R00 * a0 + R01 * a1 + R02 * a2;            // world-frame dE/dX_i part
+            double g1 = R10 * a0 + R11 * a1 + R12 * a2;
+            double g2 = R20 * a0 + R21 * a1 + R22 * a2;
+            // camera-frame sums: force and torque q x g
+            const double w0 = q1 * a2 - q2 * a1, w1 = q2 * a0 - q0 * a2, w2 = q0 * a1 - q1 * a0;
+            if (a.debug & 1) {
+                asm volatile("" ::"v"(w0), "v"(w1), "v"(w2));
+            } else if (valid) {
                 if (LDS_CAM) {
-                    __hip_atomic_fetch_add(acc + 0 * K + j, a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(acc + 1 * K + j, a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(acc + 2 * K + j, a2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(acc + 3 * K + j, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(acc + 4 * K + j, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(acc + 5 * K + j, w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    double *acc = lds_cam + j;
+                    __hip_atomic_fetch_add(acc + 0 * K, a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(acc + 1 * K, a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(acc + 2 * K, a2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(acc + 3 * K, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(acc + 4 * K, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(acc + 5 * K, w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 } else {
-                    __hip_atomic_fetch_add(acc + 0 * (int64_t)K + j, a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_fetch_add(acc + 1 * (int64_t)K + j, a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_fetch_add(acc + 2 * (int64_t)K + j, a2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_fetch_add(acc + 3 * (int64_t)K + j, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_fetch_add(acc + 4 * (int64_t)K + j, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_fetch_add(acc + 5 * (int64_t)K + j, w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    double *acc = a.cam_sums + j;
+                    const int64_t Kl = K;
+                    __hip_atomic_fetch_add(acc + 0 * Kl, a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(acc + 1 * Kl, a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(acc + 2 * Kl, a2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(acc + 3 * Kl, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(acc + 4 * Kl, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(acc + 5 * Kl, w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
 
@@ -375,6 +435,10 @@ __global__ void __launch_bounds__(EVAL_BLOCK) k_eval(EvalArgs a) {
                 c1 = __shfl(g1, 63);
                 c2 = __shfl(g2, 63);
             }
+
+            rec0 = rec1;
+            rec1 = rec2;
+            ops0 = ops1;
         }
         if (a.gX && lane == 0 && carry_i >= 0) {
             double *o = a.gX + 3 * (int64_t)carry_i;
@@ -400,6 +464,323 @@ __global__ void __launch_bounds__(EVAL_BLOCK) k_eval(EvalArgs a) {
     }
 }
 
+// --------------------------------------------------------------------------------------------
+// K2 (tiled form): the observation list is cut into tiles of a few hundred observations whose
+// boundaries fall on point boundaries.  A tile touches a contiguous range of points and a short
+// list of distinct cameras (a video track is seen by consecutive frames), so one workgroup keeps
+// everything a tile needs in LDS: the camera rows, X of its points, and the accumulators of both
+// sides.  The per-observation operand fetch is then LDS reads instead of scattered global loads
+// (which were bound by the vector-L1 rate), and both reductions are LDS atomics.
+// Observation records carry the camera's slot in the tile's list instead of its index.
+// --------------------------------------------------------------------------------------------
+constexpr int TILE_BLOCK = 256;
+constexpr int TILE_WAVES = TILE_BLOCK / 64;
+constexpr int ROW_LDS = 12;  // doubles of a camera row kept in LDS: R (9), C (3)
+
+// Everything a workgroup needs to know about its tile, fetched with one scalar load.
+struct TileMeta {
+    int32_t e0, e1;   // observation range
+    int32_t p0, np;   // first point and point span
+    int32_t nc;       // distinct cameras
+    int32_t j0;       // first camera when the cameras are the contiguous range j0 .. j0+nc-1, else -1
+    int64_t cb;       // offset of the tile's camera list in cam_list
+    int32_t wlo, whi; // points whose gradient this tile writes: its own and the unobserved ones up to
+                      // the next tile's first point (so that every point is written exactly once)
+};
+
+struct TileArgs {
+    const int32_t *oi;
+    const int32_t *oslot;
+    const double2 *ouv;
+    const TileMeta *meta;        // n_tiles
+    const int32_t *cam_list;     // distinct cameras of every tile, ascending
+    int n_tiles;
+    int K;
+    int cam_cap;                 // LDS capacity in cameras / points (max over tiles)
+    int pt_cap;
+    int cam_rep;                 // copies of the camera accumulators (power of two <= 16)
+    const double *X;
+    const double *T;
+    const double *scalars;
+    double *gX;        // may be null
+    double *cam_sums;  // 6 x K, component-major (pre-zeroed)
+    double *partials;  // per-tile {sum r^2, sum m.r}
+    int debug;
+};
+
+struct TileRec {
+    int i, slot;
+    double2 uv;
+};
+// lanes past the end of the tile read its last record (a valid address) and are masked later
+__device__ __forceinline__ TileRec load_tile_record(const TileArgs &a, int e, int e_last) {
+    const int ec = e < e_last ? e : e_last;
+    TileRec r;
+    r.i = a.oi[ec];
+    r.slot = a.oslot[ec];
+    r.uv = a.ouv[ec];
+    return r;
+}
+
+__global__ void __launch_bounds__(TILE_BLOCK) k_eval_tiled(TileArgs a) {
+    extern __shared__ double lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int t = blockIdx.x;
+    const TileMeta tm = a.meta[t];
+    const int e0 = tm.e0, e1 = tm.e1, p0 = tm.p0, np = tm.np, nc = tm.nc;
+    const int64_t cb = tm.cb;
+    __shared__ double red[2][TILE_WAVES];
+    if (e0 >= e1) {
+        if (tid == 0) {
+            a.partials[2 * (int64_t)t + 0] = 0.0;
+            a.partials[2 * (int64_t)t + 1] = 0.0;
+        }
+        return;
+    }
+    // records of this wave's first two steps: issued before anything else so that they travel
+    // together with the tile's camera rows and points
+    const int e_last = e1 - 1;
+    int base = e0 + wid * 64;
+    TileRec recA = load_tile_record(a, base + lane, e_last);
+    TileRec recB = load_tile_record(a, base + TILE_BLOCK + lane, e_last);
+
+    // Same-address LDS atomics serialise (about one conflict-free instruction per colliding lane),
+    // and lanes of one wave share cameras (track after track covers the same frames).  The camera
+    // accumulators are therefore kept in cam_rep copies selected by the low lane bits, which
+    // separates the colliding lanes; the copies are added up when the tile is flushed.
+    const int rep = a.cam_rep;
+    double *rows = lds;                                        // cam_cap x ROW_LDS
+    double *cacc = rows + (size_t)a.cam_cap * ROW_LDS;         // rep x 6 x nc (component-major)
+    double *xs = cacc + (size_t)a.cam_cap * 6 * rep;           // np x 3
+    double *pacc = xs + (size_t)a.pt_cap * 3;                  // np x 3
+
+    for (int idx = tid; idx < nc * (ROW_LDS / 2); idx += TILE_BLOCK) {
+        const int row = idx / (ROW_LDS / 2), piece = idx - row * (ROW_LDS / 2);
+        const int j = tm.j0 >= 0 ? tm.j0 + row : a.cam_list[cb + row];
+        ((double2 *)rows)[idx] = ((const double2 *)(a.T + (int64_t)j * CAM_ROW))[piece];
+    }
+    for (int idx = tid; idx < 6 * nc * rep; idx += TILE_BLOCK) cacc[idx] = 0.0;
+    for (int idx = tid; idx < 3 * np; idx += TILE_BLOCK) {
+        xs[idx] = a.X[3 * (int64_t)p0 + idx];
+        pacc[idx] = 0.0;
+    }
+    double *cacc_lane = cacc + (size_t)(lane & (rep - 1)) * 6 * nc;
+    const double f = a.scalars[SC_F], pcx = a.scalars[SC_CX], pcy = a.scalars[SC_CY];
+    __syncthreads();
+
+    double esum = 0.0, psum = 0.0;
+    for (; base < e1; base += TILE_BLOCK) {
+        const TileRec recC = load_tile_record(a, base + 2 * TILE_BLOCK + lane, e_last);
+        const bool valid = base + lane < e1;
+        const int li = valid ? recA.i - p0 : -2;
+        const int slot = recA.slot;
+        const double2 uv = recA.uv;
+        recA = recB;
+        recB = recC;
+        const double2 *rw = (const double2 *)(rows + slot * ROW_LDS);
+        const double2 t0 = rw[0], t1 = rw[1], t2 = rw[2], t3 = rw[3], t4 = rw[4], t5 = rw[5];
+        const double *x = xs + 3 * (valid ? li : 0);
+        const double R00 = t0.x, R01 = t0.y, R02 = t1.x, R10 = t1.y, R11 = t2.x, R12 = t2.y, R20 = t3.x,
+                     R21 = t3.y, R22 = t4.x;
+        const double d0 = x[0] - t4.y, d1 = x[1] - t5.x, d2 = x[2] - t5.y;
+        const double q0 = R00 * d0 + R10 * d1 + R20 * d2;
+        const double q1 = R01 * d0 + R11 * d1 + R21 * d2;
+        const double q2 = R02 * d0 + R12 * d1 + R22 * d2;
+        const double inv = 1.0 / q2;
+        const double m0 = q0 * inv, m1 = q1 * inv;
+        const double r0 = valid ? f * m0 + pcx - uv.x : 0.0;
+        const double r1 = valid ? f * m1 + pcy - uv.y : 0.0;
+        esum += r0 * r0 + r1 * r1;
+        const double mr = m0 * r0 + m1 * r1;
+        psum += mr;
+        const double fi = f * inv;
+        const double a0 = fi * r0, a1 = fi * r1, a2 = -fi * mr;  // camera-frame force g
+        double g0 = R00 * a0 + R01 * a1 + R02 * a2;            // world-frame dE/dX_i part
+        double g1 = R10 * a0 + R11 * a1 + R12 * a2;
+        double g2 = R20 * a0 + R21 * a1 + R22 * a2;
+        const double w0 = q1 * a2 - q2 * a1, w1 = q2 * a0 - q0 * a2, w2 = q0 * a1 - q1 * a0;  // torque q x g
+        if (a.debug & 1) {
+            asm volatile("" ::"v"(w0), "v"(w1), "v"(w2));
+        } else if (valid) {
+            double *acc = cacc_lane + slot;
+            __hip_atomic_fetch_add(acc + 0 * nc, a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(acc + 1 * nc, a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(acc + 2 * nc, a2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(acc + 3 * nc, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(acc + 4 * nc, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(acc + 5 * nc, w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (a.debug & 2) {
+            asm volatile("" ::"v"(g0), "v"(g1), "v"(g2));
+        } else {
+            // Point side: observations of one point are adjacent lanes.  Segmented inclusive scan
+            // inside every 16-lane row (DPP row shifts, no LDS traffic); the last lane of each run
+            // then holds the run's sum and adds it to the tile's point accumulator.  A run cut by a
+            // row or wave boundary simply contributes two partial sums.
+            const int lane16 = lane & 15;
+            const int ip = row_shr<1>(li);
+            const bool head = (lane16 == 0) || (ip != li);
+            const unsigned long long hm = __ballot(head);
+            const unsigned long long below = hm & (~0ull >> (63 - lane));
+            const int dist = lane - (63 - __clzll(below));
+            {
+                const double s0 = row_shr<1>(g0), s1 = row_shr<1>(g1), s2 = row_shr<1>(g2);
+                if (dist >= 1) { g0 += s0; g1 += s1; g2 += s2; }
+            }
+            {
+                const double s0 = row_shr<2>(g0), s1 = row_shr<2>(g1), s2 = row_shr<2>(g2);
+                if (dist >= 2) { g0 += s0; g1 += s1; g2 += s2; }
+            }
+            {
+                const double s0 = row_shr<4>(g0), s1 = row_shr<4>(g1), s2 = row_shr<4>(g2);
+                if (dist >= 4) { g0 += s0; g1 += s1; g2 += s2; }
+            }
+            {
+                const double s0 = row_shr<8>(g0), s1 = row_shr<8>(g1), s2 = row_shr<8>(g2);
+                if (dist >= 8) { g0 += s0; g1 += s1; g2 += s2; }
+            }
+            const bool tail = (lane == 63) || ((hm >> (lane + 1)) & 1ull);
+            if (tail && li >= 0) {
+                double *pa = pacc + 3 * li;
+                __hip_atomic_fetch_add(pa + 0, g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(pa + 1, g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(pa + 2, g2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+    esum = wave_sum(esum);
+    psum = wave_sum(psum);
+    if (lane == 0) {
+        red[0][wid] = esum;
+        red[1][wid] = psum;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        a.partials[2 * (int64_t)t + 0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        a.partials[2 * (int64_t)t + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+    if (a.gX) {
+        const int lo = 3 * (tm.wlo - p0), hi = 3 * (tm.whi - p0);  // relative to the tile's first point
+        double *o = a.gX + 3 * (int64_t)p0;
+        for (int idx = lo + tid; idx < hi; idx += TILE_BLOCK) o[idx] = (idx >= 0 && idx < 3 * np) ? pacc[idx] : 0.0;
+    }
+    for (int idx = tid; idx < 6 * nc; idx += TILE_BLOCK) {
+        const int comp = idx / nc, slot = idx - comp * nc;
+        const int j = tm.j0 >= 0 ? tm.j0 + slot : a.cam_list[cb + slot];
+        double v = cacc[idx];
+        for (int r = 1; r < rep; ++r) v += cacc[idx + (size_t)r * 6 * nc];
+        __hip_atomic_fetch_add(a.cam_sums + (int64_t)comp * a.K + j, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ---- tile construction -----------------------------------------------------------------------
+// Pass 1: number of distinct cameras and point span of every tile (one workgroup per tile; a
+// K-bit set in LDS).  Pass 2, after an exclusive scan of the counts: the ascending camera list of
+// every tile and, for every observation, its camera's position in that list.
+__device__ __forceinline__ void tile_camera_bitmap(const int32_t *oj, int e0, int e1, int n_words, unsigned *bits) {
+    for (int w = threadIdx.x; w < n_words; w += TILE_BLOCK) bits[w] = 0u;
+    __syncthreads();
+    for (int e = e0 + threadIdx.x; e < e1; e += TILE_BLOCK) {
+        const int j = oj[e];
+        atomicOr(&bits[j >> 5], 1u << (j & 31));
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(TILE_BLOCK) k_tile_count(const int32_t *__restrict__ oi, const int32_t *__restrict__ oj,
+                                                           const int32_t *__restrict__ tile_obs, int K,
+                                                           int64_t *__restrict__ counts, int *__restrict__ maxima) {
+    extern __shared__ unsigned bits[];
+    __shared__ int wsum[TILE_WAVES];
+    const int t = blockIdx.x;
+    const int e0 = tile_obs[t], e1 = tile_obs[t + 1];
+    const int n_words = (K + 31) >> 5;
+    tile_camera_bitmap(oj, e0, e1, n_words, bits);
+    int c = 0;
+    for (int w = threadIdx.x; w < n_words; w += TILE_BLOCK) c += __popc(bits[w]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        counts[t] = total;
+        atomicMax(&maxima[0], total);
+        if (e1 > e0) atomicMax(&maxima[1], oi[e1 - 1] - oi[e0] + 1);
+    }
+}
+
+__global__ void __launch_bounds__(TILE_BLOCK) k_tile_fill(const int32_t *__restrict__ oj, const int32_t *__restrict__ tile_obs,
+                                                          const int64_t *__restrict__ tile_cam_ptr, int K,
+                                                          const int32_t *__restrict__ oi, int64_t nV, int64_t N,
+                                                          int32_t *__restrict__ cam_list, int32_t *__restrict__ oslot,
+                                                          TileMeta *__restrict__ meta) {
+    extern __shared__ unsigned bits[];  // n_words bit set, then n_words exclusive prefix counts
+    __shared__ int wtot[TILE_WAVES];
+    __shared__ int carry;
+    const int t = blockIdx.x;
+    const int e0 = tile_obs[t], e1 = tile_obs[t + 1];
+    const int n_words = (K + 31) >> 5;
+    unsigned *prefix = bits + n_words;
+    tile_camera_bitmap(oj, e0, e1, n_words, bits);
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int base = 0; base < n_words; base += TILE_BLOCK) {
+        const int w = base + threadIdx.x;
+        const int c = (w < n_words) ? __popc(bits[w]) : 0;
+        int inc = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(inc, off);
+            if (lane >= off) inc += v;
+        }
+        if (lane == 63) wtot[wid] = inc;
+        __syncthreads();
+        int before = carry;
+        for (int k = 0; k < wid; ++k) before += wtot[k];
+        if (w < n_words) prefix[w] = (unsigned)(before + inc - c);
+        __syncthreads();
+        if (threadIdx.x == 0) carry += wtot[0] + wtot[1] + wtot[2] + wtot[3];
+        __syncthreads();
+    }
+    const int64_t cb = tile_cam_ptr[t];
+    if (threadIdx.x == 0) {
+        // lowest / highest camera of the tile from the bit set
+        const int nc = (int)(tile_cam_ptr[t + 1] - cb);
+        int lo = -1, hi = -1;
+        for (int w = 0; w < n_words && lo < 0; ++w)
+            if (bits[w]) lo = (w << 5) + __ffs(bits[w]) - 1;
+        for (int w = n_words - 1; w >= 0 && hi < 0; --w)
+            if (bits[w]) hi = (w << 5) + 31 - __clz(bits[w]);
+        TileMeta m;
+        m.e0 = e0;
+        m.e1 = e1;
+        m.p0 = e1 > e0 ? oi[e0] : 0;
+        m.np = e1 > e0 ? oi[e1 - 1] - m.p0 + 1 : 0;
+        m.nc = nc;
+        m.j0 = (nc > 0 && hi - lo + 1 == nc) ? lo : -1;
+        m.cb = cb;
+        m.wlo = e0 == 0 ? 0 : m.p0;
+        m.whi = e1 < nV ? oi[e1] : (int32_t)N;
+        meta[t] = m;
+    }
+    for (int w = threadIdx.x; w < n_words; w += TILE_BLOCK) {
+        unsigned m = bits[w];
+        int pos = (int)prefix[w];
+        while (m) {
+            const int b = __ffs(m) - 1;
+            cam_list[cb + pos++] = (w << 5) + b;
+            m &= m - 1;
+        }
+    }
+    for (int e = e0 + threadIdx.x; e < e1; e += TILE_BLOCK) {
+        const int j = oj[e];
+        const unsigned m = bits[j >> 5] & ((1u << (j & 31)) - 1u);
+        oslot[e] = (int)prefix[j >> 5] + __popc(m);
+    }
+}
+
 // partial sums -> sums[2]; camera-frame sums -> dE/dC, dE/dTheta (un-normalised)
 __global__ void __launch_bounds__(256) k_finalize(int64_t K, int n_partials, const double *__restrict__ partials,
                                                   const double *__restrict__ cam_sums, const double *__restrict__ T,
@@ -409,9 +790,21 @@ __global__ void __launch_bounds__(256) k_finalize(int64_t K, int n_partials, con
     if (blockIdx.x == 0) {
         __shared__ double red[2][4];
         double e = 0.0, p = 0.0;
-        for (int t = threadIdx.x; t < n_partials; t += 256) {
-            e += partials[2 * t + 0];
-            p += partials[2 * t + 1];
+        const double2 *pp = (const double2 *)partials;
+        int t = threadIdx.x;
+        for (; t + 7 * 256 < n_partials; t += 8 * 256) {  // 8 independent loads in flight per thread
+            double2 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = pp[t + k * 256];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                e += v[k].x;
+                p += v[k].y;
+            }
+        }
+        for (; t < n_partials; t += 256) {
+            e += pp[t].x;
+            p += pp[t].y;
         }
         e = wave_sum(e);
         p = wave_sum(p);
@@ -441,34 +834,172 @@ __global__ void __launch_bounds__(256) k_finalize(int64_t K, int n_partials, con
 // --------------------------------------------------------------------------------------------
 // K6: update rules (p2w:336-360)
 // --------------------------------------------------------------------------------------------
-__global__ void k_adam(int64_t n, double *__restrict__ x, const double *__restrict__ g, double *__restrict__ s,
-                       double *__restrict__ r, double lr, double gscale, double bc1, double bc2) {
+struct UpdateRule {
+    int mode;  // 0 = leave unchanged, 1 = SGD (p2w:336-342), 2 = Adam (p2w:344-360)
+    double lr, gscale, bc1, bc2;
+};
+
+// one parameter: returns the new value, updates the moments in place
+__device__ __forceinline__ double apply_rule(const UpdateRule &u, double x, double g, double *s, double *r) {
     const double rho1 = 0.9, rho2 = 0.999;
+    const double gr = g * u.gscale;
+    if (u.mode == 2) {
+        const double sn = rho1 * *s + (1.0 - rho1) * gr;
+        const double rn = rho2 * *r + (1.0 - rho2) * (gr * gr);
+        *s = sn;
+        *r = rn;
+        return x - u.lr * (sn / u.bc1) / (1e-12 + sqrt(rn / u.bc2));
+    }
+    return x - u.lr * gr;
+}
+
+// elementwise update of n parameters; `release` (optional) receives the values before the update
+__global__ void k_update(int64_t n, double *__restrict__ x, const double *__restrict__ g, double *__restrict__ s,
+                         double *__restrict__ r, double *__restrict__ release, UpdateRule u) {
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
-        const double gr = g[t] * gscale;
-        const double sn = rho1 * s[t] + (1.0 - rho1) * gr;
-        const double rn = rho2 * r[t] + (1.0 - rho2) * (gr * gr);
-        s[t] = sn;
-        r[t] = rn;
-        x[t] = x[t] - lr * (sn / bc1) / (1e-12 + sqrt(rn / bc2));
+        const double xo = x[t];
+        if (release) release[t] = xo;
+        double sv = 0.0, rv = 0.0;
+        if (u.mode == 2) {
+            sv = s[t];
+            rv = r[t];
+        }
+        x[t] = apply_rule(u, xo, g[t], &sv, &rv);
+        if (u.mode == 2) {
+            s[t] = sv;
+            r[t] = rv;
+        }
     }
 }
 
-__global__ void k_sgd(int64_t n, double *__restrict__ x, const double *__restrict__ g, double lr, double gscale) {
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
-        x[t] = x[t] - lr * (g[t] * gscale);
+// Points: update rule, snapshot of the old value and the rigid part of the gauge fix
+// X <- ((X - C0) @ R0) * factor (p2w:285-293, 327) in ONE pass over X and its moments.
+// A workgroup owns 256 consecutive points = 768 consecutive doubles of every array, which it
+// reads and writes element-wise (fully coalesced); the 3-vectors meet in LDS for the rotation.
+constexpr int PS_POINTS = 256;
+__global__ void __launch_bounds__(PS_POINTS) k_points_step(int64_t N, double *__restrict__ X,
+                                                           const double *__restrict__ gX, double *__restrict__ s,
+                                                           double *__restrict__ r, double *__restrict__ release,
+                                                           UpdateRule u, const double *__restrict__ gauge) {
+    __shared__ double xs[3 * PS_POINTS];
+    const int64_t base = (int64_t)blockIdx.x * (3 * PS_POINTS);
+    const int64_t n = 3 * N;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int l = k * PS_POINTS + threadIdx.x;
+        const int64_t t = base + l;
+        if (t < n) {
+            const double xo = X[t];
+            if (release) release[t] = xo;
+            double xn = xo;
+            if (u.mode) {
+                double sv = 0.0, rv = 0.0;
+                if (u.mode == 2) {
+                    sv = s[t];
+                    rv = r[t];
+                }
+                xn = apply_rule(u, xo, gX[t], &sv, &rv);
+                if (u.mode == 2) {
+                    s[t] = sv;
+                    r[t] = rv;
+                }
+            }
+            if (gauge) xs[l] = xn;
+            else X[t] = xn;
+        }
+    }
+    if (!gauge) return;
+    __syncthreads();
+    const double c0 = gauge[9], c1 = gauge[10], c2 = gauge[11], factor = gauge[12];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int l = k * PS_POINTS + threadIdx.x;
+        const int64_t t = base + l;
+        if (t < n) {
+            const int pt = l / 3, comp = l - 3 * pt;
+            const double d0 = xs[3 * pt + 0] - c0, d1 = xs[3 * pt + 1] - c1, d2 = xs[3 * pt + 2] - c2;
+            X[t] = (d0 * gauge[comp] + d1 * gauge[3 + comp] + d2 * gauge[6 + comp]) * factor;
+        }
+    }
 }
 
 // --------------------------------------------------------------------------------------------
-// K7: gauge fix (p2w:270-333)
+// K7: camera side of one step, single workgroup: update rule on the free slice of
+// [C | Theta | phi_x], then align_scene + normalize_scene for the cameras (p2w:270-333), then the
+// camera table and scalars of the NEW parameters, so that the next observation pass needs no
+// table kernel.  With the gauge fix the table holds R0^T R(Theta), the matrix align_scene returns
+// and the reference keeps using (p2w:711), and cos/sin(theta_z) recovered from its entries the way
+// p2w:665-676 does.  gauge[0..8] = R0, [9..11] = C0, [12] = scale factor, [13] = j1.
 // --------------------------------------------------------------------------------------------
-// single workgroup: cameras.  gauge[0..8] = R0, [9..11] = C0, [12] = scale factor, [13] = j1
-__global__ void __launch_bounds__(1024) k_gauge_cameras(int64_t K, double *__restrict__ C, double *__restrict__ Theta,
-                                                        double *__restrict__ R_out, double *__restrict__ gauge) {
+struct CameraStep {
+    int64_t K;
+    double *cam;          // [C (3K) | Theta (3K) | phi_x (1)]
+    const double *g;      // gradient in the same packing (may be null when mode == 0)
+    double *s, *r;        // Adam moments, same packing
+    double *release;      // optional snapshot of the free slice before the update
+    int64_t lo, hi;       // free slice
+    UpdateRule rule;
+    int do_gauge;
+    double W, H;
+    double *T;            // camera table (K x CAM_ROW), may be null
+    double *scalars;      // may be null
+    double *R_out;        // optional K x 9
+    double *gauge;        // optional 16
+};
+
+__global__ void __launch_bounds__(1024) k_camera_step(CameraStep a) {
     __shared__ double sR0[9], sC0[3];
     __shared__ double red_v[16];
     __shared__ long long red_j[16];
     __shared__ double s_factor;
+    const int64_t K = a.K;
+    double *C = a.cam, *Theta = a.cam + 3 * K;
+
+    if (a.rule.mode) {
+        for (int64_t t = a.lo + threadIdx.x; t < a.hi; t += 1024) {
+            const double xo = a.cam[t];
+            if (a.release) a.release[t] = xo;
+            double sv = 0.0, rv = 0.0;
+            if (a.rule.mode == 2) {
+                sv = a.s[t];
+                rv = a.r[t];
+            }
+            a.cam[t] = apply_rule(a.rule, xo, a.g[t], &sv, &rv);
+            if (a.rule.mode == 2) {
+                a.s[t] = sv;
+                a.r[t] = rv;
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && a.scalars) {
+        const double ph = a.cam[6 * K];
+        const double f = a.W / 2.0 / tan(ph / 2.0);
+        a.scalars[SC_F] = f;
+        a.scalars[SC_CX] = a.W / 2.0;
+        a.scalars[SC_CY] = a.H / 2.0;
+        a.scalars[SC_DPHI] = -f / sin(ph);
+    }
+
+    if (!a.do_gauge) {
+        if (a.T) {
+            for (int64_t j = threadIdx.x; j < K; j += 1024) {
+                double R[9], cz, sz;
+                rotation_yxz(Theta[3 * j + 0], Theta[3 * j + 1], Theta[3 * j + 2], R, &cz, &sz);
+                double *row = a.T + j * CAM_ROW;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) row[k] = R[k];
+                row[9] = C[3 * j + 0];
+                row[10] = C[3 * j + 1];
+                row[11] = C[3 * j + 2];
+                row[12] = cz;
+                row[13] = sz;
+            }
+        }
+        return;
+    }
+
     if (threadIdx.x == 0) {
         double cz, sz;
         rotation_yxz(Theta[0], Theta[1], Theta[2], sR0, &cz, &sz);
@@ -498,18 +1029,25 @@ __global__ void __launch_bounds__(1024) k_gauge_cameras(int64_t K, double *__res
         rotation_yxz(Theta[3 * j + 0], Theta[3 * j + 1], Theta[3 * j + 2], R, &cz, &sz);
         double Rn[9];  // R0^T R
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
+        for (int p = 0; p < 3; ++p)
 #pragma unroll
-            for (int b = 0; b < 3; ++b) Rn[3 * a + b] = R0[a] * R[b] + R0[3 + a] * R[3 + b] + R0[6 + a] * R[6 + b];
+            for (int q = 0; q < 3; ++q) Rn[3 * p + q] = R0[p] * R[q] + R0[3 + p] * R[3 + q] + R0[6 + p] * R[6 + q];
         // get_rotations (p2w:260-266)
         const double Cx = sqrt(Rn[3] * Rn[3] + Rn[4] * Rn[4]);
         const double Sx = -Rn[5];
         Theta[3 * j + 0] = atan2(Sx, Cx);
         Theta[3 * j + 1] = atan2(Rn[2] / Cx, Rn[8] / Cx);
         Theta[3 * j + 2] = atan2(Rn[3] / Cx, Rn[4] / Cx);
-        if (R_out) {
+        if (a.R_out) {
 #pragma unroll
-            for (int k = 0; k < 9; ++k) R_out[9 * j + k] = Rn[k];
+            for (int k = 0; k < 9; ++k) a.R_out[9 * j + k] = Rn[k];
+        }
+        if (a.T) {
+            double *row = a.T + j * CAM_ROW;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) row[k] = Rn[k];
+            row[12] = Rn[4] / Cx;  // cos(theta_z), p2w:674
+            row[13] = Rn[3] / Cx;  // sin(theta_z), p2w:675
         }
         if (j >= 1) {
             const double nn = n0 * n0 + n1 * n1 + n2 * n2;
@@ -533,6 +1071,7 @@ __global__ void __launch_bounds__(1024) k_gauge_cameras(int64_t K, double *__res
         red_v[threadIdx.x >> 6] = best;
         red_j[threadIdx.x >> 6] = best_j;
     }
+    __threadfence_block();
     __syncthreads();
     if (threadIdx.x == 0) {
         double bv = red_v[0];
@@ -545,21 +1084,335 @@ __global__ void __launch_bounds__(1024) k_gauge_cameras(int64_t K, double *__res
         }
         const double factor = 1.0 / sqrt(bv);
         s_factor = factor;
-        if (gauge) {
+        if (a.gauge) {
 #pragma unroll
-            for (int k = 0; k < 9; ++k) gauge[k] = R0[k];
-            gauge[9] = c00;
-            gauge[10] = c01;
-            gauge[11] = c02;
-            gauge[12] = factor;
-            gauge[13] = (double)bj;
-            gauge[14] = 0.0;
-            gauge[15] = 0.0;
+            for (int k = 0; k < 9; ++k) a.gauge[k] = R0[k];
+            a.gauge[9] = c00;
+            a.gauge[10] = c01;
+            a.gauge[11] = c02;
+            a.gauge[12] = factor;
+            a.gauge[13] = (double)bj;
+            a.gauge[14] = 0.0;
+            a.gauge[15] = 0.0;
         }
     }
     __syncthreads();
     const double factor = s_factor;
-    for (int64_t t = threadIdx.x; t < 3 * K; t += 1024) C[t] *= factor;
+    for (int64_t j = threadIdx.x; j < K; j += 1024) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double c = C[3 * j + k] * factor;
+            C[3 * j + k] = c;
+            if (a.T) a.T[j * CAM_ROW + 9 + k] = c;
+        }
+    }
+}
+
+// The same step spread over ceil(K/256) workgroups.  The only cross-workgroup dependencies are
+// camera 0 (whose new pose defines the rigid motion) and the longest baseline (which defines the
+// scale):
+//   * every workgroup recomputes camera 0's update from its OLD parameters, which nobody
+//     overwrites before the end: camera 0's own results are staged in `stage` by workgroup 0;
+//   * every workgroup publishes its best baseline and takes a ticket; the workgroup that draws
+//     the last ticket reduces the baselines, scales all centres, writes camera 0 and phi_x.
+// Publication follows the agent-scope release / acquire protocol (stores, vmcnt(0), barrier,
+// release fence, relaxed ticket; last arriver: acquire fence, barrier, plain loads).
+struct CameraStepShared {
+    int *counter;         // zero before the launch; reset by the last workgroup
+    double *block_best;   // 2 per workgroup: squared baseline, camera index
+    double *stage;        // 16: camera 0's Theta (3), moments s (6), r (6)
+};
+
+__device__ __forceinline__ void camera_pose_update(const CameraStep &a, int64_t j, bool write, double *c, double *th,
+                                                   double *s_out, double *r_out) {
+    const int64_t K = a.K;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int64_t t = (k < 3) ? 3 * j + k : 3 * K + 3 * j + (k - 3);
+        const double xo = a.cam[t];
+        double xn = xo, sv = 0.0, rv = 0.0;
+        if (a.rule.mode && t >= a.lo && t < a.hi) {
+            if (write && a.release) a.release[t] = xo;
+            if (a.rule.mode == 2) {
+                sv = a.s[t];
+                rv = a.r[t];
+            }
+            xn = apply_rule(a.rule, xo, a.g[t], &sv, &rv);
+            if (write && a.rule.mode == 2) {
+                a.s[t] = sv;
+                a.r[t] = rv;
+            }
+        }
+        if (s_out) {
+            s_out[k] = sv;
+            r_out[k] = rv;
+        }
+        if (k < 3) c[k] = xn;
+        else th[k - 3] = xn;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_camera_step_mb(CameraStep a, CameraStepShared sh) {
+    __shared__ double sR0[9], sC0[3];
+    __shared__ double red_v[4];
+    __shared__ long long red_j[4];
+    __shared__ int s_last;
+    __shared__ double s_factor;
+    const int64_t K = a.K;
+    double *C = a.cam, *Theta = a.cam + 3 * K;
+    const int tid = threadIdx.x;
+    const int64_t j = (int64_t)blockIdx.x * 256 + tid;
+
+    if (!a.do_gauge) {
+        // independent cameras: update, then the table row of the new pose
+        if (j < K) {
+            double c[3], th[3];
+            camera_pose_update(a, j, true, c, th, nullptr, nullptr);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                C[3 * j + k] = c[k];
+                Theta[3 * j + k] = th[k];
+            }
+            if (a.T) {
+                double R[9], cz, sz;
+                rotation_yxz(th[0], th[1], th[2], R, &cz, &sz);
+                double *row = a.T + j * CAM_ROW;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) row[k] = R[k];
+                row[9] = c[0];
+                row[10] = c[1];
+                row[11] = c[2];
+                row[12] = cz;
+                row[13] = sz;
+            }
+        }
+        if (j == 0) {
+            const int64_t t = 6 * K;
+            double ph = a.cam[t];
+            if (a.rule.mode && t >= a.lo && t < a.hi) {
+                if (a.release) a.release[t] = ph;
+                double sv = 0.0, rv = 0.0;
+                if (a.rule.mode == 2) {
+                    sv = a.s[t];
+                    rv = a.r[t];
+                }
+                ph = apply_rule(a.rule, ph, a.g[t], &sv, &rv);
+                if (a.rule.mode == 2) {
+                    a.s[t] = sv;
+                    a.r[t] = rv;
+                }
+                a.cam[t] = ph;
+            }
+            if (a.scalars) {
+                const double f = a.W / 2.0 / tan(ph / 2.0);
+                a.scalars[SC_F] = f;
+                a.scalars[SC_CX] = a.W / 2.0;
+                a.scalars[SC_CY] = a.H / 2.0;
+                a.scalars[SC_DPHI] = -f / sin(ph);
+            }
+        }
+        return;
+    }
+
+    // camera 0's new pose, from its old parameters (identical in every workgroup)
+    if (tid == 0) {
+        double c[3], th[3], s6[6], r6[6], cz, sz;
+        camera_pose_update(a, 0, false, c, th, s6, r6);
+        rotation_yxz(th[0], th[1], th[2], sR0, &cz, &sz);
+        sC0[0] = c[0];
+        sC0[1] = c[1];
+        sC0[2] = c[2];
+        if (blockIdx.x == 0) {
+            // camera 0 after the gauge fix: centre 0, angles of R0^T R0; staged until the end
+            double Rn[9];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    Rn[3 * p + q] = sR0[p] * sR0[q] + sR0[3 + p] * sR0[3 + q] + sR0[6 + p] * sR0[6 + q];
+            const double Cx = sqrt(Rn[3] * Rn[3] + Rn[4] * Rn[4]);
+            sh.stage[0] = atan2(-Rn[5], Cx);
+            sh.stage[1] = atan2(Rn[2] / Cx, Rn[8] / Cx);
+            sh.stage[2] = atan2(Rn[3] / Cx, Rn[4] / Cx);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                sh.stage[3 + k] = s6[k];
+                sh.stage[9 + k] = r6[k];
+            }
+            if (a.R_out) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) a.R_out[k] = Rn[k];
+            }
+            if (a.T) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) a.T[k] = Rn[k];
+                a.T[9] = 0.0;
+                a.T[10] = 0.0;
+                a.T[11] = 0.0;
+                a.T[12] = Rn[4] / Cx;
+                a.T[13] = Rn[3] / Cx;
+            }
+        }
+    }
+    __syncthreads();
+    double R0[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R0[k] = sR0[k];
+    const double c00 = sC0[0], c01 = sC0[1], c02 = sC0[2];
+
+    double best = -1.0;
+    long long best_j = K;
+    if (j >= 1 && j < K) {
+        double c[3], th[3];
+        camera_pose_update(a, j, true, c, th, nullptr, nullptr);
+        const double d0 = c[0] - c00, d1 = c[1] - c01, d2 = c[2] - c02;
+        const double n0 = d0 * R0[0] + d1 * R0[3] + d2 * R0[6];  // (C - C0) @ R0
+        const double n1 = d0 * R0[1] + d1 * R0[4] + d2 * R0[7];
+        const double n2 = d0 * R0[2] + d1 * R0[5] + d2 * R0[8];
+        C[3 * j + 0] = n0;
+        C[3 * j + 1] = n1;
+        C[3 * j + 2] = n2;
+        double R[9], cz, sz;
+        rotation_yxz(th[0], th[1], th[2], R, &cz, &sz);
+        double Rn[9];  // R0^T R
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) Rn[3 * p + q] = R0[p] * R[q] + R0[3 + p] * R[3 + q] + R0[6 + p] * R[6 + q];
+        const double Cx = sqrt(Rn[3] * Rn[3] + Rn[4] * Rn[4]);  // get_rotations (p2w:260-266)
+        Theta[3 * j + 0] = atan2(-Rn[5], Cx);
+        Theta[3 * j + 1] = atan2(Rn[2] / Cx, Rn[8] / Cx);
+        Theta[3 * j + 2] = atan2(Rn[3] / Cx, Rn[4] / Cx);
+        if (a.R_out) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) a.R_out[9 * j + k] = Rn[k];
+        }
+        if (a.T) {
+            double *row = a.T + j * CAM_ROW;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) row[k] = Rn[k];
+            row[12] = Rn[4] / Cx;  // cos(theta_z), p2w:674
+            row[13] = Rn[3] / Cx;  // sin(theta_z), p2w:675
+        }
+        best = n0 * n0 + n1 * n1 + n2 * n2;
+        best_j = j;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {  // argmax, ties to the smaller index (p2w:322)
+        const double ov = __shfl_xor(best, off);
+        const long long oj = __shfl_xor(best_j, off);
+        if (ov > best || (ov == best && oj < best_j)) {
+            best = ov;
+            best_j = oj;
+        }
+    }
+    if ((tid & 63) == 0) {
+        red_v[tid >> 6] = best;
+        red_j[tid >> 6] = best_j;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w) {
+            if (red_v[w] > best || (red_v[w] == best && red_j[w] < best_j)) {
+                best = red_v[w];
+                best_j = red_j[w];
+            }
+        }
+        sh.block_best[2 * blockIdx.x + 0] = best;
+        sh.block_best[2 * blockIdx.x + 1] = (double)best_j;
+    }
+    // publish this workgroup's results and take a ticket
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int ticket = __hip_atomic_fetch_add(sh.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = ticket == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+
+    // last workgroup: everything the others wrote is visible after the acquire
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double bv = -1.0;
+        long long bj = K;
+        for (int b = 0; b < (int)gridDim.x; ++b) {
+            const double v = sh.block_best[2 * b + 0];
+            const long long vj = (long long)sh.block_best[2 * b + 1];
+            if (v > bv || (v == bv && vj < bj)) {
+                bv = v;
+                bj = vj;
+            }
+        }
+        const double factor = 1.0 / sqrt(bv);
+        s_factor = factor;
+        if (a.gauge) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) a.gauge[k] = R0[k];
+            a.gauge[9] = c00;
+            a.gauge[10] = c01;
+            a.gauge[11] = c02;
+            a.gauge[12] = factor;
+            a.gauge[13] = (double)bj;
+            a.gauge[14] = 0.0;
+            a.gauge[15] = 0.0;
+        }
+        // camera 0: snapshot of the old pose, new moments, gauge-fixed pose
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int64_t t = (k < 3) ? k : 3 * K + (k - 3);
+            if (a.rule.mode && t >= a.lo && t < a.hi) {
+                if (a.release) a.release[t] = a.cam[t];
+                if (a.rule.mode == 2) {
+                    a.s[t] = sh.stage[3 + k];
+                    a.r[t] = sh.stage[9 + k];
+                }
+            }
+            a.cam[t] = (k < 3) ? 0.0 : sh.stage[k - 3];
+        }
+        *sh.counter = 0;
+    }
+    if (tid == 64) {  // phi_x and the scalars that depend on it
+        const int64_t t = 6 * K;
+        double ph = a.cam[t];
+        if (a.rule.mode && t >= a.lo && t < a.hi) {
+            if (a.release) a.release[t] = ph;
+            double sv = 0.0, rv = 0.0;
+            if (a.rule.mode == 2) {
+                sv = a.s[t];
+                rv = a.r[t];
+            }
+            ph = apply_rule(a.rule, ph, a.g[t], &sv, &rv);
+            if (a.rule.mode == 2) {
+                a.s[t] = sv;
+                a.r[t] = rv;
+            }
+            a.cam[t] = ph;
+        }
+        if (a.scalars) {
+            const double f = a.W / 2.0 / tan(ph / 2.0);
+            a.scalars[SC_F] = f;
+            a.scalars[SC_CX] = a.W / 2.0;
+            a.scalars[SC_CY] = a.H / 2.0;
+            a.scalars[SC_DPHI] = -f / sin(ph);
+        }
+    }
+    __syncthreads();
+    const double factor = s_factor;
+    for (int64_t jj = 1 + tid; jj < K; jj += 256) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double c = C[3 * jj + k] * factor;
+            C[3 * jj + k] = c;
+            if (a.T) a.T[jj * CAM_ROW + 9 + k] = c;
+        }
+    }
 }
 
 __global__ void k_gauge_points(int64_t N, double *__restrict__ X, const double *__restrict__ gauge) {
@@ -621,6 +1474,85 @@ static int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 using namespace ba;
 
+// Cuts the observation list into LDS tiles (see k_eval_tiled).  The tile is halved until the
+// camera rows, the points and both accumulator sets of the largest tile fit the LDS budget of a
+// workgroup; scenes whose tiles would each need most of the cameras keep p->tiled == 0 and run
+// the wave-chunk kernel instead.
+static int build_tiles(ba_problem *p) {
+    const int64_t K = p->K, nV = p->nV;
+    const int n_words = (int)((K + 31) >> 5);
+    const size_t lds_budget = 64 * 1024;
+    int tobs = 2048;
+    if (const char *env = getenv("BA_TILE_OBS")) tobs = atoi(env);
+    if (tobs < 64 || (size_t)n_words * 8 > lds_budget) return BA_OK;
+    int *maxima = p->flag;  // 2 ints of the handle's flag buffer
+    int nt = 0;
+    for (;; tobs /= 2) {
+        if (tobs < 64) return BA_OK;
+        nt = (int)((nV + tobs - 1) / tobs);
+        hipFree(p->tile_obs);
+        hipFree(p->tile_cam_ptr);
+        p->tile_obs = nullptr;
+        p->tile_cam_ptr = nullptr;
+        BA_HIP(hipMalloc(&p->tile_obs, sizeof(int32_t) * (nt + 1)));
+        BA_HIP(hipMalloc(&p->tile_cam_ptr, sizeof(int64_t) * (nt + 1)));
+        BA_HIP(hipMemset(maxima, 0, 8));
+        hipLaunchKernelGGL(k_chunk_bounds, dim3(cdiv(nt + 1, 256)), dim3(256), 0, 0, p->oi, nV, nt, (int64_t)tobs,
+                           p->tile_obs);
+        hipLaunchKernelGGL(k_tile_count, dim3(nt), dim3(TILE_BLOCK), sizeof(unsigned) * n_words, 0, p->oi, p->oj,
+                           p->tile_obs, (int)K, p->tile_cam_ptr, maxima);
+        BA_HIP(hipGetLastError());
+        int hmax[2];
+        BA_HIP(hipMemcpy(hmax, maxima, 8, hipMemcpyDeviceToHost));
+        int rep = 16;
+        if (const char *env = getenv("BA_CAM_REP")) rep = atoi(env);
+        size_t need = 0;
+        for (;; rep >>= 1) {  // fewer accumulator copies rather than fewer workgroups per CU
+            need = sizeof(double) * ((size_t)(ROW_LDS + 6 * rep) * hmax[0] + 6 * (size_t)hmax[1]);
+            if (need <= lds_budget / 4 || rep <= 1) break;
+        }
+        if (need <= lds_budget) {
+            p->cam_rep = rep < 1 ? 1 : rep;
+            p->n_tiles = nt;
+            p->tile_obs_target = tobs;
+            p->cam_cap = hmax[0];
+            p->pt_cap = hmax[1];
+            p->tile_lds_bytes = need;
+            break;
+        }
+    }
+    // exclusive scan of the per-tile camera counts -> offsets into cam_list
+    const int n_scan_tiles = cdiv(nt, SCAN_TILE);
+    int64_t *tile_sums = nullptr;
+    BA_HIP(hipMalloc(&tile_sums, sizeof(int64_t) * (n_scan_tiles + 1)));
+    hipLaunchKernelGGL(k_scan_tiles, dim3(n_scan_tiles), dim3(1024), 0, 0, p->tile_cam_ptr, (int64_t)nt, p->tile_cam_ptr,
+                       tile_sums);
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(1), dim3(1024), 0, 0, tile_sums, n_scan_tiles);
+    hipLaunchKernelGGL(k_scan_add, dim3(cdiv(nt, 256)), dim3(256), 0, 0, p->tile_cam_ptr, (int64_t)nt, tile_sums,
+                       n_scan_tiles);
+    int64_t total_cams = 0;
+    hipError_t e = hipMemcpy(&total_cams, p->tile_cam_ptr + nt, sizeof(int64_t), hipMemcpyDeviceToHost);
+    hipFree(tile_sums);
+    BA_HIP(e);
+    // tiles pay off only while fetching every tile's camera rows stays small next to the
+    // observation stream
+    const bool worth = getenv("BA_FORCE_TILES") || (double)total_cams * 128.0 <= 0.5 * 24.0 * (double)nV;
+    if (worth) {
+        BA_HIP(hipMalloc(&p->cam_list, sizeof(int32_t) * (total_cams > 0 ? total_cams : 1)));
+        BA_HIP(hipMalloc(&p->oslot, sizeof(int32_t) * nV));
+        BA_HIP(hipMalloc(&p->tile_meta, sizeof(TileMeta) * nt));
+        hipLaunchKernelGGL(k_tile_fill, dim3(nt), dim3(TILE_BLOCK), sizeof(unsigned) * 2 * n_words, 0, p->oj, p->tile_obs,
+                           p->tile_cam_ptr, (int)K, p->oi, nV, p->N, p->cam_list, p->oslot, (TileMeta *)p->tile_meta);
+        BA_HIP(hipGetLastError());
+        p->tiled = 1;
+    }
+    if (getenv("BA_VERBOSE"))
+        fprintf(stderr, "[ba] tiles: tiled=%d n_tiles=%d target_obs=%d cam_cap=%d pt_cap=%d rep=%d lds=%zu B cams/tile=%.1f\n",
+                p->tiled, p->n_tiles, p->tile_obs_target, p->cam_cap, p->pt_cap, p->cam_rep, p->tile_lds_bytes,
+                nt ? (double)total_cams / nt : 0.0);
+    return BA_OK;
+}
+
 // ============================================================================================
 // C ABI
 // ============================================================================================
@@ -681,10 +1613,18 @@ int ba_problem_destroy(ba_problem *p) {
     hipFree(p->oj);
     hipFree(p->ouv);
     hipFree(p->chunk_begin);
+    hipFree(p->tile_obs);
+    hipFree(p->tile_cam_ptr);
+    hipFree(p->cam_list);
+    hipFree(p->oslot);
+    hipFree(p->tile_meta);
     hipFree(p->cam_table);
     hipFree(p->cam_sums);
     hipFree(p->partials);
     hipFree(p->scalars);
+    hipFree(p->step_counter);
+    hipFree(p->step_best);
+    hipFree(p->step_stage);
     hipFree(p->flag);
     for (auto e : p->ev_begin) hipEventDestroy(e);
     for (auto e : p->ev_end) hipEventDestroy(e);
@@ -771,10 +1711,20 @@ int ba_problem_create(int64_t N, int64_t K, int64_t nV, const int32_t *i, const 
                        p->chunk_begin);
     BA_TRY(hipGetLastError());
 
+    if (int rc_tiles = build_tiles(p)) return fail(rc_tiles);
+
     BA_TRY(hipMalloc(&p->cam_table, sizeof(double) * K * CAM_ROW));
     BA_TRY(hipMalloc(&p->cam_sums, sizeof(double) * K * 6));
-    BA_TRY(hipMalloc(&p->partials, sizeof(double) * 2 * (size_t)p->grid * EVAL_WAVES));
+    {
+        size_t n_part = (size_t)p->grid * EVAL_WAVES;
+        if ((size_t)p->n_tiles > n_part) n_part = p->n_tiles;
+        BA_TRY(hipMalloc(&p->partials, sizeof(double) * 2 * n_part));
+    }
     BA_TRY(hipMalloc(&p->scalars, sizeof(double) * SC_COUNT));
+    BA_TRY(hipMalloc(&p->step_counter, 16));
+    BA_TRY(hipMemset(p->step_counter, 0, 16));
+    BA_TRY(hipMalloc(&p->step_best, sizeof(double) * 2 * cdiv(K, 256)));
+    BA_TRY(hipMalloc(&p->step_stage, sizeof(double) * 16));
     p->ev_begin.resize(TIMING_RING);
     p->ev_end.resize(TIMING_RING);
     for (int t = 0; t < TIMING_RING; ++t) {
@@ -808,11 +1758,15 @@ int ba_eval(ba_problem *p, const double *X, const double *C, const double *Theta
     hipStream_t st = (hipStream_t)stream;
     const int64_t K = p->K;
 
-    hipLaunchKernelGGL(k_camera_table, dim3(cdiv(K, 256)), dim3(256), 0, st, K, C, Theta, phi, p->W, p->H, p->cam_table,
-                       p->scalars);
+    if (!(flags & BA_EVAL_REUSE_TABLE))
+        hipLaunchKernelGGL(k_camera_table, dim3(cdiv(K, 256)), dim3(256), 0, st, K, C, Theta, phi, p->W, p->H,
+                           p->cam_table, p->scalars);
     BA_HIP(hipMemsetAsync(p->cam_sums, 0, sizeof(double) * 6 * K, st));
     const bool want_gx = (flags & BA_EVAL_GRAD_X) != 0;
-    if (want_gx && p->n_points_seen < p->N) BA_HIP(hipMemsetAsync(gX, 0, sizeof(double) * 3 * p->N, st));
+    const bool use_tiles = p->tiled && !(flags & (BA_EVAL_CAM_ATOMICS | BA_EVAL_UNTILED));
+    // the tiled pass writes every point's gradient itself; the wave-chunk pass only the observed ones
+    if (want_gx && !use_tiles && p->n_points_seen < p->N)
+        BA_HIP(hipMemsetAsync(gX, 0, sizeof(double) * 3 * p->N, st));
 
     EvalArgs a;
     a.oi = p->oi;
@@ -827,12 +1781,36 @@ int ba_eval(ba_problem *p, const double *X, const double *C, const double *Theta
     a.gX = want_gx ? gX : nullptr;
     a.cam_sums = p->cam_sums;
     a.partials = p->partials;
+    a.debug = (flags >> 6) & 7;
+    if (a.debug & 2) a.gX = nullptr;
 
     const size_t lds_bytes = sizeof(double) * 6 * (size_t)K;
     const bool use_lds = !(flags & BA_EVAL_CAM_ATOMICS) && lds_bytes <= (size_t)p->lds_limit;
     const bool timed = (flags & BA_EVAL_TIMED) != 0 && p->ev_count < TIMING_RING;
+    int n_partials = p->grid * EVAL_WAVES;
     if (timed) BA_HIP(hipEventRecord(p->ev_begin[p->ev_count], st));
-    if (use_lds) {
+    if (use_tiles) {
+        TileArgs ta;
+        ta.oi = p->oi;
+        ta.oslot = p->oslot;
+        ta.ouv = p->ouv;
+        ta.meta = (const TileMeta *)p->tile_meta;
+        ta.cam_list = p->cam_list;
+        ta.n_tiles = p->n_tiles;
+        ta.K = (int)K;
+        ta.cam_cap = p->cam_cap;
+        ta.pt_cap = p->pt_cap;
+        ta.cam_rep = p->cam_rep;
+        ta.X = X;
+        ta.T = p->cam_table;
+        ta.scalars = p->scalars;
+        ta.gX = a.gX;
+        ta.cam_sums = p->cam_sums;
+        ta.partials = p->partials;
+        ta.debug = a.debug;
+        n_partials = p->n_tiles;
+        hipLaunchKernelGGL(k_eval_tiled, dim3(p->n_tiles), dim3(TILE_BLOCK), p->tile_lds_bytes, st, ta);
+    } else if (use_lds) {
         if (lds_bytes > 64 * 1024)
             BA_HIP(hipFuncSetAttribute((const void *)k_eval<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds_bytes));
@@ -846,7 +1824,7 @@ int ba_eval(ba_problem *p, const double *X, const double *C, const double *Theta
         p->ev_count++;
     }
     const bool want_cam = (flags & BA_EVAL_GRAD_CAM) != 0;
-    hipLaunchKernelGGL(k_finalize, dim3(want_cam ? cdiv(K, 256) : 1), dim3(256), 0, st, K, p->grid * EVAL_WAVES,
+    hipLaunchKernelGGL(k_finalize, dim3(want_cam ? cdiv(K, 256) : 1), dim3(256), 0, st, K, n_partials,
                        p->partials, p->cam_sums, p->cam_table, p->scalars, E_sum,
                        (flags & BA_EVAL_GRAD_PHI) ? gphi : nullptr, want_cam ? gC : nullptr,
                        want_cam ? gTheta : nullptr);
@@ -866,23 +1844,79 @@ int ba_eval_timing(ba_problem *p, float *h_ms, int capacity, int *h_count) {
     return BA_OK;
 }
 
+static UpdateRule make_rule(int mode, double lr, double gscale, double bc1, double bc2) {
+    UpdateRule u;
+    u.mode = mode;
+    u.lr = lr;
+    u.gscale = gscale;
+    u.bc1 = bc1;
+    u.bc2 = bc2;
+    return u;
+}
+
 int ba_adam_step(int64_t n, double *x, const double *g, double *s, double *r, double lr, double gscale, double bc1,
-                 double bc2, void *stream) {
+                 double bc2, double *release, void *stream) {
     BA_REQUIRE(n >= 0 && (n == 0 || (x && g && s && r)), "ba_adam_step: null pointer");
     if (n == 0) return BA_OK;
     int grid = cdiv(n, 256);
     if (grid > 8192) grid = 8192;
-    hipLaunchKernelGGL(k_adam, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, x, g, s, r, lr, gscale, bc1, bc2);
+    hipLaunchKernelGGL(k_update, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, x, g, s, r, release,
+                       make_rule(2, lr, gscale, bc1, bc2));
     BA_HIP(hipGetLastError());
     return BA_OK;
 }
 
-int ba_sgd_step(int64_t n, double *x, const double *g, double lr, double gscale, void *stream) {
+int ba_sgd_step(int64_t n, double *x, const double *g, double lr, double gscale, double *release, void *stream) {
     BA_REQUIRE(n >= 0 && (n == 0 || (x && g)), "ba_sgd_step: null pointer");
     if (n == 0) return BA_OK;
     int grid = cdiv(n, 256);
     if (grid > 8192) grid = 8192;
-    hipLaunchKernelGGL(k_sgd, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, x, g, lr, gscale);
+    hipLaunchKernelGGL(k_update, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, x, g, (double *)nullptr,
+                       (double *)nullptr, release, make_rule(1, lr, gscale, 1.0, 1.0));
+    BA_HIP(hipGetLastError());
+    return BA_OK;
+}
+
+int ba_points_step(int64_t N, double *X, const double *gX, double *s, double *r, double *release, int rule, double lr,
+                   double gscale, double bc1, double bc2, const double *gauge, void *stream) {
+    BA_REQUIRE(N >= 0 && rule >= 0 && rule <= 2, "ba_points_step: bad size or rule");
+    if (N == 0) return BA_OK;
+    BA_REQUIRE(X && (rule == 0 || gX) && (rule != 2 || (s && r)), "ba_points_step: null pointer");
+    hipLaunchKernelGGL(k_points_step, dim3(cdiv(N, PS_POINTS)), dim3(PS_POINTS), 0, (hipStream_t)stream, N, X, gX, s, r, release,
+                       make_rule(rule, lr, gscale, bc1, bc2), gauge);
+    BA_HIP(hipGetLastError());
+    return BA_OK;
+}
+
+int ba_camera_step(ba_problem *p, double *cam, const double *g, double *s, double *r, double *release, int64_t lo,
+                   int64_t hi, int rule, double lr, double gscale, double bc1, double bc2, int gauge, double *R_out,
+                   double *gauge_out, void *stream) {
+    BA_REQUIRE(p && cam, "ba_camera_step: null pointer");
+    BA_REQUIRE(rule >= 0 && rule <= 2 && lo >= 0 && hi <= 6 * p->K + 1, "ba_camera_step: bad rule or range");
+    BA_REQUIRE(rule == 0 || lo >= hi || (g && (rule != 2 || (s && r))), "ba_camera_step: null pointer");
+    BA_REQUIRE(!gauge || (p->K >= 2 && gauge_out), "ba_camera_step: the gauge fix needs two cameras and gauge_out");
+    CameraStep a;
+    a.K = p->K;
+    a.cam = cam;
+    a.g = g;
+    a.s = s;
+    a.r = r;
+    a.release = release;
+    a.lo = lo;
+    a.hi = hi;
+    a.rule = make_rule(lo < hi ? rule : 0, lr, gscale, bc1, bc2);
+    a.do_gauge = gauge;
+    a.W = p->W;
+    a.H = p->H;
+    a.T = p->cam_table;
+    a.scalars = p->scalars;
+    a.R_out = R_out;
+    a.gauge = gauge_out;
+    CameraStepShared sh;
+    sh.counter = p->step_counter;
+    sh.block_best = p->step_best;
+    sh.stage = p->step_stage;
+    hipLaunchKernelGGL(k_camera_step_mb, dim3(cdiv(p->K, 256)), dim3(256), 0, (hipStream_t)stream, a, sh);
     BA_HIP(hipGetLastError());
     return BA_OK;
 }
@@ -891,8 +1925,16 @@ int ba_gauge_fix(int64_t N, int64_t K, double *X, double *C, double *Theta, doub
                  void *stream) {
     BA_REQUIRE(K >= 2, "ba_gauge_fix: needs at least two cameras");
     BA_REQUIRE(C && Theta && gauge_out && (N == 0 || X), "ba_gauge_fix: null pointer");
+    BA_REQUIRE(Theta == C + 3 * K, "ba_gauge_fix: Theta must follow C in one buffer ([C | Theta])");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_gauge_cameras, dim3(1), dim3(1024), 0, st, K, C, Theta, R_out, gauge_out);
+    CameraStep a;
+    memset(&a, 0, sizeof(a));
+    a.K = K;
+    a.cam = C;
+    a.do_gauge = 1;
+    a.R_out = R_out;
+    a.gauge = gauge_out;
+    hipLaunchKernelGGL(k_camera_step, dim3(1), dim3(1024), 0, st, a);
     if (N > 0) hipLaunchKernelGGL(k_gauge_points, dim3(cdiv(N, 256)), dim3(256), 0, st, N, X, gauge_out);
     BA_HIP(hipGetLastError());
     return BA_OK;

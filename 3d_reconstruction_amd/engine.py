@@ -49,13 +49,20 @@ class Shard:
     camera-side update is one launch.  Reduction buffer: red = [gC (3K) | gTheta (3K) | gphi (1) |
     sum r^2 (1)], the only thing that crosses GPUs (one all-reduce per evaluation)."""
 
-    def __init__(self, oi, oj, uv, N, K, W, H, device, n_visible_total=None, group=None):
+    def __init__(self, oi, oj, uv, N, K, W, H, device, n_visible_total=None, group=None, reorder=True):
         self.lib = _lib.load()
         self.device = torch.device(device)
         self.N, self.K, self.W, self.H = int(N), int(K), float(W), float(H)
         oi = _dev_tensor(oi, torch.int32, self.device)
         oj = _dev_tensor(oj, torch.int32, self.device)
-        uv = _dev_tensor(uv, F64, self.device)
+        uv = _dev_tensor(uv, F64, self.device).view(-1, 2)
+        self.perm = None        # engine row -> caller's point index (None: same order)
+        if oi.numel() > 0:
+            lo_i, hi_i, lo_j, hi_j = (int(v) for v in (oi.min(), oi.max(), oj.min(), oj.max()))
+            if lo_i < 0 or hi_i >= self.N or lo_j < 0 or hi_j >= self.K:
+                raise _lib.BAError('observation index out of range')
+        if reorder and oi.numel() > 0:
+            oi, oj, uv = self._order_points_by_first_camera(oi, oj, uv)
         self.nV_local = int(oi.numel())
         self.nV = int(n_visible_total) if n_visible_total is not None else self.nV_local
         self.group = group
@@ -79,6 +86,7 @@ class Shard:
         self.E_sum = self.red[2 * K3 + 1:]
         self.gauge = z(16)
         self.R_gauge = z(self.K, 9)
+        self.table_valid = False    # the handle's camera table matches cam (see eval / step_update)
 
     def close(self):
         if getattr(self, 'handle', None):
@@ -91,24 +99,63 @@ class Shard:
         except Exception:
             pass
 
+    def _order_points_by_first_camera(self, oi, oj, uv):
+        """Internal point order: ascending first observing camera, so that consecutive points are
+        seen by the same few cameras and the observation list cuts into tiles with short camera
+        lists (a keypoint track of a video lives in consecutive frames).  The parameters X and
+        everything indexed by point are kept in this order on the device; `points_to_caller`
+        restores the caller's order.  Nothing is permuted when the input already has the property."""
+        i64 = oi.to(torch.int64)
+        first = torch.full((self.N,), self.K, dtype=torch.int64, device=self.device)
+        first.scatter_reduce_(0, i64, oj.to(torch.int64), reduce='amin', include_self=True)
+        if bool((first[1:] >= first[:-1]).all()):
+            return oi, oj, uv
+        perm = torch.argsort(first, stable=True)
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(self.N, device=self.device)
+        new_i = inv[i64]
+        order = torch.argsort(new_i, stable=True)
+        self.perm = perm
+        return new_i[order].to(torch.int32), oj[order].contiguous(), uv[order].contiguous()
+
+    def points_to_engine(self, a):
+        """(N, ...) array in the caller's point order -> device tensor in engine order."""
+        t = _dev_tensor(a, F64, self.device)
+        return t if self.perm is None else t[self.perm]
+
+    def points_to_caller(self, t):
+        """Device tensor indexed by engine point order -> same data in the caller's order."""
+        if self.perm is None:
+            return t
+        out = torch.empty_like(t)
+        out[self.perm] = t
+        return out
+
     # ---- parameters -------------------------------------------------------------------------
     def set_params(self, X, C_, Theta, phi_x):
-        self.X.copy_(_dev_tensor(X, F64, self.device))
+        self.X.copy_(self.points_to_engine(X))
         self.C.copy_(_dev_tensor(C_, F64, self.device))
         self.Theta.copy_(_dev_tensor(Theta, F64, self.device))
         self.phi.fill_(float(phi_x))
+        self.table_valid = False
+
+    def invalidate_table(self):
+        """Call after writing camera parameters behind the library's back (rollback, set_params)."""
+        self.table_valid = False
 
     # ---- kernels ----------------------------------------------------------------------------
-    def eval(self, grad_x=True, grad_cam=True, grad_phi=True, timed=False, cam_atomics=False):
+    def eval(self, grad_x=True, grad_cam=True, grad_phi=True, timed=False, cam_atomics=False, untiled=False):
         """One fused observation pass at the current parameters.  Leaves un-normalised gradients
         in gX / red and returns nothing; `energy()` reads the scalar back."""
         flags = (_lib.EVAL_GRAD_X if grad_x else 0) | (_lib.EVAL_GRAD_CAM if grad_cam else 0) | \
                 (_lib.EVAL_GRAD_PHI if grad_phi else 0) | (_lib.EVAL_TIMED if timed else 0) | \
-                (_lib.EVAL_CAM_ATOMICS if cam_atomics else 0)
+                (_lib.EVAL_CAM_ATOMICS if cam_atomics else 0) | (_lib.EVAL_UNTILED if untiled else 0) | \
+                (_lib.EVAL_REUSE_TABLE if self.table_valid else 0)
         with torch.cuda.device(self.device):
             check(self.lib.ba_eval(self.handle, ptr(self.X), ptr(self.C), ptr(self.Theta), ptr(self.phi), flags,
                                    ptr(self.E_sum), ptr(self.gX), ptr(self.gC), ptr(self.gTheta), ptr(self.gphi),
                                    None, None, None, None, stream_ptr()))
+        self.table_valid = True
         allreduce_sum_(self.red, self.group)
 
     def energy(self):
@@ -121,20 +168,47 @@ class Shard:
         check(self.lib.ba_eval_timing(self.handle, buf, 256, C.byref(n)))
         return [buf[k] for k in range(n.value)]
 
-    def adam(self, x, g, s, r, lr, bc1, bc2):
+    def adam(self, x, g, s, r, lr, bc1, bc2, release=None):
         with torch.cuda.device(self.device):
             check(self.lib.ba_adam_step(x.numel(), ptr(x), ptr(g), ptr(s), ptr(r), float(lr), 1.0 / self.nV,
-                                        float(bc1), float(bc2), stream_ptr()))
+                                        float(bc1), float(bc2), ptr(release), stream_ptr()))
+        self.table_valid = False
 
-    def sgd(self, x, g, lr):
+    def sgd(self, x, g, lr, release=None):
         with torch.cuda.device(self.device):
-            check(self.lib.ba_sgd_step(x.numel(), ptr(x), ptr(g), float(lr), 1.0 / self.nV, stream_ptr()))
+            check(self.lib.ba_sgd_step(x.numel(), ptr(x), ptr(g), float(lr), 1.0 / self.nV, ptr(release),
+                                       stream_ptr()))
+        self.table_valid = False
 
     def gauge_fix(self):
         """align_scene + normalize_scene in place (p2w:710-712)."""
         with torch.cuda.device(self.device):
             check(self.lib.ba_gauge_fix(self.N, self.K, ptr(self.X), ptr(self.C), ptr(self.Theta),
                                         ptr(self.R_gauge), ptr(self.gauge), stream_ptr()))
+        self.table_valid = False
+
+    def step_update(self, rule, lr, bc1, bc2, x_free, cam_range, mom_x, mom_cam, rel_x, rel_cam, gauge):
+        """One optimiser step for every free group plus the gauge fix, in two launches
+        (p2w:704-712).  rule: 1 SGD, 2 Adam.  mom_* = (s, r) moment tensors or None; rel_* = snapshot
+        destinations or None (the old values are written there in the same pass).  cam_range =
+        (lo, hi) slice of [C | Theta | phi_x] that is free, or None."""
+        gs = 1.0 / self.nV
+        with torch.cuda.device(self.device):
+            if cam_range is not None or gauge:
+                lo, hi = cam_range if cam_range is not None else (0, 0)
+                s_c, r_c = mom_cam if mom_cam is not None else (None, None)
+                # moment / snapshot tensors of the camera group cover the free slice only
+                off = lambda t: None if t is None else C.c_void_p(t.data_ptr() - 8 * lo)
+                check(self.lib.ba_camera_step(self.handle, ptr(self.cam), ptr(self.red), off(s_c), off(r_c),
+                                              off(rel_cam), lo, hi, rule, float(lr), gs, float(bc1), float(bc2),
+                                              int(bool(gauge)), ptr(self.R_gauge), ptr(self.gauge), stream_ptr()))
+                self.table_valid = True
+            if x_free or gauge:
+                s_x, r_x = mom_x if mom_x is not None else (None, None)
+                check(self.lib.ba_points_step(self.N, ptr(self.X), ptr(self.gX), ptr(s_x), ptr(r_x),
+                                              ptr(rel_x) if x_free else None, rule if x_free else 0, float(lr), gs,
+                                              float(bc1), float(bc2), ptr(self.gauge) if gauge else None,
+                                              stream_ptr()))
 
 
 def project(X, C_, Theta, phi_x, W, H, i=None, j=None, delete_back_points=True, delete_boundary_points=False,

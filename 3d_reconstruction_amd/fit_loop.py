@@ -33,12 +33,16 @@ class SceneFit:
         self.stop_value, self.stop_diff, self.print_step = stop_value, stop_diff, print_step
         self.ret_all_iters = ret_all_iters
         self.print = printer
+        self.timed = False          # record HIP events around the observation-pass kernel
         self.gauge = self.masks[0] and self.masks[1]      # p2w:533, 710
 
         K6 = 6 * shard.K
         lo = 0 if self.masks[1] else K6
         hi = (K6 + 1) if self.masks[2] else K6
         self.cam_range = (lo, hi) if hi > lo else None     # free slice of [C | Theta | phi_x]
+
+        if self.gauge:
+            shard.gauge_fix()                                            # p2w:533-536
 
         # free parameter groups as (parameters, gradient) tensor pairs
         self.groups = []
@@ -63,8 +67,7 @@ class SceneFit:
         self.began_decreasing = self.increased = False
         self.iters = 0
         self.finished = False
-        if self.gauge:
-            shard.gauge_fix()                                            # p2w:533-536
+        self._snapshot = False      # a snapshot of the current parameters is due with the next update
 
     # ---- optimiser state moves (p2w:411-414, 439-446) -----------------------------------------
     def _adam_reset(self):
@@ -90,7 +93,7 @@ class SceneFit:
             self.t = self.t_tmp
 
     def _evaluate(self):
-        self.sh.eval(grad_x=self.masks[0], grad_cam=self.masks[1], grad_phi=self.masks[2])
+        self.sh.eval(grad_x=self.masks[0], grad_cam=self.masks[1], grad_phi=self.masks[2], timed=self.timed)
 
     # ---- learning-rate schedule ---------------------------------------------------------------
     def _manage(self):
@@ -102,8 +105,9 @@ class SceneFit:
         elif e < self.E_min:
             self.E_min = e
             self.began_decreasing = True
-            for rel, (p, _) in zip(self.release, self.groups):
-                rel.copy_(p)
+            # release <- main (p2w:397-398); the copy is written by the update kernels, which read
+            # the old parameters anyway.  Nothing reads `release` before the next call of _manage.
+            self._snapshot = True
             self.patience_timer = self.patience
             if self.success_timer > 0:
                 self.success_timer -= 1
@@ -130,6 +134,7 @@ class SceneFit:
                 self.lr /= self.factor
                 for rel, (p, _) in zip(self.release, self.groups):
                     p.copy_(rel)
+                self.sh.invalidate_table()
                 self._evaluate()          # gradients at the rolled-back parameters
                 if (not self.increased) or (self.E_min_temp > self.E_min):
                     self._adam_reset()
@@ -167,21 +172,23 @@ class SceneFit:
             self.print(f'{it} : {self.E_min}')
 
         self.update()
-        if self.gauge:
-            self.sh.gauge_fix()
         self.iters += 1
         return True
 
     def update(self):
-        """Apply the update rule to every free group (p2w:704-708)."""
+        """Update rule on every free group, pending snapshot, gauge fix (p2w:704-712)."""
+        bc1 = bc2 = 1.0
         if self.adam:
             bc1, bc2 = 1.0 - RHO_1 ** self.t, 1.0 - RHO_2 ** self.t
-            for k, (p, g) in enumerate(self.groups):
-                self.sh.adam(p, g, self.s[k], self.r[k], self.lr, bc1, bc2)
+        gx = 0 if self.masks[0] else None                 # index of the X group
+        gc = (1 if self.masks[0] else 0) if self.cam_range else None
+        mom = lambda k: (self.s[k], self.r[k]) if (self.adam and k is not None) else None
+        rel = lambda k: self.release[k] if (self._snapshot and k is not None) else None
+        self.sh.step_update(2 if self.adam else 1, self.lr, bc1, bc2, self.masks[0], self.cam_range,
+                            mom(gx), mom(gc), rel(gx), rel(gc), self.gauge)
+        self._snapshot = False
+        if self.adam:
             self.t += 1
-        else:
-            for p, g in self.groups:
-                self.sh.sgd(p, g, self.lr)
 
     def _finish(self):
         self.finished = True

@@ -125,7 +125,8 @@ def _pack_results(fit, shard, masks, gather_X=None):
     X_mask, C_Theta_mask, phi_x_mask = masks
     out = []
     if X_mask:
-        X = shard.X if gather_X is None else gather_X(shard.X)
+        X = shard.points_to_caller(shard.X)
+        X = X if gather_X is None else gather_X(X)
         out.append(X.cpu().numpy().copy())
     if C_Theta_mask:
         out.append(shard.C.cpu().numpy().copy())
@@ -138,7 +139,9 @@ def _pack_results(fit, shard, masks, gather_X=None):
         K3 = 3 * shard.K
         g = 0
         if X_mask:
-            out.append(np.array([h.reshape(-1, 3) for h in hist[g]]))
+            back = (lambda h: h) if shard.perm is None else \
+                (lambda h, inv=torch.argsort(shard.perm).cpu().numpy(): h[inv])
+            out.append(np.array([back(h.reshape(-1, 3)) for h in hist[g]]))
             g += 1
         if C_Theta_mask:
             out.append(np.array([h[:K3].reshape(-1, 3) for h in hist[g]]))

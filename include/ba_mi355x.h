@@ -42,7 +42,11 @@ enum ba_eval_flags {
     BA_EVAL_GRAD_PHI = 4,   /* write gphi                   (p2w:700-702) */
     BA_EVAL_JTJ = 8,        /* also write V, B, bphi, hphi (Gauss-Newton blocks; no reference counterpart) */
     BA_EVAL_CAM_ATOMICS = 16, /* force the global-atomic camera reduction (default: LDS-private when it fits) */
-    BA_EVAL_TIMED = 32      /* record HIP events around the observation-pass kernel (see ba_eval_timing) */
+    BA_EVAL_TIMED = 32,     /* record HIP events around the observation-pass kernel (see ba_eval_timing) */
+    BA_EVAL_DEBUG_MASK = 64 | 128 | 256, /* diagnostics only: skip parts of the pass (results are wrong) */
+    BA_EVAL_UNTILED = 512,  /* use the wave-chunk kernel even when the scene has LDS tiles */
+    BA_EVAL_REUSE_TABLE = 1024 /* the handle's camera table already describes C, Theta, phi (left there by
+                                  ba_camera_step); skip rebuilding it */
 };
 
 const char *ba_last_error(void);
@@ -88,17 +92,36 @@ int ba_eval_timing(ba_problem *p, float *h_ms, int capacity, int *h_count);
 
 /* ---- update rules (p2w:336-360), in place, n doubles; g is multiplied by gscale (= 1/|V|) first.
  * Adam: s = rho1 s + (1-rho1) g; r = rho2 r + (1-rho2) g^2;
- *       x -= lr (s/bc1) / (1e-12 + sqrt(r/bc2)),  bc1 = 1-rho1^t, bc2 = 1-rho2^t (host supplies). */
+ *       x -= lr (s/bc1) / (1e-12 + sqrt(r/bc2)),  bc1 = 1-rho1^t, bc2 = 1-rho2^t (host supplies).
+ * `release` (optional, n doubles) receives x before the update: the snapshot lr_manager takes at
+ * p2w:397-398, written in the same pass. */
 int ba_adam_step(int64_t n, double *x, const double *g, double *s, double *r, double lr,
-                 double gscale, double bc1, double bc2, void *stream);
-int ba_sgd_step(int64_t n, double *x, const double *g, double lr, double gscale, void *stream);
+                 double gscale, double bc1, double bc2, double *release, void *stream);
+int ba_sgd_step(int64_t n, double *x, const double *g, double lr, double gscale, double *release,
+                void *stream);
 
 /* ---- gauge fix: align_scene + normalize_scene (p2w:270-333) in place.
  * Camera 0 goes to the origin with identity rotation; the longest baseline from camera 0
- * gets length 1.  R_out[K][9] (optional) receives R0^T R_j as align_scene(ret_R=True) does.
- * gauge_out[16] (optional): R0 (9, row-major), C0 (3), scale factor, j1, 2 spare. */
+ * gets length 1.  C and Theta must be one buffer [C (3K) | Theta (3K)].  R_out[K][9] (optional)
+ * receives R0^T R_j as align_scene(ret_R=True) does.
+ * gauge_out[16]: R0 (9, row-major), C0 (3), scale factor, j1, 2 spare. */
 int ba_gauge_fix(int64_t N, int64_t K, double *X, double *C, double *Theta, double *R_out,
                  double *gauge_out, void *stream);
+
+/* ---- one optimiser step, fused (p2w:704-712): the same arithmetic as ba_adam_step / ba_sgd_step
+ * followed by ba_gauge_fix, in two launches and one pass over each array.
+ * ba_camera_step: update rule (0 none, 1 SGD, 2 Adam) on the slice [lo, hi) of
+ *   cam = [C (3K) | Theta (3K) | phi_x (1)] (g, s, r, release in the same packing), then, if
+ *   `gauge`, the camera half of the gauge fix; it also leaves the handle's camera table and
+ *   scalars valid for the new parameters (see BA_EVAL_REUSE_TABLE).
+ * ba_points_step: update rule on X with optional snapshot, then, if `gauge` (the record written by
+ *   ba_camera_step) is given, X <- ((X - C0) @ R0) * factor. */
+int ba_camera_step(ba_problem *p, double *cam, const double *g, double *s, double *r, double *release,
+                   int64_t lo, int64_t hi, int rule, double lr, double gscale, double bc1, double bc2,
+                   int gauge, double *R_out, double *gauge_out, void *stream);
+int ba_points_step(int64_t N, double *X, const double *gX, double *s, double *r, double *release,
+                   int rule, double lr, double gscale, double bc1, double bc2, const double *gauge,
+                   void *stream);
 
 /* ---- transform (p2w:192-216) on a list of pairs: model pixels out[n][2], NaN behind the camera
  * (delete_back_points) and optionally outside [0,W)x[0,H) (delete_boundary_points).

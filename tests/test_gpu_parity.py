@@ -59,12 +59,14 @@ def test_visibility_only_x_decides(ba):
 # ---- H3/H4/H7/H8/H9: fused observation pass --------------------------------------------------
 def _eval_all(ba, sh, nv, **kw):
     sh.eval(**kw)
-    return (sh.energy(), sh.gX.cpu().numpy() / nv, sh.gC.cpu().numpy() / nv, sh.gTheta.cpu().numpy() / nv,
+    return (sh.energy(), sh.points_to_caller(sh.gX).cpu().numpy() / nv, sh.gC.cpu().numpy() / nv,
+            sh.gTheta.cpu().numpy() / nv,
             sh.gphi.cpu().numpy() / nv)
 
 
-@pytest.mark.parametrize('cam_atomics', [False, True])
-def test_eval_teacher_forced_moscow(ba, golden, cam_atomics):
+@pytest.mark.parametrize('variant', [dict(), dict(untiled=True), dict(cam_atomics=True)],
+                         ids=['lds-tiles', 'wave-chunks', 'global-atomics'])
+def test_eval_teacher_forced_moscow(ba, golden, variant):
     g = golden('f2_moscow_ride.npz')
     W, H = int(g['W']), int(g['H'])
     nv = g['obs_i'].size
@@ -72,7 +74,7 @@ def test_eval_teacher_forced_moscow(ba, golden, cam_atomics):
     worst = 0.0
     for s in range(g['tf__step_X'].shape[0]):
         sh.set_params(g['tf__step_X'][s], g['tf__step_C'][s], g['tf__step_Theta'][s], g['tf__step_phi_x'][s][0])
-        E, gX, gC, gT, gp = _eval_all(ba, sh, nv, cam_atomics=cam_atomics)
+        E, gX, gC, gT, gp = _eval_all(ba, sh, nv, **variant)
         worst = max(worst, abs(E - g['tf__E'][s]) / g['tf__E'][s], rel_err(gX, g['tf__grad_X'][s]),
                     rel_err(gC, g['tf__grad_C'][s]), rel_err(gT, g['tf__grad_Theta'][s]),
                     rel_err(gp, g['tf__grad_phi_x'][s]))
@@ -111,15 +113,18 @@ def test_eval_ragged_and_empty_points(ba):
     j = np.concatenate([np.sort(rng.choice(K, c, replace=False)) for c in counts]).astype(np.int32)
     X = rng.normal(0, 1, (N, 3)) + np.array([0, 0, 30.0])
     uv = rng.uniform(0, 1000, (i.size, 2))
-    sh = ba.engine.Shard(i, j, uv, N, K, 1920, 1080, DEV)
-    sh.gX.fill_(123.0)       # stale content must not survive
-    sh.set_params(X, C, Th, 1.1)
-    E, gX, gC, gT, gp = _eval_all(ba, sh, i.size)
     E_ref, gX_r, gC_r, gT_r, gp_r = orc.energy_and_gradients(X, C, Th, np.array([1.1]), 1920, 1080, i, j, uv)
-    assert abs(E - E_ref) / E_ref < TOL
-    assert rel_err(gX, gX_r) < TOL and rel_err(gC, gC_r) < TOL and rel_err(gT, gT_r) < TOL and rel_err(gp, gp_r) < TOL
-    assert np.all(gX[counts == 0] == 0.0)
-    sh.close()
+    for reorder in (True, False):
+        sh = ba.engine.Shard(i, j, uv, N, K, 1920, 1080, DEV, reorder=reorder)
+        sh.set_params(X, C, Th, 1.1)
+        for kw in (dict(), dict(untiled=True), dict(cam_atomics=True)):
+            sh.gX.fill_(123.0)       # stale content must not survive
+            E, gX, gC, gT, gp = _eval_all(ba, sh, i.size, **kw)
+            assert abs(E - E_ref) / E_ref < TOL, (reorder, kw)
+            assert rel_err(gX, gX_r) < TOL and rel_err(gC, gC_r) < TOL, (reorder, kw)
+            assert rel_err(gT, gT_r) < TOL and rel_err(gp, gp_r) < TOL, (reorder, kw)
+            assert np.all(gX[counts == 0] == 0.0), (reorder, kw)
+        sh.close()
 
 
 def test_problem_create_rejects_bad_input(ba):
@@ -127,7 +132,7 @@ def test_problem_create_rejects_bad_input(ba):
     j = np.array([0, 1, 2], dtype=np.int32)
     uv = np.zeros((3, 2))
     with pytest.raises(ba.engine._lib.BAError, match='sorted'):
-        ba.engine.Shard(i, j, uv, 3, 3, 10, 10, DEV)
+        ba.engine.Shard(i, j, uv, 3, 3, 10, 10, DEV, reorder=False)
     with pytest.raises(ba.engine._lib.BAError, match='out of range'):
         ba.engine.Shard(np.array([0, 1, 5], dtype=np.int32), j, uv, 3, 3, 10, 10, DEV)
 
@@ -277,18 +282,19 @@ def test_full_size_invariants(ba):
     # translation invariance of the energy: sum_i dE/dX_i + sum_j dE/dC_j = 0
     tot = gX.sum(0) + sh.gC.sum(0)
     assert float(tot.abs().max()) < 1e-7 * float(gX.abs().sum())
-    # LDS-private and global-atomic camera reductions agree (different summation orders)
-    sh.eval(cam_atomics=True)
-    assert abs(sh.energy() - E1) / E1 < 1e-12
-    assert float((sh.red - red).abs().max()) <= 1e-10 * float(red.abs().max())
-    assert torch.equal(sh.gX, gX)
+    # the three forms of the pass agree (different summation orders only)
+    for kw in (dict(untiled=True), dict(cam_atomics=True)):
+        sh.eval(**kw)
+        assert abs(sh.energy() - E1) / E1 < 1e-12
+        assert float((sh.red - red).abs().max()) <= 1e-10 * float(red.abs().max())
+        assert float((sh.gX - gX).abs().max()) <= 1e-12 * float(gX.abs().max())
     # a sample of points and cameras against the oracle restricted to their observations
     pts = np.array([0, 1, 77777, 500000, 999999])
     sel = np.isin(sc['i'], pts)
     _, gX_r, _, _, _ = orc.energy_and_gradients(sc['X_0'], sc['C_0'], sc['Theta_0'], np.array([sc['phi_x_0']]),
                                                 sc['W'], sc['H'], sc['i'][sel], sc['j'][sel], sc['uv'][sel],
                                                 n_visible=nv)
-    assert rel_err(gX.cpu().numpy()[pts] / nv, gX_r[pts]) < TOL
+    assert rel_err(sh.points_to_caller(gX).cpu().numpy()[pts] / nv, gX_r[pts]) < TOL
     cams = np.array([0, 1, 999, 1999])
     selc = np.isin(sc['j'], cams)
     _, _, gC_r, gT_r, _ = orc.energy_and_gradients(sc['X_0'], sc['C_0'], sc['Theta_0'], np.array([sc['phi_x_0']]),

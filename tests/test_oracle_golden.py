@@ -207,3 +207,21 @@ def test_f6_medium_scene(golden):
     assert log == want
     assert rel_err(out[-1][:100], g['E'][:100]) < 1e-8
     assert np.abs(out[0] - g['final_X']).max() < 1e-3      # 500 free iterations with 8 LR events
+
+
+def test_c_oracle_matches_golden_and_numpy_oracle(golden):
+    """The C restatement (CPU baseline of bench.py) against the reference's vectors."""
+    from oracle import c_oracle
+    g = golden('f2_moscow_ride.npz')
+    W, H = int(g['W']), int(g['H'])
+    i, j, uv = g['obs_i'], g['obs_j'], g['obs_xy'] + 0.5
+    for s in (0, 7, 49):
+        E, gX, gC, gT, gp = c_oracle.energy_and_gradients(g['tf__step_X'][s], g['tf__step_C'][s],
+                                                          g['tf__step_Theta'][s], g['tf__step_phi_x'][s][0], W, H, i, j, uv)
+        assert abs(E - g['tf__E'][s]) / g['tf__E'][s] < TOL
+        assert rel_err(gX, g['tf__grad_X'][s]) < TOL and rel_err(gC, g['tf__grad_C'][s]) < TOL
+        assert rel_err(gT, g['tf__grad_Theta'][s]) < TOL and rel_err(gp, g['tf__grad_phi_x'][s]) < TOL
+    # full iterations: same trajectory as the reference while no LR event fires
+    it = c_oracle.Iterator(i, j, uv, g['free__X_0'], g['C_0'], g['Theta_0'], float(g['phi_x_0']), W, H, 1e-3)
+    E = np.array([it.step() for _ in range(60)])
+    assert rel_err(E, g['free__E'][:60]) < 1e-9
