@@ -1,0 +1,193 @@
+"""CPU tests of everything that is not a kernel: the C ABI surface, the host-side loop control,
+input validation, partitioning and the synthetic scene generator.  No GPU needed."""
+import ctypes
+import importlib
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, logs_match, rel_err
+from mock_shard import MockShard
+from oracle import ba_oracle as orc
+
+ba_lib = importlib.import_module('3d_reconstruction_amd._lib')
+fit_loop = importlib.import_module('3d_reconstruction_amd.fit_loop')
+sharding = importlib.import_module('3d_reconstruction_amd.sharding')
+scenes = importlib.import_module('3d_reconstruction_amd.scenes')
+p2w = importlib.import_module('3d_reconstruction_amd.pix2world')
+
+
+# ---- C ABI -------------------------------------------------------------------------------------
+def _declared_functions():
+    text = open(os.path.join(ROOT, 'include', 'ba_mi355x.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(ba_[a-z_0-9]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = _declared_functions()
+    assert len(names) >= 14
+    assert os.path.exists(ba_lib.LIB_PATH), 'build libba_mi355x.so first (__graft_entry__.build())'
+    lib = ba_lib.load()
+    for n in names:
+        assert hasattr(lib, n), f'{n} is declared in the header but not exported'
+        assert n in ba_lib.SIGNATURES, f'{n} has no ctypes signature'
+    assert sorted(ba_lib.SIGNATURES) == names
+    assert lib.ba_version() >= 100
+    assert isinstance(lib.ba_last_error(), bytes)
+
+
+def test_argument_errors_need_no_gpu():
+    lib = ba_lib.load()
+    out = ctypes.c_void_p()
+    assert lib.ba_problem_create(0, 5, 10, None, None, None, 10.0, 10.0, 0, ctypes.byref(out)) == -1
+    assert b'positive' in lib.ba_last_error()
+    assert lib.ba_adam_step(5, None, None, None, None, 1e-3, 1.0, 0.1, 0.001, None, None) == -1
+    with pytest.raises(ba_lib.BAError, match='null pointer'):
+        ba_lib.check(lib.ba_sgd_step(5, None, None, 1e-3, 1.0, None, None))
+
+
+def test_no_cpu_fallback_in_product_package():
+    """The product package never touches the oracle."""
+    pkg = os.path.join(ROOT, '3d_reconstruction_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                src = open(os.path.join(dirpath, f)).read()
+                assert 'oracle' not in src.replace('orthogonolize', ''), f
+
+
+# ---- validation (p2w:21-95, 503-528) --------------------------------------------------------------
+def test_validation_messages():
+    v = p2w.validate_scene_parameters
+    X, C, Th = np.zeros((4, 3)), np.zeros((2, 3)), np.zeros((2, 3))
+    assert v(X=X, C=C, Theta=Th, phi_x=1.0, ret_shapes=True) == (4, 2)
+    cases = [
+        (dict(X=np.zeros(3)), 'Expected X to have ndim = 2, got 1'),
+        (dict(X=np.zeros((3, 2))), 'Expected X to have shape[1] = 3, got 2'),
+        (dict(C=np.full((2, 3), np.nan)), 'Expected C not to have nan or inf values'),
+        (dict(C=C, Theta=np.zeros((3, 3))), 'Expected Theta to have shape[0] = 2, got 3'),
+        (dict(X=X, X_pix=np.zeros((5, 2, 2), dtype=int)), 'Expected X_pix to have shape[0] = 4, got 5'),
+        (dict(C=C, X_pix=np.zeros((4, 3, 2), dtype=int)), 'Expected X_pix to have shape[1] = 2, got 3'),
+        (dict(X_pix=np.zeros((4, 3), dtype=int)), 'Expected X_pix to have ndim = 3, got 2'),
+        (dict(phi_x=0.0), 'Expected phi_x to have a value within (0.0, pi), got 0.0'),
+        (dict(R=np.zeros((2, 3, 3))), 'Expected R[i] @ R[i].T must be approximately equal to eye(3)'),
+    ]
+    for kw, msg in cases:
+        with pytest.raises(ValueError) as ei:
+            v(**kw)
+        assert msg in str(ei.value)
+    with pytest.raises(ValueError, match='At least one of'):
+        p2w.check_solvable(100, 4, 2, False, False, False)
+    p2w.check_solvable(9, 4, 2, True, True, True)          # 18 equations, 3*4 + 6*2 - 7 + 1 = 18 unknowns
+    with pytest.raises(ValueError, match='number of equations is smaller'):
+        p2w.check_solvable(8, 4, 2, True, True, True)
+
+
+def test_connected_components_match_union_find():
+    rng = np.random.default_rng(0)
+    for N, K, n in ((30, 8, 40), (50, 20, 45), (10, 3, 30)):
+        i = np.sort(rng.integers(0, N, n))
+        j = rng.integers(0, K, n)
+        assert sharding.connected_components_count(i, j, N, K) == orc.count_components(i, j, N, K)
+
+
+# ---- host loop control against the reference's own traces ------------------------------------------
+def _run_mock(g, i, j, uv, N, K, lr, max_iters, **kw):
+    sh = MockShard(i, j, uv, N, K, int(g['W']), int(g['H']))
+    sh.set_params(g['X_0'], g['C_0'], g['Theta_0'], float(g['phi_x_0']))
+    lines = []
+    fit = fit_loop.SceneFit(sh, lr, max_iters, printer=lines.append, **kw)
+    fit.run()
+    return sh, fit, lines
+
+
+def test_loop_control_reproduces_lr_events(golden):
+    g = golden('f3_lr_events.npz')
+    i, j, uv = orc.visibility_coo(g['X_pix'])
+    N, K = g['X_pix'].shape[:2]
+    sh, fit, lines = _run_mock(g, i, j, uv, N, K, 1e-3, 200, patience=20)
+    assert logs_match([ln for ln in lines if 'LR' in ln or 'Reached' in ln],
+                      [ln for ln in g['log'].tolist() if 'LR' in ln or 'Reached' in ln])
+    assert fit.energies().shape == g['E'].shape
+    assert rel_err(fit.energies()[:100], g['E'][:100]) < 1e-8
+    # one evaluation per loop pass plus one per rollback
+    rollbacks = sum('Decrease' in ln for ln in lines)
+    assert sh.evals == g['manager_calls'].shape[0] + rollbacks
+
+
+@pytest.mark.parametrize('opt', ['Adam', 'SGD'])
+def test_loop_control_all_masks(golden, opt):
+    g = golden('f1_tiny_masks.npz')
+    i, j, uv = orc.visibility_coo(g['X_pix'])
+    N, K = g['X_pix'].shape[:2]
+    lr = 1e-3 if opt == 'Adam' else 1e-7
+    for m in g['combos']:
+        m = tuple(bool(t) for t in m)
+        tag = f"{opt}_{''.join('1' if t else '0' for t in m)}"
+        sh, fit, lines = _run_mock(g, i, j, uv, N, K, lr, 5, X_mask=m[0], C_Theta_mask=m[1], phi_x_mask=m[2],
+                                   optimizer=opt)
+        assert rel_err(fit.energies(), g[f'{tag}__E']) < 1e-9, tag
+        if m[0]:
+            assert np.abs(sh.X.numpy() - g[f'{tag}__final_X']).max() < 1e-9
+        if m[1]:
+            assert np.abs(sh.C.numpy() - g[f'{tag}__final_C']).max() < 1e-9
+            assert np.abs(sh.Theta.numpy() - g[f'{tag}__final_Theta']).max() < 1e-9
+        if m[2]:
+            assert abs(float(sh.phi[0]) - float(g[f'{tag}__final_phi_x'])) < 1e-9
+        assert logs_match(lines, g[f'{tag}__log'].tolist()), tag
+
+
+def test_unknown_optimizer_message():
+    sh = MockShard(np.zeros(1, int), np.zeros(1, int), np.zeros((1, 2)), 1, 2, 10, 10)
+    with pytest.raises(ValueError, match='Unkown name of the optmizer'):
+        fit_loop.SceneFit(sh, 1e-3, 5, optimizer='LBFGS')
+    assert set(p2w.gd_func_dict) == {'SGD', 'Adam'}
+
+
+# ---- partitioning ----------------------------------------------------------------------------------
+def test_partition_points_properties():
+    rng = np.random.default_rng(1)
+    for trial in range(30):
+        N = int(rng.integers(1, 60))
+        counts = rng.integers(0, 9, N)
+        if counts.sum() == 0:
+            counts[0] = 1
+        obs_i = np.repeat(np.arange(N), counts)
+        for world in (1, 2, 3, 8):
+            pb, ob = sharding.partition_points(obs_i, N, world)
+            assert len(pb) == len(ob) == world + 1
+            assert pb[0] == 0 and pb[-1] == N and ob[0] == 0 and ob[-1] == obs_i.size
+            assert all(a <= b for a, b in zip(pb, pb[1:])) and all(a <= b for a, b in zip(ob, ob[1:]))
+            for r in range(world):
+                seg = obs_i[ob[r]:ob[r + 1]]
+                if seg.size:
+                    assert pb[r] <= seg.min() and seg.max() < pb[r + 1]      # a point never straddles ranks
+    obs_i = np.repeat(np.arange(1000), 10)
+    pb, ob = sharding.partition_points(obs_i, 1000, 8)
+    assert max(b - a for a, b in zip(ob, ob[1:])) <= 1260               # balanced within a point's run
+
+
+# ---- synthetic scenes --------------------------------------------------------------------------------
+def test_orbit_scene_is_well_formed():
+    sc = scenes.orbit_scene(N=3000, K=120, track_len=10, seed=3)
+    i, j, xy = sc['i'], sc['j'], sc['xy']
+    assert i.dtype == np.int32 and j.dtype == np.int32 and xy.dtype == np.int32
+    key = i.astype(np.int64) * sc['K'] + j
+    assert np.all(np.diff(key) > 0)                                       # i-major, j ascending, no duplicates
+    assert xy[:, 0].min() >= 0 and xy[:, 0].max() < sc['W'] and xy[:, 1].min() >= 0 and xy[:, 1].max() < sc['H']
+    assert np.array_equal(sc['uv'], xy + 0.5)
+    assert i.size > 0.6 * 3000 * 10
+    # pixels are floor(projection) of the true scene: the energy at the truth is the quantisation floor
+    E, *_ = orc.energy_and_gradients(sc['X'], sc['C'], sc['Theta'], np.array([sc['phi_x']]), sc['W'], sc['H'],
+                                     i, j, sc['uv'])
+    assert 0.05 < E < 0.12
+    assert orc.count_components(i, j, sc['N_local'], sc['K']) == 1
+    # shards of one scene share the cameras and cover the points
+    a = scenes.orbit_scene(N=3000, K=120, seed=3, part=0, parts=2)
+    b = scenes.orbit_scene(N=3000, K=120, seed=3, part=1, parts=2)
+    assert np.array_equal(a['C'], b['C']) and np.array_equal(a['Theta_0'], b['Theta_0'])
+    assert a['N_local'] + b['N_local'] == 3000 and b['point_offset'] == a['N_local']
