@@ -27,6 +27,17 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak
 
 
+def measured_traffic(points_per_gpu, cameras, track_len):
+    """HBM bytes per launch of the observation-pass kernel from the committed rocprofv3 PMC passes
+    (FETCH_SIZE / WRITE_SIZE, corrected as profiles/summarize_pmc.py documents); only for the
+    workload those passes were taken on, else None."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic_cfg3.json')
+    if (points_per_gpu, cameras, track_len) != (1_000_000, 2000, 10) or not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        return json.load(fh).get('ba::k_eval_tiled', {}).get('hbm_bytes_per_launch')
+
+
 def cpu_baseline(sc, budget_s=15.0):
     """Full iterations of the C restatement (oracle/ba_oracle.c) on one host core, on a bounded
     prefix of this rank's shard."""
@@ -129,9 +140,10 @@ def main():
                        'points': N_total, 'cameras': K, 'observations': nv_total,
                        'parallelism': f'point-sharded x{world}, cameras replicated',
                        'energy_first_timed': E_first, 'energy_last_timed': E_last},
-            'roofline': {'bound': 'hbm', 'kernel': 'ba::k_eval (fused observation pass, gradient)',
+            'roofline': {'bound': 'hbm', 'kernel': 'ba::k_eval_tiled (fused observation pass, gradient)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'frac': achieved / HBM_PEAK_GBS,
+                         'traffic': measured_traffic(args.points_per_gpu, args.cameras, args.track_len),
                          'algorithmic_bytes_per_launch': algo_bytes, 'avg_kernel_ms': avg_ms,
                          'launches_timed': len(kern_ms)},
         }
