@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libba_mi355x.so')
 
 # enum ba_eval_flags
-EVAL_GRAD_X, EVAL_GRAD_CAM, EVAL_GRAD_PHI, EVAL_JTJ, EVAL_CAM_ATOMICS, EVAL_TIMED = 1, 2, 4, 8, 16, 32
+EVAL_GRAD_X, EVAL_GRAD_CAM, EVAL_GRAD_PHI, EVAL_CAM_ATOMICS, EVAL_TIMED = 1, 2, 4, 16, 32
 EVAL_UNTILED = 512
 EVAL_REUSE_TABLE = 1024
 
@@ -32,7 +32,12 @@ SIGNATURES = {
     'ba_visibility_fill': (_int, [_p, _i64, _i64, _p, _p, _p, _p, _p]),
     'ba_problem_create': (_int, [_i64, _i64, _i64, _p, _p, _p, _dbl, _dbl, _int, C.POINTER(_p)]),
     'ba_problem_destroy': (_int, [_p]),
-    'ba_eval': (_int, [_p, _p, _p, _p, _p, _int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    'ba_eval': (_int, [_p, _p, _p, _p, _p, _int, _p, _p, _p, _p, _p, _p]),
+    'ba_eval_jtj': (_int, [_p, _p, _p, _p, _p, _int] + [_p] * 11),
+    'ba_schur_dim': (_int, [_i64, C.POINTER(_i64), C.POINTER(_i64)]),
+    'ba_schur_build': (_int, [_p, _p, _dbl] + [_p] * 12),
+    'ba_cholesky_solve': (_int, [_i64, _i64, _p, _p, C.POINTER(_int), _p]),
+    'ba_backsubstitute': (_int, [_p, _p, _dbl, _p, _p, _p, _p, _p, _p, _p]),
     'ba_eval_timing': (_int, [_p, C.POINTER(C.c_float), _int, C.POINTER(_int)]),
     'ba_adam_step': (_int, [_i64, _p, _p, _p, _p, _dbl, _dbl, _dbl, _dbl, _p, _p]),
     'ba_sgd_step': (_int, [_i64, _p, _p, _dbl, _dbl, _p, _p]),

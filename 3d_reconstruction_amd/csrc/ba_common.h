@@ -60,7 +60,8 @@ struct ba_problem {
     int grid = 0;                 // workgroups of the observation pass
     int64_t n_points_seen = 0;    // points with at least one observation
     // tiled form of the observation pass (null / 0 when the scene does not tile)
-    int tiled = 0;
+    int tiled = 0;                // tiles exist
+    int tiles_worth = 0;          // ... and the gradient pass is faster on them
     int n_tiles = 0, tile_obs_target = 0;
     int cam_cap = 0, pt_cap = 0;  // largest camera list / point span of a tile
     int cam_rep = 1;              // copies of the camera accumulators in LDS
@@ -68,7 +69,7 @@ struct ba_problem {
     int32_t *tile_obs = nullptr;      // n_tiles + 1
     int64_t *tile_cam_ptr = nullptr;  // n_tiles + 1
     int32_t *cam_list = nullptr;
-    int32_t *oslot = nullptr;         // nV: camera slot within the tile's list
+    uint32_t *opack = nullptr;        // nV: (point - tile's first point) << 16 | camera slot in the tile's list
     void *tile_meta = nullptr;        // n_tiles x TileMeta
     // scratch owned by the handle (device)
     double *cam_table = nullptr;  // K x CAM_ROW
@@ -79,7 +80,17 @@ struct ba_problem {
     int *step_counter = nullptr;  // arrival counter of the multi-workgroup camera step (kept at 0)
     double *step_best = nullptr;  // 2 per workgroup of that kernel
     double *step_stage = nullptr; // 16
+    // second-order extension (allocated on first use)
+    double *cam_sums_jtj = nullptr;  // 33 x K
+    double *partials_jtj = nullptr;  // 3 per tile
+    int64_t *row_ptr = nullptr;      // N + 1
+    int max_degree = 0;              // most observations of one point
     // timing ring
     std::vector<hipEvent_t> ev_begin, ev_end;
     int ev_count = 0;
 };
+
+namespace ba {
+// builds the camera table and scalars of the handle from C, Theta, phi (K1)
+int camera_table(ba_problem *p, const double *C, const double *Theta, const double *phi, hipStream_t st);
+}  // namespace ba

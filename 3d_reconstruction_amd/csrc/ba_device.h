@@ -1,0 +1,65 @@
+// Device-side pieces shared by the kernels of the engine (internal).
+#pragma once
+
+#include "ba_common.h"
+
+namespace ba {
+
+// --------------------------------------------------------------------------------------------
+// small device helpers
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// value of the lane N positions lower in the same 16-lane row (0.0 / 0 where there is none)
+template <int N>
+__device__ __forceinline__ int row_shr(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, 0x110 + N, 0xf, 0xf, true);
+}
+template <int N>
+__device__ __forceinline__ double row_shr(double v) {
+    const int lo = row_shr<N>(__double2loint(v)), hi = row_shr<N>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+// R = Ry(ty) Rx(tx) Rz(tz), row-major (p2w:114-140)
+__device__ __forceinline__ void rotation_yxz(double tx, double ty, double tz, double *R, double *cz_out,
+                                             double *sz_out) {
+    double sx, cx, sy, cy, sz, cz;
+    sincos(tx, &sx, &cx);
+    sincos(ty, &sy, &cy);
+    sincos(tz, &sz, &cz);
+    const double sysx = sy * sx, cysx = cy * sx;
+    R[0] = cy * cz + sysx * sz;
+    R[1] = -cy * sz + sysx * cz;
+    R[2] = sy * cx;
+    R[3] = cx * sz;
+    R[4] = cx * cz;
+    R[5] = -sx;
+    R[6] = -sy * cz + cysx * sz;
+    R[7] = sy * sz + cysx * cz;
+    R[8] = cy * cx;
+    *cz_out = cz;
+    *sz_out = sz;
+}
+
+// Everything a workgroup needs to know about its tile, fetched with one scalar load.
+struct TileMeta {
+    int32_t e0, e1;   // observation range
+    int32_t p0, np;   // first point and point span
+    int32_t nc;       // distinct cameras
+    int32_t j0;       // first camera when the cameras are the contiguous range j0 .. j0+nc-1, else -1
+    int64_t cb;       // offset of the tile's camera list in cam_list
+    int32_t wlo, whi; // points whose gradient this tile writes: its own and the unobserved ones up to
+                      // the next tile's first point (so that every point is written exactly once)
+};
+
+
+constexpr int TILE_BLOCK = 256;
+constexpr int TILE_WAVES = TILE_BLOCK / 64;
+constexpr int ROW_LDS = 12;  // doubles of a camera row kept in LDS: R (9), C (3)
+
+}  // namespace ba

@@ -15,6 +15,7 @@
 // (dq/dtheta_l = -a_l x q for R = Ry Rx Rz, so the 27 entries of dR/dTheta the reference builds
 //  at p2w:678-692 are never formed.)  All sums are un-normalised; the caller applies 1/|V|.
 #include "ba_common.h"
+#include "ba_device.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -31,47 +32,6 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line) {
     g_error = std::string("HIP error ") + hipGetErrorString(e) + " in " + what + " at " + file + ":" +
               std::to_string(line);
     return BA_ERR_HIP;
-}
-
-// --------------------------------------------------------------------------------------------
-// small device helpers
-// --------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
-}
-
-// value of the lane N positions lower in the same 16-lane row (0.0 / 0 where there is none)
-template <int N>
-__device__ __forceinline__ int row_shr(int v) {
-    return __builtin_amdgcn_update_dpp(0, v, 0x110 + N, 0xf, 0xf, true);
-}
-template <int N>
-__device__ __forceinline__ double row_shr(double v) {
-    const int lo = row_shr<N>(__double2loint(v)), hi = row_shr<N>(__double2hiint(v));
-    return __hiloint2double(hi, lo);
-}
-
-// R = Ry(ty) Rx(tx) Rz(tz), row-major (p2w:114-140)
-__device__ __forceinline__ void rotation_yxz(double tx, double ty, double tz, double *R, double *cz_out,
-                                             double *sz_out) {
-    double sx, cx, sy, cy, sz, cz;
-    sincos(tx, &sx, &cx);
-    sincos(ty, &sy, &cy);
-    sincos(tz, &sz, &cz);
-    const double sysx = sy * sx, cysx = cy * sx;
-    R[0] = cy * cz + sysx * sz;
-    R[1] = -cy * sz + sysx * cz;
-    R[2] = sy * cx;
-    R[3] = cx * sz;
-    R[4] = cx * cz;
-    R[5] = -sx;
-    R[6] = -sy * cz + cysx * sz;
-    R[7] = sy * sz + cysx * cz;
-    R[8] = cy * cx;
-    *cz_out = cz;
-    *sz_out = sz;
 }
 
 // --------------------------------------------------------------------------------------------
@@ -473,24 +433,8 @@ __global__ void __launch_bounds__(EVAL_BLOCK) k_eval(EvalArgs a) {
 // (which were bound by the vector-L1 rate), and both reductions are LDS atomics.
 // Observation records carry the camera's slot in the tile's list instead of its index.
 // --------------------------------------------------------------------------------------------
-constexpr int TILE_BLOCK = 256;
-constexpr int TILE_WAVES = TILE_BLOCK / 64;
-constexpr int ROW_LDS = 12;  // doubles of a camera row kept in LDS: R (9), C (3)
-
-// Everything a workgroup needs to know about its tile, fetched with one scalar load.
-struct TileMeta {
-    int32_t e0, e1;   // observation range
-    int32_t p0, np;   // first point and point span
-    int32_t nc;       // distinct cameras
-    int32_t j0;       // first camera when the cameras are the contiguous range j0 .. j0+nc-1, else -1
-    int64_t cb;       // offset of the tile's camera list in cam_list
-    int32_t wlo, whi; // points whose gradient this tile writes: its own and the unobserved ones up to
-                      // the next tile's first point (so that every point is written exactly once)
-};
-
 struct TileArgs {
-    const int32_t *oi;
-    const int32_t *oslot;
+    const uint32_t *opack;       // per observation: (point index - tile's first point) << 16 | camera slot
     const double2 *ouv;
     const TileMeta *meta;        // n_tiles
     const int32_t *cam_list;     // distinct cameras of every tile, ascending
@@ -508,16 +452,17 @@ struct TileArgs {
     int debug;
 };
 
+// A tiled record is 20 bytes: the point (relative to the tile) and the camera slot share one
+// 32-bit word (both are below 65536 inside a tile), the pixel centre is a double2.
 struct TileRec {
-    int i, slot;
+    uint32_t pack;
     double2 uv;
 };
 // lanes past the end of the tile read its last record (a valid address) and are masked later
 __device__ __forceinline__ TileRec load_tile_record(const TileArgs &a, int e, int e_last) {
     const int ec = e < e_last ? e : e_last;
     TileRec r;
-    r.i = a.oi[ec];
-    r.slot = a.oslot[ec];
+    r.pack = a.opack[ec];
     r.uv = a.ouv[ec];
     return r;
 }
@@ -572,8 +517,8 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_eval_tiled(TileArgs a) {
     for (; base < e1; base += TILE_BLOCK) {
         const TileRec recC = load_tile_record(a, base + 2 * TILE_BLOCK + lane, e_last);
         const bool valid = base + lane < e1;
-        const int li = valid ? recA.i - p0 : -2;
-        const int slot = recA.slot;
+        const int li = valid ? (int)(recA.pack >> 16) : -2;
+        const int slot = (int)(recA.pack & 0xffffu);
         const double2 uv = recA.uv;
         recA = recB;
         recB = recC;
@@ -713,7 +658,7 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_tile_count(const int32_t *__rest
 __global__ void __launch_bounds__(TILE_BLOCK) k_tile_fill(const int32_t *__restrict__ oj, const int32_t *__restrict__ tile_obs,
                                                           const int64_t *__restrict__ tile_cam_ptr, int K,
                                                           const int32_t *__restrict__ oi, int64_t nV, int64_t N,
-                                                          int32_t *__restrict__ cam_list, int32_t *__restrict__ oslot,
+                                                          int32_t *__restrict__ cam_list, uint32_t *__restrict__ opack,
                                                           TileMeta *__restrict__ meta) {
     extern __shared__ unsigned bits[];  // n_words bit set, then n_words exclusive prefix counts
     __shared__ int wtot[TILE_WAVES];
@@ -777,7 +722,8 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_tile_fill(const int32_t *__restr
     for (int e = e0 + threadIdx.x; e < e1; e += TILE_BLOCK) {
         const int j = oj[e];
         const unsigned m = bits[j >> 5] & ((1u << (j & 31)) - 1u);
-        oslot[e] = (int)prefix[j >> 5] + __popc(m);
+        const unsigned slot = prefix[j >> 5] + (unsigned)__popc(m);
+        opack[e] = ((unsigned)(oi[e] - oi[e0]) << 16) | slot;
     }
 }
 
@@ -1474,6 +1420,13 @@ static int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 using namespace ba;
 
+int ba::camera_table(ba_problem *p, const double *C, const double *Theta, const double *phi, hipStream_t st) {
+    hipLaunchKernelGGL(k_camera_table, dim3(cdiv(p->K, 256)), dim3(256), 0, st, p->K, C, Theta, phi, p->W, p->H,
+                       p->cam_table, p->scalars);
+    BA_HIP(hipGetLastError());
+    return BA_OK;
+}
+
 // Cuts the observation list into LDS tiles (see k_eval_tiled).  The tile is halved until the
 // camera rows, the points and both accumulator sets of the largest tile fit the LDS budget of a
 // workgroup; scenes whose tiles would each need most of the cameras keep p->tiled == 0 and run
@@ -1511,7 +1464,7 @@ static int build_tiles(ba_problem *p) {
             need = sizeof(double) * ((size_t)(ROW_LDS + 6 * rep) * hmax[0] + 6 * (size_t)hmax[1]);
             if (need <= lds_budget / 4 || rep <= 1) break;
         }
-        if (need <= lds_budget) {
+        if (need <= lds_budget && hmax[0] < 65536 && hmax[1] < 65536) {
             p->cam_rep = rep < 1 ? 1 : rep;
             p->n_tiles = nt;
             p->tile_obs_target = tobs;
@@ -1536,19 +1489,19 @@ static int build_tiles(ba_problem *p) {
     BA_HIP(e);
     // tiles pay off only while fetching every tile's camera rows stays small next to the
     // observation stream
-    const bool worth = getenv("BA_FORCE_TILES") || (double)total_cams * 128.0 <= 0.5 * 24.0 * (double)nV;
-    if (worth) {
+    p->tiles_worth = getenv("BA_FORCE_TILES") || (double)total_cams * 128.0 <= 0.5 * 24.0 * (double)nV;
+    {
         BA_HIP(hipMalloc(&p->cam_list, sizeof(int32_t) * (total_cams > 0 ? total_cams : 1)));
-        BA_HIP(hipMalloc(&p->oslot, sizeof(int32_t) * nV));
+        BA_HIP(hipMalloc(&p->opack, sizeof(uint32_t) * nV));
         BA_HIP(hipMalloc(&p->tile_meta, sizeof(TileMeta) * nt));
         hipLaunchKernelGGL(k_tile_fill, dim3(nt), dim3(TILE_BLOCK), sizeof(unsigned) * 2 * n_words, 0, p->oj, p->tile_obs,
-                           p->tile_cam_ptr, (int)K, p->oi, nV, p->N, p->cam_list, p->oslot, (TileMeta *)p->tile_meta);
+                           p->tile_cam_ptr, (int)K, p->oi, nV, p->N, p->cam_list, p->opack, (TileMeta *)p->tile_meta);
         BA_HIP(hipGetLastError());
         p->tiled = 1;
     }
     if (getenv("BA_VERBOSE"))
-        fprintf(stderr, "[ba] tiles: tiled=%d n_tiles=%d target_obs=%d cam_cap=%d pt_cap=%d rep=%d lds=%zu B cams/tile=%.1f\n",
-                p->tiled, p->n_tiles, p->tile_obs_target, p->cam_cap, p->pt_cap, p->cam_rep, p->tile_lds_bytes,
+        fprintf(stderr, "[ba] tiles: tiled=%d worth=%d n_tiles=%d target_obs=%d cam_cap=%d pt_cap=%d rep=%d lds=%zu B cams/tile=%.1f\n",
+                p->tiled, p->tiles_worth, p->n_tiles, p->tile_obs_target, p->cam_cap, p->pt_cap, p->cam_rep, p->tile_lds_bytes,
                 nt ? (double)total_cams / nt : 0.0);
     return BA_OK;
 }
@@ -1616,7 +1569,7 @@ int ba_problem_destroy(ba_problem *p) {
     hipFree(p->tile_obs);
     hipFree(p->tile_cam_ptr);
     hipFree(p->cam_list);
-    hipFree(p->oslot);
+    hipFree(p->opack);
     hipFree(p->tile_meta);
     hipFree(p->cam_table);
     hipFree(p->cam_sums);
@@ -1625,6 +1578,9 @@ int ba_problem_destroy(ba_problem *p) {
     hipFree(p->step_counter);
     hipFree(p->step_best);
     hipFree(p->step_stage);
+    hipFree(p->cam_sums_jtj);
+    hipFree(p->partials_jtj);
+    hipFree(p->row_ptr);
     hipFree(p->flag);
     for (auto e : p->ev_begin) hipEventDestroy(e);
     for (auto e : p->ev_end) hipEventDestroy(e);
@@ -1743,18 +1699,12 @@ int ba_problem_create(int64_t N, int64_t K, int64_t nV, const int32_t *i, const 
 }
 
 int ba_eval(ba_problem *p, const double *X, const double *C, const double *Theta, const double *phi, int flags,
-            double *E_sum, double *gX, double *gC, double *gTheta, double *gphi, double *V, double *B, double *bphi,
-            double *hphi, void *stream) {
+            double *E_sum, double *gX, double *gC, double *gTheta, double *gphi, void *stream) {
     BA_REQUIRE(p, "ba_eval: null problem");
     BA_REQUIRE(X && C && Theta && phi && E_sum, "ba_eval: null parameter or E_sum pointer");
     BA_REQUIRE(!(flags & BA_EVAL_GRAD_PHI) || gphi, "ba_eval: BA_EVAL_GRAD_PHI needs gphi");
     BA_REQUIRE(!(flags & BA_EVAL_GRAD_X) || gX, "ba_eval: BA_EVAL_GRAD_X needs gX");
     BA_REQUIRE(!(flags & BA_EVAL_GRAD_CAM) || (gC && gTheta), "ba_eval: BA_EVAL_GRAD_CAM needs gC and gTheta");
-    BA_REQUIRE(!(flags & BA_EVAL_JTJ), "ba_eval: BA_EVAL_JTJ is not available in this build");
-    (void)V;
-    (void)B;
-    (void)bphi;
-    (void)hphi;
     hipStream_t st = (hipStream_t)stream;
     const int64_t K = p->K;
 
@@ -1763,7 +1713,7 @@ int ba_eval(ba_problem *p, const double *X, const double *C, const double *Theta
                            p->cam_table, p->scalars);
     BA_HIP(hipMemsetAsync(p->cam_sums, 0, sizeof(double) * 6 * K, st));
     const bool want_gx = (flags & BA_EVAL_GRAD_X) != 0;
-    const bool use_tiles = p->tiled && !(flags & (BA_EVAL_CAM_ATOMICS | BA_EVAL_UNTILED));
+    const bool use_tiles = p->tiled && p->tiles_worth && !(flags & (BA_EVAL_CAM_ATOMICS | BA_EVAL_UNTILED));
     // the tiled pass writes every point's gradient itself; the wave-chunk pass only the observed ones
     if (want_gx && !use_tiles && p->n_points_seen < p->N)
         BA_HIP(hipMemsetAsync(gX, 0, sizeof(double) * 3 * p->N, st));
@@ -1791,8 +1741,7 @@ int ba_eval(ba_problem *p, const double *X, const double *C, const double *Theta
     if (timed) BA_HIP(hipEventRecord(p->ev_begin[p->ev_count], st));
     if (use_tiles) {
         TileArgs ta;
-        ta.oi = p->oi;
-        ta.oslot = p->oslot;
+        ta.opack = p->opack;
         ta.ouv = p->ouv;
         ta.meta = (const TileMeta *)p->tile_meta;
         ta.cam_list = p->cam_list;

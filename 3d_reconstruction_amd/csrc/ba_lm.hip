@@ -1,0 +1,934 @@
+// Second-order extension of the engine (no counterpart in the reference, which is first-order
+// only): Gauss-Newton blocks J^T J in the same fused observation pass, the Schur complement onto
+// the cameras, a blocked dense fp64 Cholesky whose trailing update runs on the fp64 matrix cores
+// (v_mfma_f64_16x16x4_f64), triangular solves and the back-substitution for the points.
+//
+// Unknown order of the reduced system: camera j owns rows 6j .. 6j+5 (C_x, C_y, C_z, theta_x,
+// theta_y, theta_z), phi_x is row 6K; n = 6K + 1, stored row-major with leading dimension
+// ld = n rounded up to a multiple of 64 (padding rows/columns are the identity).
+//
+// Per observation (camera frame, see ba_engine.hip): u_0 = fi (1, 0, -m0), u_1 = fi (0, 1, -m1) are the
+// rows of d model / d q (fi = f / q2).  Then
+//   J_X   rows jx_a = R u_a                     (world frame)
+//   J_cam rows G_a T,  G_a = (-u_a, u_a x q),  T = blockdiag(R^T, [a_x a_y a_z])
+//   J_phi rows dphi m_a,  dphi = -f / sin(phi_x)
+// so per camera the blocks are accumulated in the camera frame (B' = sum G^T G, b' = sum G^T m) and
+// rotated once per camera afterwards.
+#include "ba_device.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+namespace ba {
+
+constexpr int CAMV = 33;  // per camera: force (3), torque (3), B' upper triangle (21), b' (6)
+constexpr int PTV = 12;   // per point: gradient (3), V upper triangle (6), point x phi (3)
+
+struct JtjArgs {
+    const uint32_t *opack;
+    const double2 *ouv;
+    const TileMeta *meta;
+    const int32_t *cam_list;
+    int K;
+    int cam_cap, pt_cap;
+    const double *X;
+    const double *T;
+    const double *scalars;
+    double *gX;        // N x 3
+    double *V;         // N x 6
+    double *Xphi;      // N x 3
+    double *cam_sums;  // CAMV x K, component-major (pre-zeroed)
+    double *partials;  // per tile {sum r^2, sum m.r, sum m.m}
+};
+
+// per-observation quantities shared by the J^T J pass and the Schur kernels
+struct ObsJac {
+    double r0, r1, m0, m1, fi;
+    double q0, q1, q2;
+    double jx0[3], jx1[3];  // rows of J_X
+    double G0[6], G1[6];    // rows of the camera-frame camera Jacobian
+};
+
+__device__ __forceinline__ ObsJac obs_jacobian(const double *x, const double2 *rw, double f, double pcx, double pcy,
+                                               double2 uv) {
+    const double2 t0 = rw[0], t1 = rw[1], t2 = rw[2], t3 = rw[3], t4 = rw[4], t5 = rw[5];
+    const double R00 = t0.x, R01 = t0.y, R02 = t1.x, R10 = t1.y, R11 = t2.x, R12 = t2.y, R20 = t3.x, R21 = t3.y,
+                 R22 = t4.x;
+    ObsJac o;
+    const double d0 = x[0] - t4.y, d1 = x[1] - t5.x, d2 = x[2] - t5.y;
+    o.q0 = R00 * d0 + R10 * d1 + R20 * d2;
+    o.q1 = R01 * d0 + R11 * d1 + R21 * d2;
+    o.q2 = R02 * d0 + R12 * d1 + R22 * d2;
+    const double inv = 1.0 / o.q2;
+    o.m0 = o.q0 * inv;
+    o.m1 = o.q1 * inv;
+    o.r0 = f * o.m0 + pcx - uv.x;
+    o.r1 = f * o.m1 + pcy - uv.y;
+    const double fi = f * inv;
+    o.fi = fi;
+    o.jx0[0] = fi * (R00 - o.m0 * R02);
+    o.jx0[1] = fi * (R10 - o.m0 * R12);
+    o.jx0[2] = fi * (R20 - o.m0 * R22);
+    o.jx1[0] = fi * (R01 - o.m1 * R02);
+    o.jx1[1] = fi * (R11 - o.m1 * R12);
+    o.jx1[2] = fi * (R21 - o.m1 * R22);
+    o.G0[0] = -fi;
+    o.G0[1] = 0.0;
+    o.G0[2] = fi * o.m0;
+    o.G0[3] = fi * (o.m0 * o.q1);
+    o.G0[4] = -fi * (o.m0 * o.q0 + o.q2);
+    o.G0[5] = fi * o.q1;
+    o.G1[0] = 0.0;
+    o.G1[1] = -fi;
+    o.G1[2] = fi * o.m1;
+    o.G1[3] = fi * (o.q2 + o.m1 * o.q1);
+    o.G1[4] = -fi * (o.m1 * o.q0);
+    o.G1[5] = -fi * o.q0;
+    return o;
+}
+
+// --------------------------------------------------------------------------------------------
+// K3: fused residual + Jacobian + J^T J pass on LDS tiles
+// --------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(TILE_BLOCK) k_jtj_tiled(JtjArgs a) {
+    extern __shared__ double lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int t = blockIdx.x;
+    const TileMeta tm = a.meta[t];
+    const int e0 = tm.e0, e1 = tm.e1, p0 = tm.p0, np = tm.np, nc = tm.nc;
+    const int64_t cb = tm.cb;
+    __shared__ double red[3][TILE_WAVES];
+    if (e0 >= e1) {
+        if (tid < 3) a.partials[3 * (int64_t)t + tid] = 0.0;
+        return;
+    }
+    double *rows = lds;                                    // cam_cap x ROW_LDS
+    double *cacc = rows + (size_t)a.cam_cap * ROW_LDS;     // CAMV x nc (component-major)
+    double *xs = cacc + (size_t)a.cam_cap * CAMV;          // np x 3
+    double *pacc = xs + (size_t)a.pt_cap * 3;              // np x PTV
+
+    for (int idx = tid; idx < nc * (ROW_LDS / 2); idx += TILE_BLOCK) {
+        const int row = idx / (ROW_LDS / 2), piece = idx - row * (ROW_LDS / 2);
+        const int j = tm.j0 >= 0 ? tm.j0 + row : a.cam_list[cb + row];
+        ((double2 *)rows)[idx] = ((const double2 *)(a.T + (int64_t)j * CAM_ROW))[piece];
+    }
+    for (int idx = tid; idx < CAMV * nc; idx += TILE_BLOCK) cacc[idx] = 0.0;
+    for (int idx = tid; idx < 3 * np; idx += TILE_BLOCK) xs[idx] = a.X[3 * (int64_t)p0 + idx];
+    for (int idx = tid; idx < PTV * np; idx += TILE_BLOCK) pacc[idx] = 0.0;
+    const double f = a.scalars[SC_F], pcx = a.scalars[SC_CX], pcy = a.scalars[SC_CY], dphi = a.scalars[SC_DPHI];
+    __syncthreads();
+
+    double esum = 0.0, psum = 0.0, hsum = 0.0;
+    for (int base = e0 + wid * 64; base < e1; base += TILE_BLOCK) {
+        const int e = base + lane;
+        const bool valid = e < e1;
+        const int ec = valid ? e : e1 - 1;
+        const uint32_t pack = a.opack[ec];
+        const int li = valid ? (int)(pack >> 16) : -2;
+        const int slot = (int)(pack & 0xffffu);
+        const double2 uv = a.ouv[ec];
+        ObsJac o = obs_jacobian(xs + 3 * (valid ? li : 0), (const double2 *)(rows + slot * ROW_LDS), f, pcx, pcy, uv);
+        const double vm = valid ? 1.0 : 0.0;
+        const double r0 = o.r0 * vm, r1 = o.r1 * vm;
+        esum += r0 * r0 + r1 * r1;
+        psum += o.m0 * r0 + o.m1 * r1;
+        hsum += vm * (o.m0 * o.m0 + o.m1 * o.m1);
+
+        if (valid) {
+            double cv[CAMV];
+            // force g = u0 r0 + u1 r1 = -(G0 r0 + G1 r1)[0..2]; torque q x g = -(G0 r0 + G1 r1)[3..5]
+#pragma unroll
+            for (int k = 0; k < 6; ++k) cv[k] = -(o.G0[k] * r0 + o.G1[k] * r1);
+            int idx = 6;
+#pragma unroll
+            for (int p = 0; p < 6; ++p)
+#pragma unroll
+                for (int q = p; q < 6; ++q) cv[idx++] = o.G0[p] * o.G0[q] + o.G1[p] * o.G1[q];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) cv[27 + k] = o.G0[k] * o.m0 + o.G1[k] * o.m1;
+            double *acc = cacc + slot;
+#pragma unroll
+            for (int k = 0; k < CAMV; ++k)
+                __hip_atomic_fetch_add(acc + k * nc, cv[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+
+        // point side: 12 values, segmented scan inside 16-lane rows, run tails add to LDS
+        double pv[PTV];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pv[k] = o.jx0[k] * r0 + o.jx1[k] * r1;
+        pv[3] = vm * (o.jx0[0] * o.jx0[0] + o.jx1[0] * o.jx1[0]);
+        pv[4] = vm * (o.jx0[0] * o.jx0[1] + o.jx1[0] * o.jx1[1]);
+        pv[5] = vm * (o.jx0[0] * o.jx0[2] + o.jx1[0] * o.jx1[2]);
+        pv[6] = vm * (o.jx0[1] * o.jx0[1] + o.jx1[1] * o.jx1[1]);
+        pv[7] = vm * (o.jx0[1] * o.jx0[2] + o.jx1[1] * o.jx1[2]);
+        pv[8] = vm * (o.jx0[2] * o.jx0[2] + o.jx1[2] * o.jx1[2]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pv[9 + k] = vm * dphi * (o.jx0[k] * o.m0 + o.jx1[k] * o.m1);
+
+        const int lane16 = lane & 15;
+        const int ip = row_shr<1>(li);
+        const bool head = (lane16 == 0) || (ip != li);
+        const unsigned long long hm = __ballot(head);
+        const unsigned long long below = hm & (~0ull >> (63 - lane));
+        const int dist = lane - (63 - __clzll(below));
+#pragma unroll
+        for (int k = 0; k < PTV; ++k) {
+            double v = pv[k];
+            double s = row_shr<1>(v);
+            if (dist >= 1) v += s;
+            s = row_shr<2>(v);
+            if (dist >= 2) v += s;
+            s = row_shr<4>(v);
+            if (dist >= 4) v += s;
+            s = row_shr<8>(v);
+            if (dist >= 8) v += s;
+            pv[k] = v;
+        }
+        const bool tail = (lane == 63) || ((hm >> (lane + 1)) & 1ull);
+        if (tail && li >= 0) {
+            double *pa = pacc + PTV * li;
+#pragma unroll
+            for (int k = 0; k < PTV; ++k)
+                __hip_atomic_fetch_add(pa + k, pv[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    esum = wave_sum(esum);
+    psum = wave_sum(psum);
+    hsum = wave_sum(hsum);
+    if (lane == 0) {
+        red[0][wid] = esum;
+        red[1][wid] = psum;
+        red[2][wid] = hsum;
+    }
+    __syncthreads();
+    if (tid < 3) a.partials[3 * (int64_t)t + tid] = (red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]);
+
+    // every point is written by exactly one tile (unobserved ones get zeros)
+    const int lo = tm.wlo - p0, hi = tm.whi - p0;
+    for (int idx = 3 * lo + tid; idx < 3 * hi; idx += TILE_BLOCK) {
+        const int pt = idx >= 0 ? idx / 3 : -1, k = idx - 3 * pt;
+        const bool in = idx >= 0 && pt < np;
+        a.gX[3 * (int64_t)p0 + idx] = in ? pacc[PTV * pt + k] : 0.0;
+        a.Xphi[3 * (int64_t)p0 + idx] = in ? pacc[PTV * pt + 9 + k] : 0.0;
+    }
+    for (int idx = 6 * lo + tid; idx < 6 * hi; idx += TILE_BLOCK) {
+        const int pt = idx >= 0 ? idx / 6 : -1, k = idx - 6 * pt;
+        a.V[6 * (int64_t)p0 + idx] = (idx >= 0 && pt < np) ? pacc[PTV * pt + 3 + k] : 0.0;
+    }
+    for (int idx = tid; idx < CAMV * nc; idx += TILE_BLOCK) {
+        const int comp = idx / nc, slot = idx - comp * nc;
+        const int j = tm.j0 >= 0 ? tm.j0 + slot : a.cam_list[cb + slot];
+        __hip_atomic_fetch_add(a.cam_sums + (int64_t)comp * a.K + j, cacc[idx], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// T = blockdiag(R^T, A), A = [a_x a_y a_z] columns: row mu, column alpha of the 6x6 frame change
+__device__ __forceinline__ void camera_frame_change(const double *row, double T[6][6]) {
+#pragma unroll
+    for (int p = 0; p < 6; ++p)
+#pragma unroll
+        for (int q = 0; q < 6; ++q) T[p][q] = 0.0;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) T[p][q] = row[3 * q + p];  // R^T
+    // a_x = (cos tz, -sin tz, 0), a_y = row 1 of R, a_z = e_z
+    T[3][3] = row[12];
+    T[4][3] = -row[13];
+    T[5][3] = 0.0;
+    T[3][4] = row[3];
+    T[4][4] = row[4];
+    T[5][4] = row[5];
+    T[3][5] = 0.0;
+    T[4][5] = 0.0;
+    T[5][5] = 1.0;
+}
+
+// camera-frame sums -> gradient, B (21), bphi (6) per camera; scalars
+__global__ void __launch_bounds__(256) k_jtj_finalize(int64_t K, int n_partials, const double *__restrict__ partials,
+                                                      const double *__restrict__ cam_sums, const double *__restrict__ T,
+                                                      const double *__restrict__ scalars, double *__restrict__ E_sum,
+                                                      double *__restrict__ gphi, double *__restrict__ hphi,
+                                                      double *__restrict__ gC, double *__restrict__ gTheta,
+                                                      double *__restrict__ B, double *__restrict__ bphi) {
+    const double dphi = scalars[SC_DPHI];
+    if (blockIdx.x == 0) {
+        __shared__ double red[3][4];
+        double acc[3] = {0.0, 0.0, 0.0};
+        for (int t = threadIdx.x; t < n_partials; t += 256)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) acc[k] += partials[3 * t + k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            acc[k] = wave_sum(acc[k]);
+            if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = acc[k];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            E_sum[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+            gphi[0] = dphi * ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+            hphi[0] = dphi * dphi * ((red[2][0] + red[2][1]) + (red[2][2] + red[2][3]));
+        }
+    }
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= K) return;
+    const double *row = T + j * CAM_ROW;
+    double Tm[6][6];
+    camera_frame_change(row, Tm);
+    double c[CAMV];
+#pragma unroll
+    for (int k = 0; k < CAMV; ++k) c[k] = cam_sums[(int64_t)k * K + j];
+    // gradient: sum J_cam^T r = T^T sum G^T r = -T^T (force, torque)
+#pragma unroll
+    for (int al = 0; al < 6; ++al) {
+        double v = 0.0;
+#pragma unroll
+        for (int mu = 0; mu < 6; ++mu) v += Tm[mu][al] * c[mu];
+        if (al < 3) gC[3 * j + al] = -v;
+        else gTheta[3 * j + al - 3] = -v;
+    }
+    double Bp[6][6];
+    int idx = 6;
+#pragma unroll
+    for (int p = 0; p < 6; ++p)
+#pragma unroll
+        for (int q = p; q < 6; ++q) {
+            Bp[p][q] = c[idx];
+            Bp[q][p] = c[idx];
+            ++idx;
+        }
+    double M[6][6];  // B' T
+#pragma unroll
+    for (int mu = 0; mu < 6; ++mu)
+#pragma unroll
+        for (int be = 0; be < 6; ++be) {
+            double v = 0.0;
+#pragma unroll
+            for (int nu = 0; nu < 6; ++nu) v += Bp[mu][nu] * Tm[nu][be];
+            M[mu][be] = v;
+        }
+    idx = 0;
+#pragma unroll
+    for (int al = 0; al < 6; ++al)
+#pragma unroll
+        for (int be = al; be < 6; ++be) {
+            double v = 0.0;
+#pragma unroll
+            for (int mu = 0; mu < 6; ++mu) v += Tm[mu][al] * M[mu][be];
+            B[21 * j + idx] = v;
+            ++idx;
+        }
+#pragma unroll
+    for (int al = 0; al < 6; ++al) {
+        double v = 0.0;
+#pragma unroll
+        for (int mu = 0; mu < 6; ++mu) v += Tm[mu][al] * c[27 + mu];
+        bphi[6 * j + al] = dphi * v;
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// K4: Schur complement onto the cameras.  S starts as the damped camera / phi blocks; every point
+// subtracts Y^T V'^-1 Y, where Y holds its 3x6 cross blocks W_ij and its 3x1 phi column.
+// --------------------------------------------------------------------------------------------
+__global__ void k_schur_init(int64_t K, int64_t n, int64_t ld, double lambda, const double *__restrict__ B,
+                             const double *__restrict__ bphi, const double *__restrict__ hphi,
+                             const double *__restrict__ gC, const double *__restrict__ gTheta,
+                             const double *__restrict__ gphi, double *__restrict__ S, double *__restrict__ rhs) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < K) {
+        int idx = 0;
+        for (int p = 0; p < 6; ++p)
+            for (int q = p; q < 6; ++q) {
+                double v = B[21 * j + idx++];
+                if (p == q) v *= 1.0 + lambda;
+                S[(6 * j + p) * ld + 6 * j + q] = v;
+                S[(6 * j + q) * ld + 6 * j + p] = v;
+            }
+        for (int p = 0; p < 6; ++p) {
+            S[(6 * K) * ld + 6 * j + p] = bphi[6 * j + p];
+            S[(6 * j + p) * ld + 6 * K] = bphi[6 * j + p];
+            rhs[6 * j + p] = -(p < 3 ? gC[3 * j + p] : gTheta[3 * j + p - 3]);
+        }
+    }
+    if (j == 0) {
+        S[(6 * K) * ld + 6 * K] = hphi[0] * (1.0 + lambda);
+        rhs[6 * K] = -gphi[0];
+        for (int64_t t = n; t < ld; ++t) {
+            S[t * ld + t] = 1.0;
+            rhs[t] = 0.0;
+        }
+    }
+}
+
+// inverse of the damped symmetric 3x3 point block
+__device__ __forceinline__ void inv_sym3(const double *V6, double lambda, double *inv /*6, upper*/) {
+    const double a = V6[0] * (1.0 + lambda), b = V6[1], c = V6[2], d = V6[3] * (1.0 + lambda), e = V6[4],
+                 g = V6[5] * (1.0 + lambda);
+    const double A = d * g - e * e, Bc = c * e - b * g, Cc = b * e - c * d;
+    const double det = a * A + b * Bc + c * Cc;
+    const double id = 1.0 / det;
+    inv[0] = A * id;
+    inv[1] = Bc * id;
+    inv[2] = Cc * id;
+    inv[3] = (a * g - c * c) * id;
+    inv[4] = (b * c - a * e) * id;
+    inv[5] = (a * d - b * b) * id;
+}
+
+struct SchurArgs {
+    const int32_t *oj;
+    const double2 *ouv;
+    const int64_t *row_ptr;  // N + 1: observation range of every point
+    int64_t N, K, ld;
+    double lambda;
+    const double *X, *T, *scalars;
+    const double *V, *Xphi, *gX;
+    double *S, *rhs;
+    int max_deg;
+};
+
+// One wave per point.  LDS per wave: W (deg x 18) and Z = V'^-1 W (deg x 18), camera index (deg).
+__global__ void __launch_bounds__(256) k_schur_points(SchurArgs a) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 4 + wid;
+    if (i >= a.N) return;
+    const int64_t e0 = a.row_ptr[i], e1 = a.row_ptr[i + 1];
+    const int deg = (int)(e1 - e0);
+    if (deg == 0) return;
+    double *Wl = lds + (size_t)wid * a.max_deg * 37;
+    double *Zl = Wl + (size_t)a.max_deg * 18;
+    int *jl = (int *)(Zl + (size_t)a.max_deg * 18);
+    const double f = a.scalars[SC_F], pcx = a.scalars[SC_CX], pcy = a.scalars[SC_CY];
+    double Vi[6];
+    inv_sym3(a.V + 6 * i, a.lambda, Vi);
+    const double x[3] = {a.X[3 * i], a.X[3 * i + 1], a.X[3 * i + 2]};
+    const double wp[3] = {a.Xphi[3 * i], a.Xphi[3 * i + 1], a.Xphi[3 * i + 2]};
+    const double gx[3] = {a.gX[3 * i], a.gX[3 * i + 1], a.gX[3 * i + 2]};
+    // V'^-1 wphi and V'^-1 gX
+    const double zw[3] = {Vi[0] * wp[0] + Vi[1] * wp[1] + Vi[2] * wp[2], Vi[1] * wp[0] + Vi[3] * wp[1] + Vi[4] * wp[2],
+                          Vi[2] * wp[0] + Vi[4] * wp[1] + Vi[5] * wp[2]};
+    const double zg[3] = {Vi[0] * gx[0] + Vi[1] * gx[1] + Vi[2] * gx[2], Vi[1] * gx[0] + Vi[3] * gx[1] + Vi[4] * gx[2],
+                          Vi[2] * gx[0] + Vi[4] * gx[1] + Vi[5] * gx[2]};
+    const int64_t nphi = 6 * a.K;
+
+    for (int o = lane; o < deg; o += 64) {
+        const int64_t e = e0 + o;
+        const int j = a.oj[e];
+        const double *row = a.T + (int64_t)j * CAM_ROW;
+        ObsJac ob = obs_jacobian(x, (const double2 *)row, f, pcx, pcy, a.ouv[e]);
+        double Tm[6][6];
+        camera_frame_change(row, Tm);
+        double jc0[6], jc1[6];  // rows of J_cam = G T
+#pragma unroll
+        for (int al = 0; al < 6; ++al) {
+            double v0 = 0.0, v1 = 0.0;
+#pragma unroll
+            for (int mu = 0; mu < 6; ++mu) {
+                v0 += ob.G0[mu] * Tm[mu][al];
+                v1 += ob.G1[mu] * Tm[mu][al];
+            }
+            jc0[al] = v0;
+            jc1[al] = v1;
+        }
+        double W[3][6];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int al = 0; al < 6; ++al) W[p][al] = ob.jx0[p] * jc0[al] + ob.jx1[p] * jc1[al];
+#pragma unroll
+        for (int al = 0; al < 6; ++al) {
+            const double z0 = Vi[0] * W[0][al] + Vi[1] * W[1][al] + Vi[2] * W[2][al];
+            const double z1 = Vi[1] * W[0][al] + Vi[3] * W[1][al] + Vi[4] * W[2][al];
+            const double z2 = Vi[2] * W[0][al] + Vi[4] * W[1][al] + Vi[5] * W[2][al];
+            Wl[o * 18 + 0 * 6 + al] = W[0][al];
+            Wl[o * 18 + 1 * 6 + al] = W[1][al];
+            Wl[o * 18 + 2 * 6 + al] = W[2][al];
+            Zl[o * 18 + 0 * 6 + al] = z0;
+            Zl[o * 18 + 1 * 6 + al] = z1;
+            Zl[o * 18 + 2 * 6 + al] = z2;
+            // camera x phi column, right-hand side
+            const double sphi = W[0][al] * zw[0] + W[1][al] * zw[1] + W[2][al] * zw[2];
+            const double rr = W[0][al] * zg[0] + W[1][al] * zg[1] + W[2][al] * zg[2];
+            const int64_t ra = 6 * (int64_t)j + al;
+            __hip_atomic_fetch_add(a.S + nphi * a.ld + ra, -sphi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(a.S + ra * a.ld + nphi, -sphi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(a.rhs + ra, rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        jl[o] = j;
+    }
+    if (lane == 0) {
+        const double spp = wp[0] * zw[0] + wp[1] * zw[1] + wp[2] * zw[2];
+        const double rp = wp[0] * zg[0] + wp[1] * zg[1] + wp[2] * zg[2];
+        __hip_atomic_fetch_add(a.S + nphi * a.ld + nphi, -spp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(a.rhs + nphi, rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    // all ordered pairs (o, o') of the point's observations, 36 entries each: S[j, j'] -= W_o^T Z_o'
+    const int total = deg * deg * 36;
+    for (int w = lane; w < total; w += 64) {
+        const int pair = w / 36, ent = w - pair * 36;
+        const int o = pair / deg, o2 = pair - o * deg;
+        const int al = ent / 6, be = ent - al * 6;
+        const double v = Wl[o * 18 + al] * Zl[o2 * 18 + be] + Wl[o * 18 + 6 + al] * Zl[o2 * 18 + 6 + be] +
+                         Wl[o * 18 + 12 + al] * Zl[o2 * 18 + 12 + be];
+        if (jl[o] < jl[o2]) continue;  // lower block triangle only: the factorisation never reads the rest
+        const int64_t ra = 6 * (int64_t)jl[o] + al, cbx = 6 * (int64_t)jl[o2] + be;
+        __hip_atomic_fetch_add(a.S + ra * a.ld + cbx, -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// back-substitution: dX_i = V'^-1 (-gX_i - sum_j W_ij dcam_j - wphi_i dphi); one thread per point
+struct BacksubArgs {
+    const int32_t *oj;
+    const double2 *ouv;
+    const int64_t *row_ptr;
+    int64_t N, K;
+    double lambda;
+    const double *X, *T, *scalars;
+    const double *V, *Xphi, *gX;
+    const double *d;  // solution of the reduced system, camera-major order (6j + k), phi at 6K
+    double *dX;
+};
+
+__global__ void __launch_bounds__(256) k_backsub(BacksubArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.N) return;
+    const int64_t e0 = a.row_ptr[i], e1 = a.row_ptr[i + 1];
+    if (e0 == e1) {
+        a.dX[3 * i] = a.dX[3 * i + 1] = a.dX[3 * i + 2] = 0.0;
+        return;
+    }
+    const double f = a.scalars[SC_F], pcx = a.scalars[SC_CX], pcy = a.scalars[SC_CY];
+    const double x[3] = {a.X[3 * i], a.X[3 * i + 1], a.X[3 * i + 2]};
+    const double dphi_x = a.d[6 * a.K];
+    double rh[3] = {-a.gX[3 * i] - a.Xphi[3 * i] * dphi_x, -a.gX[3 * i + 1] - a.Xphi[3 * i + 1] * dphi_x,
+                    -a.gX[3 * i + 2] - a.Xphi[3 * i + 2] * dphi_x};
+    for (int64_t e = e0; e < e1; ++e) {
+        const int j = a.oj[e];
+        const double *row = a.T + (int64_t)j * CAM_ROW;
+        ObsJac ob = obs_jacobian(x, (const double2 *)row, f, pcx, pcy, a.ouv[e]);
+        double Tm[6][6];
+        camera_frame_change(row, Tm);
+        // s_a = J_cam row a . dcam_j
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int al = 0; al < 6; ++al) {
+            double v0 = 0.0, v1 = 0.0;
+#pragma unroll
+            for (int mu = 0; mu < 6; ++mu) {
+                v0 += ob.G0[mu] * Tm[mu][al];
+                v1 += ob.G1[mu] * Tm[mu][al];
+            }
+            const double dc = a.d[6 * (int64_t)j + al];
+            s0 += v0 * dc;
+            s1 += v1 * dc;
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) rh[p] -= ob.jx0[p] * s0 + ob.jx1[p] * s1;
+    }
+    double Vi[6];
+    inv_sym3(a.V + 6 * i, a.lambda, Vi);
+    a.dX[3 * i + 0] = Vi[0] * rh[0] + Vi[1] * rh[1] + Vi[2] * rh[2];
+    a.dX[3 * i + 1] = Vi[1] * rh[0] + Vi[3] * rh[1] + Vi[4] * rh[2];
+    a.dX[3 * i + 2] = Vi[2] * rh[0] + Vi[4] * rh[1] + Vi[5] * rh[2];
+}
+
+// observation range of every point from the sorted point indices
+__global__ void k_row_ptr(const int32_t *__restrict__ oi, int64_t nV, int64_t N, int64_t *__restrict__ row_ptr) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e > nV) return;
+    const int64_t cur = e < nV ? oi[e] : N, prev = e > 0 ? oi[e - 1] : -1;
+    for (int64_t p = prev + 1; p <= cur; ++p) row_ptr[p] = e;
+}
+
+__global__ void k_max_degree(const int64_t *__restrict__ row_ptr, int64_t N, int *out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int d = 0;
+    if (i < N) d = (int)(row_ptr[i + 1] - row_ptr[i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) d = max(d, __shfl_xor(d, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, d);
+}
+
+// solution in camera-major order -> packed [dC (3K) | dTheta (3K) | dphi]
+__global__ void k_unpack_solution(int64_t K, const double *__restrict__ d, double *__restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < 6 * K) {
+        const int64_t j = t / 6, k = t - 6 * j;
+        out[(k < 3 ? 0 : 3 * K) + 3 * j + (k % 3)] = d[t];
+    } else if (t == 6 * K) {
+        out[6 * K] = d[6 * K];
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// K5: blocked right-looking Cholesky, lower triangle, row-major with leading dimension ld,
+// n a multiple of NB = 64.  Per block column k:
+//   potrf : L_kk = chol(A_kk) and its inverse, one workgroup in LDS;
+//   trsm  : A_ik <- A_ik L_kk^-T for all i > k, as a product with the inverse  (matrix cores);
+//   syrk  : A_ij <- A_ij - A_ik A_jk^T for all i >= j > k                       (matrix cores).
+// The matrix-core tile is v_mfma_f64_16x16x4_f64: lane l supplies A[l & 15][l >> 4] and
+// B[l >> 4][l & 15]; it holds D[(l >> 4) + 4 r][l & 15] in register r = 0..3.
+// --------------------------------------------------------------------------------------------
+constexpr int NB = 64;
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256) k_potrf(double *__restrict__ A, int64_t ld, int64_t k0, double *__restrict__ Linv,
+                                               int *__restrict__ info) {
+    __shared__ double L[NB][NB + 1];
+    __shared__ double Li[NB][NB + 1];
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < NB * NB; idx += 256) {
+        const int r = idx / NB, c = idx - r * NB;
+        L[r][c] = (c <= r) ? A[(k0 + r) * ld + k0 + c] : 0.0;
+    }
+    __syncthreads();
+    for (int k = 0; k < NB; ++k) {
+        const double dkk = L[k][k];
+        if (tid == 0 && !(dkk > 0.0)) atomicCAS(info, 0, (int)(k0 + k + 1));
+        const double d = sqrt(dkk);
+        __syncthreads();
+        if (tid >= k && tid < NB) L[tid][k] = (tid == k) ? d : L[tid][k] / d;
+        __syncthreads();
+        // trailing update of the lower triangle: rows i > k, columns k < j <= i
+        for (int idx = tid; idx < NB * NB; idx += 256) {
+            const int i = idx / NB, j = idx - i * NB;
+            if (j > k && i >= j) L[i][j] -= L[i][k] * L[j][k];
+        }
+        __syncthreads();
+    }
+    // inverse of L: column c of L^-1 by forward substitution, one thread per column
+    if (tid < NB) {
+        const int c = tid;
+        for (int r = 0; r < NB; ++r) {
+            double v = (r == c) ? 1.0 : 0.0;
+            for (int m = c; m < r; ++m) v -= L[r][m] * Li[m][c];
+            Li[r][c] = (r >= c) ? v / L[r][r] : 0.0;
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < NB * NB; idx += 256) {
+        const int r = idx / NB, c = idx - r * NB;
+        A[(k0 + r) * ld + k0 + c] = L[r][c];
+        Linv[idx] = Li[r][c];
+    }
+}
+
+// D (64x64) = P (64x64, row-major, leading dimension ldp) times Q^T (Q 64x64 row-major, ldq), one wave
+__device__ __forceinline__ void mfma_tile_64(const double *__restrict__ P, int64_t ldp, const double *__restrict__ Q,
+                                             int64_t ldq, v4f64 acc[4][4]) {
+    const int lane = threadIdx.x & 63;
+    const int r16 = lane & 15, k4 = lane >> 4;
+    for (int kk = 0; kk < NB; kk += 4) {
+        double af[4], bf[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) af[m] = P[(int64_t)(16 * m + r16) * ldp + kk + k4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) bf[n] = Q[(int64_t)(16 * n + r16) * ldq + kk + k4];  // B[k][j] = Q[j][k]
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[m], bf[n], acc[m][n], 0, 0, 0);
+    }
+}
+
+// A_ik <- A_ik L_kk^-T  (= A_ik times (L^-1)^T): one wave per 64-row block
+__global__ void __launch_bounds__(64) k_trsm(double *__restrict__ A, int64_t ld, int64_t k0,
+                                             const double *__restrict__ Linv, int64_t n) {
+    const int64_t i0 = k0 + NB + (int64_t)blockIdx.x * NB;
+    if (i0 >= n) return;
+    v4f64 acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn) acc[m][nn] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    double *P = A + i0 * ld + k0;
+    mfma_tile_64(P, ld, Linv, NB, acc);
+    const int lane = threadIdx.x & 63, col = lane & 15, rq = lane >> 4;
+    // every accumulator depends on all of P, so P has been read completely before the first store
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) P[(int64_t)(16 * m + rq + 4 * r) * ld + 16 * nn + col] = acc[m][nn][r];
+}
+
+// A_ij -= A_ik A_jk^T for the lower block triangle behind block column k; one wave per 64x64 block,
+// blocks enumerated row by row: t -> (bi, bj), bj <= bi
+__global__ void __launch_bounds__(256) k_syrk(double *__restrict__ A, int64_t ld, int64_t k0, int64_t n_blocks_behind,
+                                              int64_t n_tiles) {
+    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= n_tiles) return;
+    // invert t = bi (bi + 1) / 2 + bj
+    int64_t bi = (int64_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while (bi * (bi + 1) / 2 > t) --bi;
+    while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+    const int64_t bj = t - bi * (bi + 1) / 2;
+    (void)n_blocks_behind;
+    const int64_t i0 = k0 + NB * (1 + bi), j0 = k0 + NB * (1 + bj);
+    v4f64 acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn) acc[m][nn] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    mfma_tile_64(A + i0 * ld + k0, ld, A + j0 * ld + k0, ld, acc);
+    const int lane = threadIdx.x & 63, col = lane & 15, rq = lane >> 4;
+    double *Cc = A + i0 * ld + j0;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double *dst = Cc + (int64_t)(16 * m + rq + 4 * r) * ld + 16 * nn + col;
+                *dst -= acc[m][nn][r];
+            }
+}
+
+// triangular solves with one right-hand side, block by block (NB rows at a time)
+// forward: y_k = L_kk^-1 (b_k - sum_{m<k} L_km y_m); the sums are applied eagerly after each block
+__global__ void __launch_bounds__(64) k_solve_diag(const double *__restrict__ A, int64_t ld, int64_t k0, double *__restrict__ b,
+                                                   int transpose) {
+    __shared__ double y[NB];
+    const int t = threadIdx.x;
+    y[t] = b[k0 + t];
+    __syncthreads();
+    if (!transpose) {
+        for (int r = 0; r < NB; ++r) {
+            if (t == r) y[r] /= A[(k0 + r) * ld + k0 + r];
+            __syncthreads();
+            if (t > r) y[t] -= A[(k0 + t) * ld + k0 + r] * y[r];
+            __syncthreads();
+        }
+    } else {
+        for (int r = NB - 1; r >= 0; --r) {
+            if (t == r) y[r] /= A[(k0 + r) * ld + k0 + r];
+            __syncthreads();
+            if (t < r) y[t] -= A[(k0 + r) * ld + k0 + t] * y[r];
+            __syncthreads();
+        }
+    }
+    b[k0 + t] = y[t];
+}
+
+// forward: b_i -= L_ik y_k for rows i behind block k; backward (transpose): b_i -= L_ki^T y_k for rows before
+__global__ void __launch_bounds__(256) k_solve_update(const double *__restrict__ A, int64_t ld, int64_t k0, int64_t n,
+                                                      double *__restrict__ b, int transpose) {
+    __shared__ double y[NB];
+    if (threadIdx.x < NB) y[threadIdx.x] = b[k0 + threadIdx.x];
+    __syncthreads();
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (!transpose) {
+        const int64_t i = k0 + NB + row;
+        if (i >= n) return;
+        double s = 0.0;
+        for (int c = 0; c < NB; ++c) s += A[i * ld + k0 + c] * y[c];
+        b[i] -= s;
+    } else {
+        const int64_t i = row;
+        if (i >= k0) return;
+        double s = 0.0;
+        for (int c = 0; c < NB; ++c) s += A[(k0 + c) * ld + i] * y[c];
+        b[i] -= s;
+    }
+}
+
+static int cdiv_i(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+}  // namespace ba
+
+using namespace ba;
+
+extern "C" {
+
+int ba_schur_dim(int64_t K, int64_t *n, int64_t *ld) {
+    BA_REQUIRE(K > 0 && n && ld, "ba_schur_dim: bad argument");
+    *n = 6 * K + 1;
+    *ld = ((*n + NB - 1) / NB) * NB;
+    return BA_OK;
+}
+
+int ba_eval_jtj(ba_problem *p, const double *X, const double *C, const double *Theta, const double *phi, int flags,
+                double *E_sum, double *gX, double *gC, double *gTheta, double *gphi, double *V, double *Xphi, double *B,
+                double *bphi, double *hphi, void *stream) {
+    BA_REQUIRE(p && X && C && Theta && phi, "ba_eval_jtj: null pointer");
+    BA_REQUIRE(E_sum && gX && gC && gTheta && gphi && V && Xphi && B && bphi && hphi, "ba_eval_jtj: null output");
+    if (!p->tiled) {
+        set_error("ba_eval_jtj: the scene has no LDS tiles (camera lists too long for a workgroup)");
+        return BA_ERR_STATE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t K = p->K;
+    const size_t lds = sizeof(double) * ((size_t)(ROW_LDS + CAMV) * p->cam_cap + (size_t)(3 + PTV) * p->pt_cap);
+    if (lds > 160 * 1024 - 256) {
+        set_error("ba_eval_jtj: tile accumulators exceed the LDS of a workgroup");
+        return BA_ERR_STATE;
+    }
+    if (!p->cam_sums_jtj) BA_HIP(hipMalloc(&p->cam_sums_jtj, sizeof(double) * CAMV * K));
+    if (!p->partials_jtj) BA_HIP(hipMalloc(&p->partials_jtj, sizeof(double) * 3 * (size_t)p->n_tiles));
+    if (!(flags & BA_EVAL_REUSE_TABLE))
+        if (int rc = camera_table(p, C, Theta, phi, st)) return rc;
+    BA_HIP(hipMemsetAsync(p->cam_sums_jtj, 0, sizeof(double) * CAMV * K, st));
+    JtjArgs a;
+    a.opack = p->opack;
+    a.ouv = p->ouv;
+    a.meta = (const TileMeta *)p->tile_meta;
+    a.cam_list = p->cam_list;
+    a.K = (int)K;
+    a.cam_cap = p->cam_cap;
+    a.pt_cap = p->pt_cap;
+    a.X = X;
+    a.T = p->cam_table;
+    a.scalars = p->scalars;
+    a.gX = gX;
+    a.V = V;
+    a.Xphi = Xphi;
+    a.cam_sums = p->cam_sums_jtj;
+    a.partials = p->partials_jtj;
+    if (lds > 64 * 1024)
+        BA_HIP(hipFuncSetAttribute((const void *)k_jtj_tiled, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const bool timed = (flags & BA_EVAL_TIMED) != 0 && p->ev_count < TIMING_RING;
+    if (timed) BA_HIP(hipEventRecord(p->ev_begin[p->ev_count], st));
+    hipLaunchKernelGGL(k_jtj_tiled, dim3(p->n_tiles), dim3(TILE_BLOCK), lds, st, a);
+    BA_HIP(hipGetLastError());
+    if (timed) {
+        BA_HIP(hipEventRecord(p->ev_end[p->ev_count], st));
+        p->ev_count++;
+    }
+    hipLaunchKernelGGL(k_jtj_finalize, dim3(cdiv_i(K, 256)), dim3(256), 0, st, K, p->n_tiles, p->partials_jtj,
+                       p->cam_sums_jtj, p->cam_table, p->scalars, E_sum, gphi, hphi, gC, gTheta, B, bphi);
+    BA_HIP(hipGetLastError());
+    return BA_OK;
+}
+
+static int ensure_row_ptr(ba_problem *p) {
+    if (p->row_ptr) return BA_OK;
+    BA_HIP(hipMalloc(&p->row_ptr, sizeof(int64_t) * (p->N + 1)));
+    hipLaunchKernelGGL(k_row_ptr, dim3(cdiv_i(p->nV + 1, 256)), dim3(256), 0, 0, p->oi, p->nV, p->N, p->row_ptr);
+    int *dmax = p->flag + 3;
+    BA_HIP(hipMemset(dmax, 0, sizeof(int)));
+    hipLaunchKernelGGL(k_max_degree, dim3(cdiv_i(p->N, 256)), dim3(256), 0, 0, p->row_ptr, p->N, dmax);
+    BA_HIP(hipGetLastError());
+    BA_HIP(hipMemcpy(&p->max_degree, dmax, sizeof(int), hipMemcpyDeviceToHost));
+    return BA_OK;
+}
+
+int ba_schur_build(ba_problem *p, const double *X, double lambda, const double *V, const double *Xphi, const double *gX,
+                   const double *B, const double *bphi, const double *hphi, const double *gC, const double *gTheta,
+                   const double *gphi, double *S, double *rhs, void *stream) {
+    BA_REQUIRE(p && X && V && Xphi && gX && B && bphi && hphi && gC && gTheta && gphi && S && rhs,
+               "ba_schur_build: null pointer");
+    if (int rc = ensure_row_ptr(p)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    int64_t n, ld;
+    ba_schur_dim(p->K, &n, &ld);
+    const size_t lds = (size_t)4 * p->max_degree * 37 * sizeof(double);
+    if (lds > 160 * 1024 - 256) {
+        set_error("ba_schur_build: a point has too many observations for the Schur kernel");
+        return BA_ERR_STATE;
+    }
+    BA_HIP(hipMemsetAsync(S, 0, sizeof(double) * ld * ld, st));
+    hipLaunchKernelGGL(k_schur_init, dim3(cdiv_i(p->K, 256)), dim3(256), 0, st, p->K, n, ld, lambda, B, bphi, hphi, gC,
+                       gTheta, gphi, S, rhs);
+    SchurArgs a;
+    a.oj = p->oj;
+    a.ouv = p->ouv;
+    a.row_ptr = p->row_ptr;
+    a.N = p->N;
+    a.K = p->K;
+    a.ld = ld;
+    a.lambda = lambda;
+    a.X = X;
+    a.T = p->cam_table;
+    a.scalars = p->scalars;
+    a.V = V;
+    a.Xphi = Xphi;
+    a.gX = gX;
+    a.S = S;
+    a.rhs = rhs;
+    a.max_deg = p->max_degree;
+    if (lds > 64 * 1024)
+        BA_HIP(hipFuncSetAttribute((const void *)k_schur_points, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_schur_points, dim3(cdiv_i(p->N, 4)), dim3(256), lds, st, a);
+    BA_HIP(hipGetLastError());
+    return BA_OK;
+}
+
+int ba_cholesky_solve(int64_t n, int64_t ld, double *S, double *rhs, int *h_info, void *stream) {
+    BA_REQUIRE(S && rhs && n > 0 && ld >= n && ld % NB == 0, "ba_cholesky_solve: bad argument (ld must be a multiple of 64)");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t nb = ld / NB;
+    double *Linv = nullptr;
+    int *info = nullptr;
+    BA_HIP(hipMalloc(&Linv, sizeof(double) * NB * NB));
+    BA_HIP(hipMalloc(&info, sizeof(int)));
+    BA_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
+    for (int64_t k = 0; k < nb; ++k) {
+        const int64_t k0 = k * NB, behind = nb - k - 1;
+        hipLaunchKernelGGL(k_potrf, dim3(1), dim3(256), 0, st, S, ld, k0, Linv, info);
+        if (behind > 0) {
+            hipLaunchKernelGGL(k_trsm, dim3((int)behind), dim3(64), 0, st, S, ld, k0, Linv, ld);
+            const int64_t tiles = behind * (behind + 1) / 2;
+            hipLaunchKernelGGL(k_syrk, dim3(cdiv_i(tiles, 4)), dim3(256), 0, st, S, ld, k0, behind, tiles);
+        }
+    }
+    for (int64_t k = 0; k < nb; ++k) {  // L y = b
+        hipLaunchKernelGGL(k_solve_diag, dim3(1), dim3(64), 0, st, S, ld, k * NB, rhs, 0);
+        if (k + 1 < nb)
+            hipLaunchKernelGGL(k_solve_update, dim3(cdiv_i(ld - (k + 1) * NB, 256)), dim3(256), 0, st, S, ld, k * NB, ld,
+                               rhs, 0);
+    }
+    for (int64_t k = nb - 1; k >= 0; --k) {  // L^T x = y
+        hipLaunchKernelGGL(k_solve_diag, dim3(1), dim3(64), 0, st, S, ld, k * NB, rhs, 1);
+        if (k > 0) hipLaunchKernelGGL(k_solve_update, dim3(cdiv_i(k * NB, 256)), dim3(256), 0, st, S, ld, k * NB, ld, rhs, 1);
+    }
+    hipError_t e = hipGetLastError();
+    int hinfo = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    hipFree(Linv);
+    hipFree(info);
+    BA_HIP(e);
+    if (h_info) *h_info = hinfo;
+    if (hinfo != 0) {
+        set_error("ba_cholesky_solve: matrix is not positive definite (pivot " + std::to_string(hinfo) + ")");
+        return BA_ERR_NUMERIC;
+    }
+    return BA_OK;
+}
+
+int ba_backsubstitute(ba_problem *p, const double *X, double lambda, const double *V, const double *Xphi,
+                      const double *gX, const double *d, double *dcam_packed, double *dX, void *stream) {
+    BA_REQUIRE(p && X && V && Xphi && gX && d && dX, "ba_backsubstitute: null pointer");
+    if (int rc = ensure_row_ptr(p)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    BacksubArgs a;
+    a.oj = p->oj;
+    a.ouv = p->ouv;
+    a.row_ptr = p->row_ptr;
+    a.N = p->N;
+    a.K = p->K;
+    a.lambda = lambda;
+    a.X = X;
+    a.T = p->cam_table;
+    a.scalars = p->scalars;
+    a.V = V;
+    a.Xphi = Xphi;
+    a.gX = gX;
+    a.d = d;
+    a.dX = dX;
+    hipLaunchKernelGGL(k_backsub, dim3(cdiv_i(p->N, 256)), dim3(256), 0, st, a);
+    if (dcam_packed)
+        hipLaunchKernelGGL(k_unpack_solution, dim3(cdiv_i(6 * p->K + 1, 256)), dim3(256), 0, st, p->K, d, dcam_packed);
+    BA_HIP(hipGetLastError());
+    return BA_OK;
+}
+
+}  // extern "C"

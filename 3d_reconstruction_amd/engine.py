@@ -154,7 +154,7 @@ class Shard:
         with torch.cuda.device(self.device):
             check(self.lib.ba_eval(self.handle, ptr(self.X), ptr(self.C), ptr(self.Theta), ptr(self.phi), flags,
                                    ptr(self.E_sum), ptr(self.gX), ptr(self.gC), ptr(self.gTheta), ptr(self.gphi),
-                                   None, None, None, None, stream_ptr()))
+                                   stream_ptr()))
         self.table_valid = True
         allreduce_sum_(self.red, self.group)
 
@@ -209,6 +209,47 @@ class Shard:
                                               ptr(rel_x) if x_free else None, rule if x_free else 0, float(lr), gs,
                                               float(bc1), float(bc2), ptr(self.gauge) if gauge else None,
                                               stream_ptr()))
+
+
+    # ---- second-order extension (no reference counterpart) ---------------------------------------
+    def _lm_buffers(self):
+        if not hasattr(self, 'V'):
+            z = lambda *s: torch.zeros(*s, dtype=F64, device=self.device)
+            n, ld = C.c_int64(0), C.c_int64(0)
+            check(self.lib.ba_schur_dim(self.K, C.byref(n), C.byref(ld)))
+            self.n_red, self.ld_red = int(n.value), int(ld.value)
+            self.V, self.Xphi = z(self.N, 6), z(self.N, 3)
+            self.B, self.bphi, self.hphi = z(self.K, 21), z(self.K, 6), z(1)
+            self.S, self.rhs = z(self.ld_red, self.ld_red), z(self.ld_red)
+            self.dX, self.dcam = z(self.N, 3), z(6 * self.K + 1)
+
+    def eval_jtj(self, timed=False):
+        """Fused pass that also leaves the Gauss-Newton blocks V, Xphi, B, bphi, hphi."""
+        self._lm_buffers()
+        flags = (_lib.EVAL_TIMED if timed else 0) | (_lib.EVAL_REUSE_TABLE if self.table_valid else 0)
+        with torch.cuda.device(self.device):
+            check(self.lib.ba_eval_jtj(self.handle, ptr(self.X), ptr(self.C), ptr(self.Theta), ptr(self.phi), flags,
+                                       ptr(self.E_sum), ptr(self.gX), ptr(self.gC), ptr(self.gTheta), ptr(self.gphi),
+                                       ptr(self.V), ptr(self.Xphi), ptr(self.B), ptr(self.bphi), ptr(self.hphi),
+                                       stream_ptr()))
+        self.table_valid = True
+
+    def lm_step(self, lam):
+        """Solve the damped normal equations (J^T J + lam diag) d = -J^T r by Schur complement and
+        dense Cholesky; leaves dX and dcam = [dC | dTheta | dphi].  Returns the pivot info (0 = ok)."""
+        info = C.c_int(0)
+        with torch.cuda.device(self.device):
+            check(self.lib.ba_schur_build(self.handle, ptr(self.X), float(lam), ptr(self.V), ptr(self.Xphi),
+                                          ptr(self.gX), ptr(self.B), ptr(self.bphi), ptr(self.hphi), ptr(self.gC),
+                                          ptr(self.gTheta), ptr(self.gphi), ptr(self.S), ptr(self.rhs), stream_ptr()))
+            status = self.lib.ba_cholesky_solve(self.n_red, self.ld_red, ptr(self.S), ptr(self.rhs), C.byref(info),
+                                                stream_ptr())
+            if status == -4:
+                return int(info.value)
+            check(status)
+            check(self.lib.ba_backsubstitute(self.handle, ptr(self.X), float(lam), ptr(self.V), ptr(self.Xphi),
+                                             ptr(self.gX), ptr(self.rhs), ptr(self.dcam), ptr(self.dX), stream_ptr()))
+        return 0
 
 
 def project(X, C_, Theta, phi_x, W, H, i=None, j=None, delete_back_points=True, delete_boundary_points=False,

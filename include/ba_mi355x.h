@@ -40,7 +40,6 @@ enum ba_eval_flags {
     BA_EVAL_GRAD_X = 1,     /* write gX                     (p2w:661-662) */
     BA_EVAL_GRAD_CAM = 2,   /* write gC, gTheta             (p2w:664-698) */
     BA_EVAL_GRAD_PHI = 4,   /* write gphi                   (p2w:700-702) */
-    BA_EVAL_JTJ = 8,        /* also write V, B, bphi, hphi (Gauss-Newton blocks; no reference counterpart) */
     BA_EVAL_CAM_ATOMICS = 16, /* force the global-atomic camera reduction (default: LDS-private when it fits) */
     BA_EVAL_TIMED = 32,     /* record HIP events around the observation-pass kernel (see ba_eval_timing) */
     BA_EVAL_DEBUG_MASK = 64 | 128 | 256, /* diagnostics only: skip parts of the pass (results are wrong) */
@@ -77,13 +76,9 @@ int ba_problem_destroy(ba_problem *p);
  *   X[N][3], C[K][3], Theta[K][3] (columns theta_x, theta_y, theta_z), phi[1]
  *   E_sum[1]  : sum of squared residuals (E = E_sum / (2|V|))
  *   gX[N][3], gC[K][3], gTheta[K][3], gphi[1] : un-normalised gradients (multiply by 1/|V|)
- *   with BA_EVAL_JTJ: V[N][6] (upper triangle of sum J_X^T J_X per point, order xx,xy,xz,yy,yz,zz),
- *   B[K][21] (upper triangle, row-major, of the 6x6 block over (C,Theta) per camera),
- *   bphi[K][6] (cross term camera x phi_x), hphi[1] (phi_x x phi_x).
  * Outputs not selected by `flags` may be NULL. */
 int ba_eval(ba_problem *p, const double *X, const double *C, const double *Theta, const double *phi,
-            int flags, double *E_sum, double *gX, double *gC, double *gTheta, double *gphi,
-            double *V, double *B, double *bphi, double *hphi, void *stream);
+            int flags, double *E_sum, double *gX, double *gC, double *gTheta, double *gphi, void *stream);
 
 /* Durations in milliseconds of the observation-pass kernel of the ba_eval calls made with
  * BA_EVAL_TIMED since the last call of this function (at most 256 are kept), measured with HIP
@@ -122,6 +117,33 @@ int ba_camera_step(ba_problem *p, double *cam, const double *g, double *s, doubl
 int ba_points_step(int64_t N, double *X, const double *gX, double *s, double *r, double *release,
                    int rule, double lr, double gscale, double bc1, double bc2, const double *gauge,
                    void *stream);
+
+/* ---- second-order extension: NO counterpart in the reference (its optimiser is first-order, p2w:336-362).
+ * Gauss-Newton / Levenberg-Marquardt on the same energy.  All quantities un-normalised (J^T J, J^T r).
+ * ba_eval_jtj: the fused pass of ba_eval plus the blocks of J^T J:
+ *   V[N][6]    upper triangle (xx,xy,xz,yy,yz,zz) of sum J_X^T J_X per point
+ *   Xphi[N][3] point x phi_x column,  B[K][21] upper triangle (row-major) of the 6x6 block over
+ *   (C, Theta) per camera,  bphi[K][6] camera x phi_x column,  hphi[1].
+ * ba_schur_dim: n = 6K+1 unknowns of the reduced camera system, ld = n rounded up to 64.
+ * ba_schur_build: S (ld x ld, row-major, lower triangle valid) and rhs (ld) of
+ *   (D' - Y^T V'^-1 Y) d = -g_cam + Y^T V'^-1 g_X, primes = diagonal scaled by (1 + lambda);
+ *   unknown order: camera j at 6j..6j+5 (C then Theta), phi_x at 6K.  Uses the camera table left by
+ *   the last ba_eval_jtj.
+ * ba_cholesky_solve: blocked Cholesky of S in place (trailing update on the fp64 matrix cores) and
+ *   solution of S d = rhs in place; *h_info = 0 or 1 + index of the first non-positive pivot.
+ * ba_backsubstitute: dX[N][3] = V'^-1 (-g_X - W d_cam - Xphi d_phi); dcam_packed (optional, 6K+1)
+ *   receives d reordered to [dC (3K) | dTheta (3K) | dphi]. */
+int ba_eval_jtj(ba_problem *p, const double *X, const double *C, const double *Theta, const double *phi,
+                int flags, double *E_sum, double *gX, double *gC, double *gTheta, double *gphi,
+                double *V, double *Xphi, double *B, double *bphi, double *hphi, void *stream);
+int ba_schur_dim(int64_t K, int64_t *n, int64_t *ld);
+int ba_schur_build(ba_problem *p, const double *X, double lambda, const double *V, const double *Xphi,
+                   const double *gX, const double *B, const double *bphi, const double *hphi,
+                   const double *gC, const double *gTheta, const double *gphi, double *S, double *rhs,
+                   void *stream);
+int ba_cholesky_solve(int64_t n, int64_t ld, double *S, double *rhs, int *h_info, void *stream);
+int ba_backsubstitute(ba_problem *p, const double *X, double lambda, const double *V, const double *Xphi,
+                      const double *gX, const double *d, double *dcam_packed, double *dX, void *stream);
 
 /* ---- transform (p2w:192-216) on a list of pairs: model pixels out[n][2], NaN behind the camera
  * (delete_back_points) and optionally outside [0,W)x[0,H) (delete_boundary_points).

@@ -14,7 +14,7 @@ def run(extra, name, reps=20):
     p = _lib.ptr
     for _ in range(reps+3):
         flags = 1|2|4|32|extra
-        _lib.check(lib.ba_eval(sh.handle, p(sh.X), p(sh.C), p(sh.Theta), p(sh.phi), flags, p(sh.E_sum), p(sh.gX), p(sh.gC), p(sh.gTheta), p(sh.gphi), None, None, None, None, _lib.stream_ptr()))
+        _lib.check(lib.ba_eval(sh.handle, p(sh.X), p(sh.C), p(sh.Theta), p(sh.phi), flags, p(sh.E_sum), p(sh.gX), p(sh.gC), p(sh.gTheta), p(sh.gphi), _lib.stream_ptr()))
     torch.cuda.synchronize()
     ms = sh.eval_kernel_ms()[3:]
     m = float(np.median(ms))

@@ -21,7 +21,7 @@ def bench(i, j, uv, X, tag):
     p = _lib.ptr
     for extra, name in [(0,'tiled'), (64,'tiled skip cam'), (128,'tiled skip pt'), (192,'tiled skip both'), (512,'untiled')]:
         for _ in range(23):
-            _lib.check(sh.lib.ba_eval(sh.handle, p(sh.X), p(sh.C), p(sh.Theta), p(sh.phi), 1|2|4|32|extra, p(sh.E_sum), p(sh.gX), p(sh.gC), p(sh.gTheta), p(sh.gphi), None, None, None, None, _lib.stream_ptr()))
+            _lib.check(sh.lib.ba_eval(sh.handle, p(sh.X), p(sh.C), p(sh.Theta), p(sh.phi), 1|2|4|32|extra, p(sh.E_sum), p(sh.gX), p(sh.gC), p(sh.gTheta), p(sh.gphi), _lib.stream_ptr()))
         torch.cuda.synchronize()
         ms = sh.eval_kernel_ms()[3:]
         m = float(np.median(ms))

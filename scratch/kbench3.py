@@ -20,7 +20,7 @@ def bench(tag, variants=((0,'full'),(192,'skip both'))):
     sh.set_params(X2, sc['C_0'], sc['Theta_0'], sc['phi_x_0'])
     for extra, name in variants:
         for _ in range(23):
-            _lib.check(sh.lib.ba_eval(sh.handle, p(sh.X), p(sh.C), p(sh.Theta), p(sh.phi), 1|2|4|32|extra, p(sh.E_sum), p(sh.gX), p(sh.gC), p(sh.gTheta), p(sh.gphi), None, None, None, None, _lib.stream_ptr()))
+            _lib.check(sh.lib.ba_eval(sh.handle, p(sh.X), p(sh.C), p(sh.Theta), p(sh.phi), 1|2|4|32|extra, p(sh.E_sum), p(sh.gX), p(sh.gC), p(sh.gTheta), p(sh.gphi), _lib.stream_ptr()))
         torch.cuda.synchronize()
         ms = sh.eval_kernel_ms()[3:]
         m = float(np.median(ms))

@@ -1,0 +1,99 @@
+"""Second-order extension (J^T J blocks, Schur complement, fp64 Cholesky, LM step).  The reference
+has no such solver: these results are pinned by this repository's own dense normal equations
+(oracle.dense_jacobian) on small scenes — "parity unpinned" with respect to the reference."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import ba_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _scene(ba, N=300, K=14, seed=4):
+    sc = ba.scenes.orbit_scene(N=N, K=K, track_len=6, seed=seed)
+    sh = ba.engine.Shard(sc['i'], sc['j'], sc['uv'], sc['N_local'], K, sc['W'], sc['H'], DEV)
+    sh.set_params(sc['X_0'], sc['C_0'], sc['Theta_0'], sc['phi_x_0'])
+    r, J = orc.dense_jacobian(sc['X_0'], sc['C_0'], sc['Theta_0'], sc['phi_x_0'], sc['W'], sc['H'], sc['i'],
+                              sc['j'], sc['uv'])
+    return sc, sh, r, J
+
+
+def test_jtj_blocks_match_dense_normal_equations(ba):
+    sc, sh, r, J = _scene(ba)
+    N, K = sc['N_local'], sc['K']
+    sh.eval_jtj()
+    H, g = J.T @ J, J.T @ r
+    back = lambda t: sh.points_to_caller(t).cpu().numpy()
+    assert abs(float(sh.E_sum.item()) - r @ r) / (r @ r) < 1e-12
+    assert rel_err(back(sh.gX).ravel(), g[:3 * N]) < 1e-10
+    assert rel_err(sh.gC.cpu().numpy().ravel(), g[3 * N:3 * N + 3 * K]) < 1e-10
+    assert rel_err(sh.gTheta.cpu().numpy().ravel(), g[3 * N + 3 * K:3 * N + 6 * K]) < 1e-10
+    assert abs(float(sh.gphi.item()) - g[-1]) < 1e-10 * abs(g[-1])
+    V = back(sh.V)
+    iu = np.triu_indices(3)
+    V_ref = np.array([H[3 * i:3 * i + 3, 3 * i:3 * i + 3][iu] for i in range(N)])
+    assert rel_err(V, V_ref) < 1e-10
+    assert rel_err(back(sh.Xphi), H[:3 * N, -1].reshape(N, 3)) < 1e-10
+    iu6 = np.triu_indices(6)
+    B_ref = np.zeros((K, 21))
+    b_ref = np.zeros((K, 6))
+    for j in range(K):
+        idx = np.r_[3 * N + 3 * j + np.arange(3), 3 * N + 3 * K + 3 * j + np.arange(3)]
+        B_ref[j] = H[np.ix_(idx, idx)][iu6]
+        b_ref[j] = H[idx, -1]
+    assert rel_err(sh.B.cpu().numpy(), B_ref) < 1e-10
+    assert rel_err(sh.bphi.cpu().numpy(), b_ref) < 1e-10
+    assert abs(float(sh.hphi.item()) - H[-1, -1]) < 1e-10 * H[-1, -1]
+    sh.close()
+
+
+def test_cholesky_solve_random_spd(ba):
+    lib = ba.engine._lib.load()
+    import ctypes as C
+    rng = np.random.default_rng(0)
+    for n in (64, 200, 1000):
+        ld = (n + 63) // 64 * 64
+        A = rng.normal(size=(n, 2 * n))
+        S = A @ A.T + n * np.eye(n)
+        b = rng.normal(size=n)
+        Sp = np.eye(ld)
+        Sp[:n, :n] = S
+        Sp[np.triu_indices(ld, 1)] = np.nan          # the factorisation must never read the upper triangle
+        Sd = torch.from_numpy(Sp).to(DEV)
+        bd = torch.zeros(ld, dtype=torch.float64, device=DEV)
+        bd[:n] = torch.from_numpy(b)
+        info = C.c_int(7)
+        ba.engine.check(lib.ba_cholesky_solve(n, ld, C.c_void_p(Sd.data_ptr()), C.c_void_p(bd.data_ptr()),
+                                              C.byref(info), None))
+        assert info.value == 0
+        x = bd.cpu().numpy()[:n]
+        assert rel_err(x, np.linalg.solve(S, b)) < 1e-10
+        L = np.tril(Sd.cpu().numpy()[:n, :n])
+        assert rel_err(L, np.linalg.cholesky(S)) < 1e-11
+    # not positive definite -> pivot reported
+    Sbad = -np.eye(64)
+    Sd = torch.from_numpy(Sbad).to(DEV)
+    bd = torch.zeros(64, dtype=torch.float64, device=DEV)
+    info = C.c_int(0)
+    assert lib.ba_cholesky_solve(64, 64, C.c_void_p(Sd.data_ptr()), C.c_void_p(bd.data_ptr()), C.byref(info), None) == -4
+    assert info.value == 1
+
+
+def test_lm_step_matches_dense_solve(ba):
+    sc, sh, r, J = _scene(ba, N=250, K=10, seed=9)
+    N, K = sc['N_local'], sc['K']
+    lam = 1e-2
+    sh.eval_jtj()
+    assert sh.lm_step(lam) == 0
+    H, g = J.T @ J, J.T @ r
+    d = np.linalg.solve(H + lam * np.diag(np.diag(H)), -g)
+    dX = sh.points_to_caller(sh.dX).cpu().numpy().ravel()
+    dcam = sh.dcam.cpu().numpy()
+    assert rel_err(dcam, d[3 * N:]) < 1e-7
+    assert rel_err(dX, d[:3 * N]) < 1e-7
+    sh.close()
