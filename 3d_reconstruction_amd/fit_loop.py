@@ -15,6 +15,9 @@ RHO_1, RHO_2 = 0.9, 0.999      # p2w:351-352
 # the values name the device update rule the shard runs.
 gd_func_dict = {'SGD': 'ba_sgd_step', 'Adam': 'ba_adam_step'}
 
+# optimisers beyond the reference's registry, accepted by fit_scene(optimizer=...)
+extra_optimizers = {'LM': 'Levenberg-Marquardt with Schur complement (lm.LMFit)'}
+
 
 class SceneFit:
     """One `fit_scene` run as an object: `step()` executes one pass of the loop body and

@@ -16,7 +16,8 @@ import numpy as np
 import torch
 
 from . import engine
-from .fit_loop import SceneFit, gd_func_dict  # noqa: F401  (gd_func_dict re-exported)
+from .fit_loop import SceneFit, extra_optimizers, gd_func_dict  # noqa: F401  (gd_func_dict re-exported)
+from .lm import LMFit
 from .sharding import partition_points, connected_components_count
 
 __all__ = ['fit_scene', 'fit_scene_sparse', 'transform', 'error', 'validate_scene_parameters', 'gd_func_dict']
@@ -175,8 +176,10 @@ def fit_scene_sparse(i, j, uv, N, K, W, H, lr, max_iters, X_0, C_0, Theta_0, phi
     check_solvable(nV, N, K, X_mask, C_Theta_mask, phi_x_mask)
     if X_mask and C_Theta_mask and check_connectivity:
         check_connected(i_t.cpu().numpy(), j_t.cpu().numpy(), N, K)
-    if optimizer not in gd_func_dict:
+    if optimizer not in gd_func_dict and optimizer not in extra_optimizers:
         raise ValueError(f'Unkown name of the optmizer, choose one from {[key for key in gd_func_dict]}')
+    if optimizer == 'LM' and not (X_mask and C_Theta_mask and phi_x_mask):
+        raise ValueError("optimizer='LM' needs X_mask, C_Theta_mask and phi_x_mask to be true")
 
     world = torch.distributed.get_world_size() if (torch.distributed.is_available()
                                                    and torch.distributed.is_initialized()) else 1
@@ -197,8 +200,14 @@ def fit_scene_sparse(i, j, uv, N, K, W, H, lr, max_iters, X_0, C_0, Theta_0, phi
         shard = engine.Shard(i_t, j_t, uv_t, N, K, W, H, dev)
         shard.set_params(X_0, C_0, Theta_0, phi_x_0)
     try:
-        fit = SceneFit(shard, lr, max_iters, X_mask, C_Theta_mask, phi_x_mask, optimizer, patience, factor,
-                       stop_value, stop_diff, print_step, ret_all_iters)
+        if optimizer == 'LM':
+            if world > 1:
+                raise ValueError("optimizer='LM' runs on one GPU")
+            fit = LMFit(shard, max_iters, lam=lr, stop_value=stop_value, stop_diff=stop_diff, print_step=print_step)
+            fit.ret_all_iters = False
+        else:
+            fit = SceneFit(shard, lr, max_iters, X_mask, C_Theta_mask, phi_x_mask, optimizer, patience, factor,
+                           stop_value, stop_diff, print_step, ret_all_iters)
         fit.run()
         return _pack_results(fit, shard, (X_mask, C_Theta_mask, phi_x_mask), gather_X)
     finally:

@@ -14,8 +14,9 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 
-def _scene(ba, N=300, K=14, seed=4):
-    sc = ba.scenes.orbit_scene(N=N, K=K, track_len=6, seed=seed)
+def _scene(ba, N=300, K=80, seed=4):
+    sc = ba.scenes.orbit_scene(N=N, K=K, track_len=8, seed=seed)
+    assert sc['i'].size > 4 * N
     sh = ba.engine.Shard(sc['i'], sc['j'], sc['uv'], sc['N_local'], K, sc['W'], sc['H'], DEV)
     sh.set_params(sc['X_0'], sc['C_0'], sc['Theta_0'], sc['phi_x_0'])
     r, J = orc.dense_jacobian(sc['X_0'], sc['C_0'], sc['Theta_0'], sc['phi_x_0'], sc['W'], sc['H'], sc['i'],
@@ -85,7 +86,7 @@ def test_cholesky_solve_random_spd(ba):
 
 
 def test_lm_step_matches_dense_solve(ba):
-    sc, sh, r, J = _scene(ba, N=250, K=10, seed=9)
+    sc, sh, r, J = _scene(ba, N=250, K=60, seed=9)
     N, K = sc['N_local'], sc['K']
     lam = 1e-2
     sh.eval_jtj()
@@ -97,3 +98,50 @@ def test_lm_step_matches_dense_solve(ba):
     assert rel_err(dcam, d[3 * N:]) < 1e-7
     assert rel_err(dX, d[:3 * N]) < 1e-7
     sh.close()
+
+
+def _numpy_lm(sc, iters, lam):
+    """The same LM loop with dense NumPy normal equations (reference for the trajectory)."""
+    X, C, Th = orc.align_scene(sc['X_0'], sc['C_0'], Theta=sc['Theta_0'])
+    X, C = orc.normalize_scene(X, C)
+    phi = sc['phi_x_0']
+    N, K = X.shape[0], C.shape[0]
+    args = (sc['W'], sc['H'], sc['i'], sc['j'], sc['uv'])
+    r, J = orc.dense_jacobian(X, C, Th, phi, *args)
+    E = [r @ r / (2 * r.size / 2)]
+    for _ in range(iters):
+        H, g = J.T @ J, J.T @ r
+        d = np.linalg.solve(H + lam * np.diag(np.diag(H)), -g)
+        Xn = X + d[:3 * N].reshape(N, 3)
+        Cn = C + d[3 * N:3 * N + 3 * K].reshape(K, 3)
+        Tn = Th + d[3 * N + 3 * K:3 * N + 6 * K].reshape(K, 3)
+        pn = phi + d[-1]
+        Xn, Cn, Tn = orc.align_scene(Xn, Cn, Theta=Tn)
+        Xn, Cn = orc.normalize_scene(Xn, Cn)
+        rn, Jn = orc.dense_jacobian(Xn, Cn, Tn, pn, *args)
+        En = rn @ rn / (2 * rn.size / 2)
+        if En < E[-1]:
+            X, C, Th, phi, r, J = Xn, Cn, Tn, pn, rn, Jn
+            E.append(En)
+            lam = max(lam / 3.0, 1e-12)
+        else:
+            E.append(E[-1])
+            lam *= 4.0
+    return X, C, Th, phi, np.array(E)
+
+
+def test_fit_scene_lm_converges_like_dense_lm(ba):
+    sc = ba.scenes.orbit_scene(N=300, K=80, track_len=8, seed=4)
+    assert sc['i'].size > 1500
+    out = ba.fit_scene_sparse(sc['i'], sc['j'], sc['uv'], sc['N_local'], sc['K'], sc['W'], sc['H'], 1e-3, 9,
+                              sc['X_0'], sc['C_0'], sc['Theta_0'], sc['phi_x_0'], optimizer='LM', print_step=10 ** 9)
+    X, C, Th, phi, E = out
+    Xr, Cr, Tr, pr, Er = _numpy_lm(sc, 8, 1e-3)
+    assert E.shape == Er.shape
+    assert rel_err(E, Er) < 1e-6
+    assert E[-1] < 0.2 and E[-1] < 1e-2 * E[0]          # from the noisy start down to the pixel-quantisation floor
+    assert np.abs(X - Xr).max() < 1e-6 and np.abs(C - Cr).max() < 1e-6
+    assert np.abs(Th - Tr).max() < 1e-6 and abs(phi - pr) < 1e-6
+    with pytest.raises(ValueError, match="optimizer='LM' needs"):
+        ba.fit_scene_sparse(sc['i'], sc['j'], sc['uv'], sc['N_local'], sc['K'], sc['W'], sc['H'], 1e-3, 5, sc['X_0'],
+                            sc['C_0'], sc['Theta_0'], sc['phi_x_0'], optimizer='LM', phi_x_mask=False)
