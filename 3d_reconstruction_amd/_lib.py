@@ -38,6 +38,7 @@ SIGNATURES = {
     'ba_schur_build': (_int, [_p, _p, _dbl] + [_p] * 12),
     'ba_cholesky_solve': (_int, [_i64, _i64, _p, _p, C.POINTER(_int), _p]),
     'ba_backsubstitute': (_int, [_p, _p, _dbl, _p, _p, _p, _p, _p, _p, _p]),
+    'ba_fetch_double': (_int, [_p, C.POINTER(_dbl), _p]),
     'ba_eval_timing': (_int, [_p, C.POINTER(C.c_float), _int, C.POINTER(_int)]),
     'ba_adam_step': (_int, [_i64, _p, _p, _p, _p, _dbl, _dbl, _dbl, _dbl, _p, _p]),
     'ba_sgd_step': (_int, [_i64, _p, _p, _dbl, _dbl, _p, _p]),

@@ -1870,6 +1870,14 @@ int ba_camera_step(ba_problem *p, double *cam, const double *g, double *s, doubl
     return BA_OK;
 }
 
+int ba_fetch_double(const double *src, double *h_out, void *stream) {
+    BA_REQUIRE(src && h_out, "ba_fetch_double: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    BA_HIP(hipMemcpyAsync(h_out, src, sizeof(double), hipMemcpyDeviceToHost, st));
+    BA_HIP(hipStreamSynchronize(st));
+    return BA_OK;
+}
+
 int ba_gauge_fix(int64_t N, int64_t K, double *X, double *C, double *Theta, double *R_out, double *gauge_out,
                  void *stream) {
     BA_REQUIRE(K >= 2, "ba_gauge_fix: needs at least two cameras");

@@ -87,6 +87,14 @@ class Shard:
         self.gauge = z(16)
         self.R_gauge = z(self.K, 9)
         self.table_valid = False    # the handle's camera table matches cam (see eval / step_update)
+        # hot-path plumbing: one device, one stream, pointers converted once
+        torch.cuda.set_device(self.device)
+        self.stream = stream_ptr()
+        self.distributed = torch.distributed.is_available() and torch.distributed.is_initialized() and \
+            torch.distributed.get_world_size(group) > 1
+        self._eval_args = None
+        self._E_ptr, self._E_host = ptr(self.E_sum), C.c_double(0.0)
+        self._step_cache = {}
 
     def close(self):
         if getattr(self, 'handle', None):
@@ -151,16 +159,19 @@ class Shard:
                 (_lib.EVAL_GRAD_PHI if grad_phi else 0) | (_lib.EVAL_TIMED if timed else 0) | \
                 (_lib.EVAL_CAM_ATOMICS if cam_atomics else 0) | (_lib.EVAL_UNTILED if untiled else 0) | \
                 (_lib.EVAL_REUSE_TABLE if self.table_valid else 0)
-        with torch.cuda.device(self.device):
-            check(self.lib.ba_eval(self.handle, ptr(self.X), ptr(self.C), ptr(self.Theta), ptr(self.phi), flags,
-                                   ptr(self.E_sum), ptr(self.gX), ptr(self.gC), ptr(self.gTheta), ptr(self.gphi),
-                                   stream_ptr()))
+        if self._eval_args is None:     # the buffers never move: convert the pointers once
+            self._eval_args = ([self.handle] + [ptr(t) for t in (self.X, self.C, self.Theta, self.phi)],
+                               [ptr(t) for t in (self.E_sum, self.gX, self.gC, self.gTheta, self.gphi)])
+        a, b = self._eval_args
+        check(self.lib.ba_eval(*a, flags, *b, self.stream))
         self.table_valid = True
-        allreduce_sum_(self.red, self.group)
+        if self.distributed:
+            allreduce_sum_(self.red, self.group)
 
     def energy(self):
         """E = sum r^2 / (2|V|) (p2w:612).  One 8-byte device-to-host copy (synchronises)."""
-        return float(self.E_sum.item()) / (2 * self.nV)
+        check(self.lib.ba_fetch_double(self._E_ptr, C.byref(self._E_host), self.stream))
+        return self._E_host.value / (2 * self.nV)
 
     def eval_kernel_ms(self):
         buf = (C.c_float * 256)()
@@ -193,23 +204,31 @@ class Shard:
         destinations or None (the old values are written there in the same pass).  cam_range =
         (lo, hi) slice of [C | Theta | phi_x] that is free, or None."""
         gs = 1.0 / self.nV
-        with torch.cuda.device(self.device):
+        key = (rule, x_free, cam_range, gauge, rel_x is not None, rel_cam is not None,
+               None if mom_x is None else mom_x[0].data_ptr(), None if mom_cam is None else mom_cam[0].data_ptr(),
+               None if rel_x is None else rel_x.data_ptr(), None if rel_cam is None else rel_cam.data_ptr())
+        plan = self._step_cache.get(key)
+        if plan is None:
+            cam_call = pts_call = None
             if cam_range is not None or gauge:
                 lo, hi = cam_range if cam_range is not None else (0, 0)
                 s_c, r_c = mom_cam if mom_cam is not None else (None, None)
                 # moment / snapshot tensors of the camera group cover the free slice only
                 off = lambda t: None if t is None else C.c_void_p(t.data_ptr() - 8 * lo)
-                check(self.lib.ba_camera_step(self.handle, ptr(self.cam), ptr(self.red), off(s_c), off(r_c),
-                                              off(rel_cam), lo, hi, rule, float(lr), gs, float(bc1), float(bc2),
-                                              int(bool(gauge)), ptr(self.R_gauge), ptr(self.gauge), stream_ptr()))
-                self.table_valid = True
+                cam_call = ([self.handle, ptr(self.cam), ptr(self.red), off(s_c), off(r_c), off(rel_cam), lo, hi, rule],
+                            [int(bool(gauge)), ptr(self.R_gauge), ptr(self.gauge)])
             if x_free or gauge:
                 s_x, r_x = mom_x if mom_x is not None else (None, None)
-                check(self.lib.ba_points_step(self.N, ptr(self.X), ptr(self.gX), ptr(s_x), ptr(r_x),
-                                              ptr(rel_x) if x_free else None, rule if x_free else 0, float(lr), gs,
-                                              float(bc1), float(bc2), ptr(self.gauge) if gauge else None,
-                                              stream_ptr()))
-
+                pts_call = ([self.N, ptr(self.X), ptr(self.gX), ptr(s_x), ptr(r_x), ptr(rel_x) if x_free else None,
+                             rule if x_free else 0], [ptr(self.gauge) if gauge else None])
+            plan = self._step_cache[key] = (cam_call, pts_call)
+        cam_call, pts_call = plan
+        lr, bc1, bc2 = float(lr), float(bc1), float(bc2)
+        if cam_call is not None:
+            check(self.lib.ba_camera_step(*cam_call[0], lr, gs, bc1, bc2, *cam_call[1], self.stream))
+            self.table_valid = True
+        if pts_call is not None:
+            check(self.lib.ba_points_step(*pts_call[0], lr, gs, bc1, bc2, *pts_call[1], self.stream))
 
     # ---- second-order extension (no reference counterpart) ---------------------------------------
     def _lm_buffers(self):

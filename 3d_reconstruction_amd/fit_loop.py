@@ -36,7 +36,8 @@ class SceneFit:
         self.stop_value, self.stop_diff, self.print_step = stop_value, stop_diff, print_step
         self.ret_all_iters = ret_all_iters
         self.print = printer
-        self.timed = False          # record HIP events around the observation-pass kernel
+        self.timed_every = 0        # record HIP events around the observation-pass kernel of every n-th pass
+        self._passes = 0
         self.gauge = self.masks[0] and self.masks[1]      # p2w:533, 710
 
         K6 = 6 * shard.K
@@ -96,7 +97,9 @@ class SceneFit:
             self.t = self.t_tmp
 
     def _evaluate(self):
-        self.sh.eval(grad_x=self.masks[0], grad_cam=self.masks[1], grad_phi=self.masks[2], timed=self.timed)
+        timed = self.timed_every > 0 and self._passes % self.timed_every == 0
+        self._passes += 1
+        self.sh.eval(grad_x=self.masks[0], grad_cam=self.masks[1], grad_phi=self.masks[2], timed=timed)
 
     # ---- learning-rate schedule ---------------------------------------------------------------
     def _manage(self):

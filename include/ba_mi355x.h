@@ -80,6 +80,10 @@ int ba_problem_destroy(ba_problem *p);
 int ba_eval(ba_problem *p, const double *X, const double *C, const double *Theta, const double *phi,
             int flags, double *E_sum, double *gX, double *gC, double *gTheta, double *gphi, void *stream);
 
+/* Copies one double from the device to *h_out and waits for it: the energy read-back the LR schedule
+ * branches on (E[iters] at p2w:612 is a host value in the reference). */
+int ba_fetch_double(const double *src, double *h_out, void *stream);
+
 /* Durations in milliseconds of the observation-pass kernel of the ba_eval calls made with
  * BA_EVAL_TIMED since the last call of this function (at most 256 are kept), measured with HIP
  * events recorded on the launch stream around that kernel.  Synchronises on the events. */
