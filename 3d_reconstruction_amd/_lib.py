@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libba_mi355x.so')
 EVAL_GRAD_X, EVAL_GRAD_CAM, EVAL_GRAD_PHI, EVAL_CAM_ATOMICS, EVAL_TIMED = 1, 2, 4, 16, 32
 EVAL_UNTILED = 512
 EVAL_REUSE_TABLE = 1024
+EVAL_POST = 2048
 
 _p = C.c_void_p
 _i64 = C.c_int64
@@ -39,11 +40,13 @@ SIGNATURES = {
     'ba_cholesky_solve': (_int, [_i64, _i64, _p, _p, C.POINTER(_int), _p]),
     'ba_backsubstitute': (_int, [_p, _p, _dbl, _p, _p, _p, _p, _p, _p, _p]),
     'ba_fetch_double': (_int, [_p, C.POINTER(_dbl), _p]),
+    'ba_post_energy': (_int, [_p, _p, _p]),
+    'ba_wait_energy': (_int, [_p, C.POINTER(_dbl), _p]),
     'ba_eval_timing': (_int, [_p, C.POINTER(C.c_float), _int, C.POINTER(_int)]),
     'ba_adam_step': (_int, [_i64, _p, _p, _p, _p, _dbl, _dbl, _dbl, _dbl, _p, _p]),
     'ba_sgd_step': (_int, [_i64, _p, _p, _dbl, _dbl, _p, _p]),
-    'ba_camera_step': (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _int, _dbl, _dbl, _dbl, _dbl, _int, _p, _p, _p]),
-    'ba_points_step': (_int, [_i64, _p, _p, _p, _p, _p, _int, _dbl, _dbl, _dbl, _dbl, _p, _p]),
+    'ba_camera_step': (_int, [_p] * 8 + [_i64, _i64, _int, _dbl, _dbl, _dbl, _dbl, _int, _p, _p, _p]),
+    'ba_points_step': (_int, [_i64] + [_p] * 7 + [_int, _dbl, _dbl, _dbl, _dbl, _p, _p]),
     'ba_gauge_fix': (_int, [_i64, _i64, _p, _p, _p, _p, _p, _p]),
     'ba_project': (_int, [_i64, _i64, _i64, _p, _p, _p, _p, _p, _dbl, _dbl, _dbl, _int, _int, _p, _p]),
     'ba_reprojection_error': (_int, [_i64, _p, _p, _p, _p]),

@@ -73,13 +73,16 @@ struct ba_problem {
     void *tile_meta = nullptr;        // n_tiles x TileMeta
     // scratch owned by the handle (device)
     double *cam_table = nullptr;  // K x CAM_ROW
-    double *cam_sums = nullptr;   // 6 x K camera-frame sums (SoA: component-major)
+    double *cam_sums = nullptr;   // 6 x K camera-frame sums (SoA: component-major), zero between passes
     double *partials = nullptr;   // grid*EVAL_WAVES x 2 per-wave partial sums
     double *scalars = nullptr;    // SC_COUNT
     int *flag = nullptr;          // 4 ints: validation flags, tile maxima
     int *step_counter = nullptr;  // arrival counter of the multi-workgroup camera step (kept at 0)
     double *step_best = nullptr;  // 2 per workgroup of that kernel
     double *step_stage = nullptr; // 16
+    // energy mailbox: 2 doubles of host memory mapped into the device, [0] = energy sum, [1] = post number
+    double *mailbox_host = nullptr, *mailbox_dev = nullptr;
+    uint64_t post_seq = 0;        // posts requested so far
     // second-order extension (allocated on first use)
     double *cam_sums_jtj = nullptr;  // 33 x K
     double *partials_jtj = nullptr;  // 3 per tile

@@ -15,6 +15,9 @@
 // (dq/dtheta_l = -a_l x q for R = Ry Rx Rz, so the 27 entries of dR/dTheta the reference builds
 //  at p2w:678-692 are never formed.)  All sums are un-normalised; the caller applies 1/|V|.
 #include "ba_common.h"
+
+#include <atomic>
+#include <chrono>
 #include "ba_device.h"
 
 #include <math.h>
@@ -727,12 +730,15 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_tile_fill(const int32_t *__restr
     }
 }
 
-// partial sums -> sums[2]; camera-frame sums -> dE/dC, dE/dTheta (un-normalised)
+// partial sums -> sums[2]; camera-frame sums -> dE/dC, dE/dTheta (un-normalised).  The camera-frame
+// sums are consumed here and left at zero for the next observation pass.  With a mailbox (host
+// memory mapped into the device) the energy sum is also posted there, followed by `seq`, so that
+// the host can pick it up without a copy command or a stream synchronisation.
 __global__ void __launch_bounds__(256) k_finalize(int64_t K, int n_partials, const double *__restrict__ partials,
-                                                  const double *__restrict__ cam_sums, const double *__restrict__ T,
+                                                  double *__restrict__ cam_sums, const double *__restrict__ T,
                                                   const double *__restrict__ scalars, double *__restrict__ E_sum,
                                                   double *__restrict__ gphi, double *__restrict__ gC,
-                                                  double *__restrict__ gTheta) {
+                                                  double *__restrict__ gTheta, volatile double *mailbox, double seq) {
     if (blockIdx.x == 0) {
         __shared__ double red[2][4];
         double e = 0.0, p = 0.0;
@@ -760,21 +766,40 @@ __global__ void __launch_bounds__(256) k_finalize(int64_t K, int n_partials, con
         }
         __syncthreads();
         if (threadIdx.x == 0) {
-            E_sum[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+            const double e_sum = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+            E_sum[0] = e_sum;
             if (gphi) gphi[0] = scalars[SC_DPHI] * ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+            if (mailbox) {
+                mailbox[0] = e_sum;
+                __threadfence_system();
+                mailbox[1] = seq;
+            }
         }
     }
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (j >= K || !gC) return;
-    const double *row = T + j * CAM_ROW;
+    if (j >= K) return;
     const double s0 = cam_sums[0 * K + j], s1 = cam_sums[1 * K + j], s2 = cam_sums[2 * K + j];
     const double w0 = cam_sums[3 * K + j], w1 = cam_sums[4 * K + j], w2 = cam_sums[5 * K + j];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) cam_sums[k * K + j] = 0.0;
+    if (!gC) return;
+    const double *row = T + j * CAM_ROW;
     gC[3 * j + 0] = -(row[0] * s0 + row[1] * s1 + row[2] * s2);
     gC[3 * j + 1] = -(row[3] * s0 + row[4] * s1 + row[5] * s2);
     gC[3 * j + 2] = -(row[6] * s0 + row[7] * s1 + row[8] * s2);
     gTheta[3 * j + 0] = -(row[12] * w0 - row[13] * w1);
     gTheta[3 * j + 1] = -(row[3] * w0 + row[4] * w1 + row[5] * w2);
     gTheta[3 * j + 2] = -w2;
+}
+
+// posts a device-resident energy sum to the host mailbox (used when the sum is completed outside the
+// finalisation kernel, e.g. by a cross-GPU reduction)
+__global__ void k_post_energy(const double *__restrict__ E_sum, volatile double *mailbox, double seq) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        mailbox[0] = E_sum[0];
+        __threadfence_system();
+        mailbox[1] = seq;
+    }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -818,14 +843,16 @@ __global__ void k_update(int64_t n, double *__restrict__ x, const double *__rest
     }
 }
 
-// Points: update rule, snapshot of the old value and the rigid part of the gauge fix
-// X <- ((X - C0) @ R0) * factor (p2w:285-293, 327) in ONE pass over X and its moments.
+// Points: update rule and the rigid part of the gauge fix X <- ((X - C0) @ R0) * factor
+// (p2w:285-293, 327) in ONE pass over X and its moments.  Inputs and outputs are separate
+// pointers, each pair either identical (in place) or disjoint (the caller keeps the inputs, e.g.
+// as the snapshot the LR schedule rolls back to, p2w:397-398).
 // A workgroup owns 256 consecutive points = 768 consecutive doubles of every array, which it
 // reads and writes element-wise (fully coalesced); the 3-vectors meet in LDS for the rotation.
 constexpr int PS_POINTS = 256;
-__global__ void __launch_bounds__(PS_POINTS) k_points_step(int64_t N, double *__restrict__ X,
-                                                           const double *__restrict__ gX, double *__restrict__ s,
-                                                           double *__restrict__ r, double *__restrict__ release,
+__global__ void __launch_bounds__(PS_POINTS) k_points_step(int64_t N, const double *X, double *X_out,
+                                                           const double *__restrict__ gX, const double *s,
+                                                           double *s_out, const double *r, double *r_out,
                                                            UpdateRule u, const double *__restrict__ gauge) {
     __shared__ double xs[3 * PS_POINTS];
     const int64_t base = (int64_t)blockIdx.x * (3 * PS_POINTS);
@@ -836,7 +863,6 @@ __global__ void __launch_bounds__(PS_POINTS) k_points_step(int64_t N, double *__
         const int64_t t = base + l;
         if (t < n) {
             const double xo = X[t];
-            if (release) release[t] = xo;
             double xn = xo;
             if (u.mode) {
                 double sv = 0.0, rv = 0.0;
@@ -846,12 +872,12 @@ __global__ void __launch_bounds__(PS_POINTS) k_points_step(int64_t N, double *__
                 }
                 xn = apply_rule(u, xo, gX[t], &sv, &rv);
                 if (u.mode == 2) {
-                    s[t] = sv;
-                    r[t] = rv;
+                    s_out[t] = sv;
+                    r_out[t] = rv;
                 }
             }
             if (gauge) xs[l] = xn;
-            else X[t] = xn;
+            else X_out[t] = xn;
         }
     }
     if (!gauge) return;
@@ -864,25 +890,27 @@ __global__ void __launch_bounds__(PS_POINTS) k_points_step(int64_t N, double *__
         if (t < n) {
             const int pt = l / 3, comp = l - 3 * pt;
             const double d0 = xs[3 * pt + 0] - c0, d1 = xs[3 * pt + 1] - c1, d2 = xs[3 * pt + 2] - c2;
-            X[t] = (d0 * gauge[comp] + d1 * gauge[3 + comp] + d2 * gauge[6 + comp]) * factor;
+            X_out[t] = (d0 * gauge[comp] + d1 * gauge[3 + comp] + d2 * gauge[6 + comp]) * factor;
         }
     }
 }
 
 // --------------------------------------------------------------------------------------------
-// K7: camera side of one step, single workgroup: update rule on the free slice of
+// K7: camera side of one step: update rule on the free slice of
 // [C | Theta | phi_x], then align_scene + normalize_scene for the cameras (p2w:270-333), then the
 // camera table and scalars of the NEW parameters, so that the next observation pass needs no
-// table kernel.  With the gauge fix the table holds R0^T R(Theta), the matrix align_scene returns
+// table kernel.  k_camera_step is the single-workgroup form without an update rule (in place:
+// the stand-alone gauge fix); k_camera_step_mb below is the full step.  With the gauge fix the table holds R0^T R(Theta), the matrix align_scene returns
 // and the reference keeps using (p2w:711), and cos/sin(theta_z) recovered from its entries the way
 // p2w:665-676 does.  gauge[0..8] = R0, [9..11] = C0, [12] = scale factor, [13] = j1.
 // --------------------------------------------------------------------------------------------
 struct CameraStep {
     int64_t K;
-    double *cam;          // [C (3K) | Theta (3K) | phi_x (1)]
+    const double *cam_in; // [C (3K) | Theta (3K) | phi_x (1)] before the step
+    double *cam;          // ... after the step; the same buffer as cam_in, or a disjoint one
     const double *g;      // gradient in the same packing (may be null when mode == 0)
-    double *s, *r;        // Adam moments, same packing
-    double *release;      // optional snapshot of the free slice before the update
+    const double *s_in, *r_in;  // Adam moments, same packing
+    double *s, *r;        // updated moments (same buffers as s_in / r_in, or disjoint ones)
     int64_t lo, hi;       // free slice
     UpdateRule rule;
     int do_gauge;
@@ -901,24 +929,6 @@ __global__ void __launch_bounds__(1024) k_camera_step(CameraStep a) {
     const int64_t K = a.K;
     double *C = a.cam, *Theta = a.cam + 3 * K;
 
-    if (a.rule.mode) {
-        for (int64_t t = a.lo + threadIdx.x; t < a.hi; t += 1024) {
-            const double xo = a.cam[t];
-            if (a.release) a.release[t] = xo;
-            double sv = 0.0, rv = 0.0;
-            if (a.rule.mode == 2) {
-                sv = a.s[t];
-                rv = a.r[t];
-            }
-            a.cam[t] = apply_rule(a.rule, xo, a.g[t], &sv, &rv);
-            if (a.rule.mode == 2) {
-                a.s[t] = sv;
-                a.r[t] = rv;
-            }
-        }
-        __threadfence_block();
-        __syncthreads();
-    }
     if (threadIdx.x == 0 && a.scalars) {
         const double ph = a.cam[6 * K];
         const double f = a.W / 2.0 / tan(ph / 2.0);
@@ -1058,7 +1068,8 @@ __global__ void __launch_bounds__(1024) k_camera_step(CameraStep a) {
 // camera 0 (whose new pose defines the rigid motion) and the longest baseline (which defines the
 // scale):
 //   * every workgroup recomputes camera 0's update from its OLD parameters, which nobody
-//     overwrites before the end: camera 0's own results are staged in `stage` by workgroup 0;
+//     overwrites before the end (also when the step runs in place): camera 0's own results are
+//     staged in `stage` by workgroup 0;
 //   * every workgroup publishes its best baseline and takes a ticket; the workgroup that draws
 //     the last ticket reduces the baselines, scales all centres, writes camera 0 and phi_x.
 // Publication follows the agent-scope release / acquire protocol (stores, vmcnt(0), barrier,
@@ -1075,13 +1086,12 @@ __device__ __forceinline__ void camera_pose_update(const CameraStep &a, int64_t 
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
         const int64_t t = (k < 3) ? 3 * j + k : 3 * K + 3 * j + (k - 3);
-        const double xo = a.cam[t];
+        const double xo = a.cam_in[t];
         double xn = xo, sv = 0.0, rv = 0.0;
         if (a.rule.mode && t >= a.lo && t < a.hi) {
-            if (write && a.release) a.release[t] = xo;
             if (a.rule.mode == 2) {
-                sv = a.s[t];
-                rv = a.r[t];
+                sv = a.s_in[t];
+                rv = a.r_in[t];
             }
             xn = apply_rule(a.rule, xo, a.g[t], &sv, &rv);
             if (write && a.rule.mode == 2) {
@@ -1134,21 +1144,20 @@ __global__ void __launch_bounds__(256) k_camera_step_mb(CameraStep a, CameraStep
         }
         if (j == 0) {
             const int64_t t = 6 * K;
-            double ph = a.cam[t];
+            double ph = a.cam_in[t];
             if (a.rule.mode && t >= a.lo && t < a.hi) {
-                if (a.release) a.release[t] = ph;
                 double sv = 0.0, rv = 0.0;
                 if (a.rule.mode == 2) {
-                    sv = a.s[t];
-                    rv = a.r[t];
+                    sv = a.s_in[t];
+                    rv = a.r_in[t];
                 }
                 ph = apply_rule(a.rule, ph, a.g[t], &sv, &rv);
                 if (a.rule.mode == 2) {
                     a.s[t] = sv;
                     a.r[t] = rv;
                 }
-                a.cam[t] = ph;
             }
+            a.cam[t] = ph;
             if (a.scalars) {
                 const double f = a.W / 2.0 / tan(ph / 2.0);
                 a.scalars[SC_F] = f;
@@ -1309,16 +1318,13 @@ __global__ void __launch_bounds__(256) k_camera_step_mb(CameraStep a, CameraStep
             a.gauge[14] = 0.0;
             a.gauge[15] = 0.0;
         }
-        // camera 0: snapshot of the old pose, new moments, gauge-fixed pose
+        // camera 0: new moments, gauge-fixed pose
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
             const int64_t t = (k < 3) ? k : 3 * K + (k - 3);
-            if (a.rule.mode && t >= a.lo && t < a.hi) {
-                if (a.release) a.release[t] = a.cam[t];
-                if (a.rule.mode == 2) {
-                    a.s[t] = sh.stage[3 + k];
-                    a.r[t] = sh.stage[9 + k];
-                }
+            if (a.rule.mode == 2 && t >= a.lo && t < a.hi) {
+                a.s[t] = sh.stage[3 + k];
+                a.r[t] = sh.stage[9 + k];
             }
             a.cam[t] = (k < 3) ? 0.0 : sh.stage[k - 3];
         }
@@ -1326,21 +1332,20 @@ __global__ void __launch_bounds__(256) k_camera_step_mb(CameraStep a, CameraStep
     }
     if (tid == 64) {  // phi_x and the scalars that depend on it
         const int64_t t = 6 * K;
-        double ph = a.cam[t];
+        double ph = a.cam_in[t];
         if (a.rule.mode && t >= a.lo && t < a.hi) {
-            if (a.release) a.release[t] = ph;
             double sv = 0.0, rv = 0.0;
             if (a.rule.mode == 2) {
-                sv = a.s[t];
-                rv = a.r[t];
+                sv = a.s_in[t];
+                rv = a.r_in[t];
             }
             ph = apply_rule(a.rule, ph, a.g[t], &sv, &rv);
             if (a.rule.mode == 2) {
                 a.s[t] = sv;
                 a.r[t] = rv;
             }
-            a.cam[t] = ph;
         }
+        a.cam[t] = ph;
         if (a.scalars) {
             const double f = a.W / 2.0 / tan(ph / 2.0);
             a.scalars[SC_F] = f;
@@ -1582,6 +1587,7 @@ int ba_problem_destroy(ba_problem *p) {
     hipFree(p->partials_jtj);
     hipFree(p->row_ptr);
     hipFree(p->flag);
+    if (p->mailbox_host) hipHostFree((void *)p->mailbox_host);
     for (auto e : p->ev_begin) hipEventDestroy(e);
     for (auto e : p->ev_end) hipEventDestroy(e);
     delete p;
@@ -1671,6 +1677,15 @@ int ba_problem_create(int64_t N, int64_t K, int64_t nV, const int32_t *i, const 
 
     BA_TRY(hipMalloc(&p->cam_table, sizeof(double) * K * CAM_ROW));
     BA_TRY(hipMalloc(&p->cam_sums, sizeof(double) * K * 6));
+    BA_TRY(hipMemset(p->cam_sums, 0, sizeof(double) * K * 6));   // kept at zero between passes by k_finalize
+    {
+        void *host = nullptr, *dev = nullptr;
+        BA_TRY(hipHostMalloc(&host, 64, hipHostMallocMapped | hipHostMallocCoherent));
+        memset(host, 0, 64);
+        p->mailbox_host = (double *)host;
+        BA_TRY(hipHostGetDevicePointer(&dev, host, 0));
+        p->mailbox_dev = (double *)dev;
+    }
     {
         size_t n_part = (size_t)p->grid * EVAL_WAVES;
         if ((size_t)p->n_tiles > n_part) n_part = p->n_tiles;
@@ -1711,7 +1726,6 @@ int ba_eval(ba_problem *p, const double *X, const double *C, const double *Theta
     if (!(flags & BA_EVAL_REUSE_TABLE))
         hipLaunchKernelGGL(k_camera_table, dim3(cdiv(K, 256)), dim3(256), 0, st, K, C, Theta, phi, p->W, p->H,
                            p->cam_table, p->scalars);
-    BA_HIP(hipMemsetAsync(p->cam_sums, 0, sizeof(double) * 6 * K, st));
     const bool want_gx = (flags & BA_EVAL_GRAD_X) != 0;
     const bool use_tiles = p->tiled && p->tiles_worth && !(flags & (BA_EVAL_CAM_ATOMICS | BA_EVAL_UNTILED));
     // the tiled pass writes every point's gradient itself; the wave-chunk pass only the observed ones
@@ -1773,11 +1787,57 @@ int ba_eval(ba_problem *p, const double *X, const double *C, const double *Theta
         p->ev_count++;
     }
     const bool want_cam = (flags & BA_EVAL_GRAD_CAM) != 0;
-    hipLaunchKernelGGL(k_finalize, dim3(want_cam ? cdiv(K, 256) : 1), dim3(256), 0, st, K, n_partials,
-                       p->partials, p->cam_sums, p->cam_table, p->scalars, E_sum,
-                       (flags & BA_EVAL_GRAD_PHI) ? gphi : nullptr, want_cam ? gC : nullptr,
-                       want_cam ? gTheta : nullptr);
+    double *mailbox = nullptr;
+    double seq = 0.0;
+    if (flags & BA_EVAL_POST) {
+        mailbox = p->mailbox_dev;
+        seq = (double)++p->post_seq;
+    }
+    hipLaunchKernelGGL(k_finalize, dim3(cdiv(K, 256)), dim3(256), 0, st, K, n_partials, p->partials, p->cam_sums,
+                       p->cam_table, p->scalars, E_sum, (flags & BA_EVAL_GRAD_PHI) ? gphi : nullptr,
+                       want_cam ? gC : nullptr, want_cam ? gTheta : nullptr, mailbox, seq);
     BA_HIP(hipGetLastError());
+    return BA_OK;
+}
+
+int ba_post_energy(ba_problem *p, const double *E_sum, void *stream) {
+    BA_REQUIRE(p && E_sum, "ba_post_energy: null pointer");
+    const double seq = (double)++p->post_seq;
+    hipLaunchKernelGGL(k_post_energy, dim3(1), dim3(64), 0, (hipStream_t)stream, E_sum, p->mailbox_dev, seq);
+    BA_HIP(hipGetLastError());
+    return BA_OK;
+}
+
+int ba_wait_energy(ba_problem *p, double *h_E_sum, void *stream) {
+    BA_REQUIRE(p && h_E_sum, "ba_wait_energy: null pointer");
+    BA_REQUIRE(p->post_seq > 0, "ba_wait_energy: nothing was posted");
+    volatile double *box = p->mailbox_host;
+    const double want = (double)p->post_seq;
+    const auto t0 = std::chrono::steady_clock::now();
+    bool drained = false;
+    for (uint64_t spin = 1;; ++spin) {
+        if (box[1] == want) break;
+        __builtin_ia32_pause();
+        if ((spin & 0xffff) == 0) {
+            // the stream ran dry without the post arriving, or nothing for a long time: a kernel
+            // failed; report instead of spinning forever
+            const hipError_t q = hipStreamQuery((hipStream_t)stream);
+            if (q != hipSuccess && q != hipErrorNotReady) return hip_fail(q, "hipStreamQuery", __FILE__, __LINE__);
+            if (q == hipSuccess) {
+                if (drained) {
+                    set_error("ba_wait_energy: the stream finished without posting the energy");
+                    return BA_ERR_HIP;
+                }
+                drained = true;   // one more look at the mailbox after the stream drained
+            }
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) {
+                set_error("ba_wait_energy: timed out");
+                return BA_ERR_HIP;
+            }
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    *h_E_sum = box[0];
     return BA_OK;
 }
 
@@ -1826,31 +1886,47 @@ int ba_sgd_step(int64_t n, double *x, const double *g, double lr, double gscale,
     return BA_OK;
 }
 
-int ba_points_step(int64_t N, double *X, const double *gX, double *s, double *r, double *release, int rule, double lr,
-                   double gscale, double bc1, double bc2, const double *gauge, void *stream) {
+// true when [a, a+n) and [b, b+n) are the same range or do not overlap
+static bool same_or_disjoint(const double *a, const double *b, int64_t n) {
+    return a == b || a + n <= b || b + n <= a;
+}
+
+int ba_points_step(int64_t N, const double *X_in, double *X_out, const double *gX, const double *s_in, double *s_out,
+                   const double *r_in, double *r_out, int rule, double lr, double gscale, double bc1, double bc2,
+                   const double *gauge, void *stream) {
     BA_REQUIRE(N >= 0 && rule >= 0 && rule <= 2, "ba_points_step: bad size or rule");
     if (N == 0) return BA_OK;
-    BA_REQUIRE(X && (rule == 0 || gX) && (rule != 2 || (s && r)), "ba_points_step: null pointer");
-    hipLaunchKernelGGL(k_points_step, dim3(cdiv(N, PS_POINTS)), dim3(PS_POINTS), 0, (hipStream_t)stream, N, X, gX, s, r, release,
-                       make_rule(rule, lr, gscale, bc1, bc2), gauge);
+    BA_REQUIRE(X_in && X_out && (rule == 0 || gX) && (rule != 2 || (s_in && s_out && r_in && r_out)),
+               "ba_points_step: null pointer");
+    BA_REQUIRE(same_or_disjoint(X_in, X_out, 3 * N) && (rule != 2 || (same_or_disjoint(s_in, s_out, 3 * N) &&
+                                                                       same_or_disjoint(r_in, r_out, 3 * N))),
+               "ba_points_step: an output must be its input or not overlap it");
+    if (rule == 0 && !gauge && X_in == X_out) return BA_OK;
+    hipLaunchKernelGGL(k_points_step, dim3(cdiv(N, PS_POINTS)), dim3(PS_POINTS), 0, (hipStream_t)stream, N, X_in,
+                       X_out, gX, s_in, s_out, r_in, r_out, make_rule(rule, lr, gscale, bc1, bc2), gauge);
     BA_HIP(hipGetLastError());
     return BA_OK;
 }
 
-int ba_camera_step(ba_problem *p, double *cam, const double *g, double *s, double *r, double *release, int64_t lo,
-                   int64_t hi, int rule, double lr, double gscale, double bc1, double bc2, int gauge, double *R_out,
-                   double *gauge_out, void *stream) {
-    BA_REQUIRE(p && cam, "ba_camera_step: null pointer");
+int ba_camera_step(ba_problem *p, const double *cam_in, double *cam_out, const double *g, const double *s_in,
+                   double *s_out, const double *r_in, double *r_out, int64_t lo, int64_t hi, int rule, double lr,
+                   double gscale, double bc1, double bc2, int gauge, double *R_out, double *gauge_out, void *stream) {
+    BA_REQUIRE(p && cam_in && cam_out, "ba_camera_step: null pointer");
     BA_REQUIRE(rule >= 0 && rule <= 2 && lo >= 0 && hi <= 6 * p->K + 1, "ba_camera_step: bad rule or range");
-    BA_REQUIRE(rule == 0 || lo >= hi || (g && (rule != 2 || (s && r))), "ba_camera_step: null pointer");
+    BA_REQUIRE(rule == 0 || lo >= hi || (g && (rule != 2 || (s_in && s_out && r_in && r_out))),
+               "ba_camera_step: null pointer");
     BA_REQUIRE(!gauge || (p->K >= 2 && gauge_out), "ba_camera_step: the gauge fix needs two cameras and gauge_out");
+    BA_REQUIRE(same_or_disjoint(cam_in, cam_out, 6 * p->K + 1),
+               "ba_camera_step: cam_out must be cam_in or not overlap it");
     CameraStep a;
     a.K = p->K;
-    a.cam = cam;
+    a.cam_in = cam_in;
+    a.cam = cam_out;
     a.g = g;
-    a.s = s;
-    a.r = r;
-    a.release = release;
+    a.s_in = s_in;
+    a.r_in = r_in;
+    a.s = s_out;
+    a.r = r_out;
     a.lo = lo;
     a.hi = hi;
     a.rule = make_rule(lo < hi ? rule : 0, lr, gscale, bc1, bc2);
@@ -1887,6 +1963,7 @@ int ba_gauge_fix(int64_t N, int64_t K, double *X, double *C, double *Theta, doub
     CameraStep a;
     memset(&a, 0, sizeof(a));
     a.K = K;
+    a.cam_in = C;
     a.cam = C;
     a.do_gauge = 1;
     a.R_out = R_out;

@@ -73,11 +73,11 @@ class Shard:
         self.handle = handle
         K3 = 3 * self.K
         z = lambda *s: torch.zeros(*s, dtype=F64, device=self.device)
+        # Current parameters.  X and cam are REBOUND, not overwritten, by the optimiser step
+        # (step_update returns new tensors, adopt() binds them), so a tensor a caller kept - the
+        # snapshot the LR schedule rolls back to - stays valid without a copy.
         self.X = z(self.N, 3)
         self.cam = z(2 * K3 + 1)
-        self.C = self.cam[:K3].view(self.K, 3)
-        self.Theta = self.cam[K3:2 * K3].view(self.K, 3)
-        self.phi = self.cam[2 * K3:]
         self.gX = z(self.N, 3)
         self.red = z(2 * K3 + 2)
         self.gC = self.red[:K3].view(self.K, 3)
@@ -86,15 +86,31 @@ class Shard:
         self.E_sum = self.red[2 * K3 + 1:]
         self.gauge = z(16)
         self.R_gauge = z(self.K, 9)
-        self.table_valid = False    # the handle's camera table matches cam (see eval / step_update)
-        # hot-path plumbing: one device, one stream, pointers converted once
+        self._table_cam = None      # the cam tensor the handle's camera table was built from
+        # hot-path plumbing: one device, one stream, pointers of the fixed buffers converted once
         torch.cuda.set_device(self.device)
         self.stream = stream_ptr()
         self.distributed = torch.distributed.is_available() and torch.distributed.is_initialized() and \
             torch.distributed.get_world_size(group) > 1
-        self._eval_args = None
-        self._E_ptr, self._E_host = ptr(self.E_sum), C.c_double(0.0)
-        self._step_cache = {}
+        self._out_ptrs = [t.data_ptr() for t in (self.E_sum, self.gX, self.gC, self.gTheta, self.gphi)]
+        self._E_host = C.c_double(0.0)
+
+    # views of the current camera buffer
+    @property
+    def C(self):
+        return self.cam[:3 * self.K].view(self.K, 3)
+
+    @property
+    def Theta(self):
+        return self.cam[3 * self.K:6 * self.K].view(self.K, 3)
+
+    @property
+    def phi(self):
+        return self.cam[6 * self.K:]
+
+    @property
+    def table_valid(self):
+        return self._table_cam is self.cam
 
     def close(self):
         if getattr(self, 'handle', None):
@@ -141,36 +157,50 @@ class Shard:
 
     # ---- parameters -------------------------------------------------------------------------
     def set_params(self, X, C_, Theta, phi_x):
-        self.X.copy_(self.points_to_engine(X))
-        self.C.copy_(_dev_tensor(C_, F64, self.device))
-        self.Theta.copy_(_dev_tensor(Theta, F64, self.device))
-        self.phi.fill_(float(phi_x))
-        self.table_valid = False
+        self.X = self.points_to_engine(X).clone()
+        cam = torch.empty_like(self.cam)
+        K3 = 3 * self.K
+        cam[:K3] = _dev_tensor(C_, F64, self.device).reshape(-1)
+        cam[K3:2 * K3] = _dev_tensor(Theta, F64, self.device).reshape(-1)
+        cam[2 * K3:] = float(phi_x)
+        self.cam = cam
+        self._table_cam = None
+
+    def adopt(self, X, cam):
+        """Make X / cam (tensors returned by step_update, or kept from an earlier state) current."""
+        self.X, self.cam = X, cam
 
     def invalidate_table(self):
-        """Call after writing camera parameters behind the library's back (rollback, set_params)."""
-        self.table_valid = False
+        """Call after writing into the current camera buffer in place."""
+        self._table_cam = None
 
     # ---- kernels ----------------------------------------------------------------------------
     def eval(self, grad_x=True, grad_cam=True, grad_phi=True, timed=False, cam_atomics=False, untiled=False):
-        """One fused observation pass at the current parameters.  Leaves un-normalised gradients
-        in gX / red and returns nothing; `energy()` reads the scalar back."""
+        """Queues one fused observation pass at the current parameters.  Leaves un-normalised
+        gradients in gX / red and posts the energy sum for `wait_energy()`."""
         flags = (_lib.EVAL_GRAD_X if grad_x else 0) | (_lib.EVAL_GRAD_CAM if grad_cam else 0) | \
                 (_lib.EVAL_GRAD_PHI if grad_phi else 0) | (_lib.EVAL_TIMED if timed else 0) | \
                 (_lib.EVAL_CAM_ATOMICS if cam_atomics else 0) | (_lib.EVAL_UNTILED if untiled else 0) | \
-                (_lib.EVAL_REUSE_TABLE if self.table_valid else 0)
-        if self._eval_args is None:     # the buffers never move: convert the pointers once
-            self._eval_args = ([self.handle] + [ptr(t) for t in (self.X, self.C, self.Theta, self.phi)],
-                               [ptr(t) for t in (self.E_sum, self.gX, self.gC, self.gTheta, self.gphi)])
-        a, b = self._eval_args
-        check(self.lib.ba_eval(*a, flags, *b, self.stream))
-        self.table_valid = True
+                (_lib.EVAL_REUSE_TABLE if self._table_cam is self.cam else 0) | \
+                (0 if self.distributed else _lib.EVAL_POST)
+        c = self.cam.data_ptr()
+        K24 = 24 * self.K
+        check(self.lib.ba_eval(self.handle, self.X.data_ptr(), c, c + K24, c + 2 * K24, flags, *self._out_ptrs,
+                               self.stream))
+        self._table_cam = self.cam
         if self.distributed:
             allreduce_sum_(self.red, self.group)
+            check(self.lib.ba_post_energy(self.handle, self._out_ptrs[0], self.stream))
+
+    def wait_energy(self):
+        """E = sum r^2 / (2|V|) (p2w:612) of the latest `eval`, picked up from the host mailbox the
+        GPU posts it to.  Does not wait for work queued after that pass."""
+        check(self.lib.ba_wait_energy(self.handle, C.byref(self._E_host), self.stream))
+        return self._E_host.value / (2 * self.nV)
 
     def energy(self):
-        """E = sum r^2 / (2|V|) (p2w:612).  One 8-byte device-to-host copy (synchronises)."""
-        check(self.lib.ba_fetch_double(self._E_ptr, C.byref(self._E_host), self.stream))
+        """The same value through an 8-byte device-to-host copy that synchronises the stream."""
+        check(self.lib.ba_fetch_double(self._out_ptrs[0], C.byref(self._E_host), self.stream))
         return self._E_host.value / (2 * self.nV)
 
     def eval_kernel_ms(self):
@@ -183,52 +213,58 @@ class Shard:
         with torch.cuda.device(self.device):
             check(self.lib.ba_adam_step(x.numel(), ptr(x), ptr(g), ptr(s), ptr(r), float(lr), 1.0 / self.nV,
                                         float(bc1), float(bc2), ptr(release), stream_ptr()))
-        self.table_valid = False
+        self._table_cam = None
 
     def sgd(self, x, g, lr, release=None):
         with torch.cuda.device(self.device):
             check(self.lib.ba_sgd_step(x.numel(), ptr(x), ptr(g), float(lr), 1.0 / self.nV, ptr(release),
                                        stream_ptr()))
-        self.table_valid = False
+        self._table_cam = None
 
     def gauge_fix(self):
-        """align_scene + normalize_scene in place (p2w:710-712)."""
-        with torch.cuda.device(self.device):
-            check(self.lib.ba_gauge_fix(self.N, self.K, ptr(self.X), ptr(self.C), ptr(self.Theta),
-                                        ptr(self.R_gauge), ptr(self.gauge), stream_ptr()))
-        self.table_valid = False
+        """align_scene + normalize_scene in place on the current buffers (p2w:710-712)."""
+        c = self.cam.data_ptr()
+        check(self.lib.ba_gauge_fix(self.N, self.K, self.X.data_ptr(), c, c + 24 * self.K, ptr(self.R_gauge),
+                                    ptr(self.gauge), self.stream))
+        self._table_cam = None
 
-    def step_update(self, rule, lr, bc1, bc2, x_free, cam_range, mom_x, mom_cam, rel_x, rel_cam, gauge):
-        """One optimiser step for every free group plus the gauge fix, in two launches
-        (p2w:704-712).  rule: 1 SGD, 2 Adam.  mom_* = (s, r) moment tensors or None; rel_* = snapshot
-        destinations or None (the old values are written there in the same pass).  cam_range =
-        (lo, hi) slice of [C | Theta | phi_x] that is free, or None."""
+    def step_update(self, rule, lr, bc1, bc2, x_free, cam_range, mom_x, mom_cam, gauge, in_place=False):
+        """Queues one optimiser step for every free group plus the gauge fix, in two launches
+        (p2w:704-712), reading the current parameters and the gradients of the last `eval`.
+        rule: 1 SGD, 2 Adam.  mom_x = (s, r) tensors shaped like X or None; mom_cam = (s, r) tensors
+        shaped like cam or None.  cam_range = (lo, hi) slice of [C | Theta | phi_x] that is free, or
+        None.  Returns (X, cam, mom_x, mom_cam) AFTER the step: new tensors (the inputs are left
+        untouched, so keeping them is a snapshot) unless in_place.  The results become current
+        with `adopt`; dropping them instead discards the step."""
         gs = 1.0 / self.nV
-        key = (rule, x_free, cam_range, gauge, rel_x is not None, rel_cam is not None,
-               None if mom_x is None else mom_x[0].data_ptr(), None if mom_cam is None else mom_cam[0].data_ptr(),
-               None if rel_x is None else rel_x.data_ptr(), None if rel_cam is None else rel_cam.data_ptr())
-        plan = self._step_cache.get(key)
-        if plan is None:
-            cam_call = pts_call = None
-            if cam_range is not None or gauge:
-                lo, hi = cam_range if cam_range is not None else (0, 0)
-                s_c, r_c = mom_cam if mom_cam is not None else (None, None)
-                # moment / snapshot tensors of the camera group cover the free slice only
-                off = lambda t: None if t is None else C.c_void_p(t.data_ptr() - 8 * lo)
-                cam_call = ([self.handle, ptr(self.cam), ptr(self.red), off(s_c), off(r_c), off(rel_cam), lo, hi, rule],
-                            [int(bool(gauge)), ptr(self.R_gauge), ptr(self.gauge)])
-            if x_free or gauge:
-                s_x, r_x = mom_x if mom_x is not None else (None, None)
-                pts_call = ([self.N, ptr(self.X), ptr(self.gX), ptr(s_x), ptr(r_x), ptr(rel_x) if x_free else None,
-                             rule if x_free else 0], [ptr(self.gauge) if gauge else None])
-            plan = self._step_cache[key] = (cam_call, pts_call)
-        cam_call, pts_call = plan
         lr, bc1, bc2 = float(lr), float(bc1), float(bc2)
-        if cam_call is not None:
-            check(self.lib.ba_camera_step(*cam_call[0], lr, gs, bc1, bc2, *cam_call[1], self.stream))
-            self.table_valid = True
-        if pts_call is not None:
-            check(self.lib.ba_points_step(*pts_call[0], lr, gs, bc1, bc2, *pts_call[1], self.stream))
+        new = (lambda t: t) if in_place else torch.empty_like
+        X_new, cam_new = self.X, self.cam
+        if cam_range is not None or gauge:
+            lo, hi = cam_range if cam_range is not None else (0, 0)
+            cam_new = new(self.cam)
+            if mom_cam is not None:
+                s_in, r_in = mom_cam
+                mom_cam = (new(s_in), new(r_in))
+                mp = (s_in.data_ptr(), mom_cam[0].data_ptr(), r_in.data_ptr(), mom_cam[1].data_ptr())
+            else:
+                mp = (None, None, None, None)
+            check(self.lib.ba_camera_step(self.handle, self.cam.data_ptr(), cam_new.data_ptr(), self.red.data_ptr(),
+                                          *mp, lo, hi, rule, lr, gs, bc1, bc2, int(bool(gauge)),
+                                          self.R_gauge.data_ptr(), self.gauge.data_ptr(), self.stream))
+            self._table_cam = cam_new
+        if x_free or gauge:
+            X_new = new(self.X)
+            if x_free and mom_x is not None:
+                s_in, r_in = mom_x
+                mom_x = (new(s_in), new(r_in))
+                mp = (s_in.data_ptr(), mom_x[0].data_ptr(), r_in.data_ptr(), mom_x[1].data_ptr())
+            else:
+                mp = (None, None, None, None)
+            check(self.lib.ba_points_step(self.N, self.X.data_ptr(), X_new.data_ptr(), self.gX.data_ptr(), *mp,
+                                          rule if x_free else 0, lr, gs, bc1, bc2,
+                                          self.gauge.data_ptr() if gauge else None, self.stream))
+        return X_new, cam_new, mom_x, mom_cam
 
     # ---- second-order extension (no reference counterpart) ---------------------------------------
     def _lm_buffers(self):
@@ -251,7 +287,7 @@ class Shard:
                                        ptr(self.E_sum), ptr(self.gX), ptr(self.gC), ptr(self.gTheta), ptr(self.gphi),
                                        ptr(self.V), ptr(self.Xphi), ptr(self.B), ptr(self.bphi), ptr(self.hphi),
                                        stream_ptr()))
-        self.table_valid = True
+        self._table_cam = self.cam
 
     def lm_step(self, lam):
         """Solve the damped normal equations (J^T J + lam diag) d = -J^T r by Schur complement and

@@ -4,7 +4,12 @@ optimiser state handling, stopping rules and logging.  Behaviour follows the ref
 work is delegated to a shard object (engine.Shard) whose buffers live on the GPU.
 
 The only device-to-host traffic per iteration is the 8-byte energy, which the schedule
-branches on."""
+branches on.  To keep the GPU busy while that value travels, the update that follows an
+evaluation is queued BEFORE the energy is read, with the learning rate and moments the schedule
+will use unless it changes them (LR increase, LR decrease with rollback, a stopping rule).  The
+step writes new buffers and leaves its inputs alone, so when the schedule does intervene the
+queued step is simply dropped and the loop continues from the untouched state: the sequence of
+parameters is the one the reference computes either way."""
 from __future__ import annotations
 
 import numpy as np
@@ -21,11 +26,15 @@ extra_optimizers = {'LM': 'Levenberg-Marquardt with Schur complement (lm.LMFit)'
 
 class SceneFit:
     """One `fit_scene` run as an object: `step()` executes one pass of the loop body and
-    returns False when the loop is over."""
+    returns False when the loop is over.
+
+    State lives in tensors that are never written in place once they are current: the optimiser
+    step returns new ones.  `release` (the snapshot of p2w:397-398) and the stashed Adam moments
+    (p2w:411-414) are therefore plain references to earlier tensors."""
 
     def __init__(self, shard, lr, max_iters, X_mask=True, C_Theta_mask=True, phi_x_mask=True,
                  optimizer='Adam', patience=1000, factor=2.0, stop_value=0.0, stop_diff=1e-12,
-                 print_step=1000, ret_all_iters=False, printer=print):
+                 print_step=1000, ret_all_iters=False, printer=print, speculate=True):
         if optimizer not in gd_func_dict:
             raise ValueError(f'Unkown name of the optmizer, choose one from {[key for key in gd_func_dict]}')
         self.sh = shard
@@ -36,6 +45,8 @@ class SceneFit:
         self.stop_value, self.stop_diff, self.print_step = stop_value, stop_diff, print_step
         self.ret_all_iters = ret_all_iters
         self.print = printer
+        self.speculate = bool(speculate)   # queue the update before the energy is known
+        self.dropped = 0                   # queued updates the schedule overruled
         self.timed_every = 0        # record HIP events around the observation-pass kernel of every n-th pass
         self._passes = 0
         self.gauge = self.masks[0] and self.masks[1]      # p2w:533, 710
@@ -48,21 +59,13 @@ class SceneFit:
         if self.gauge:
             shard.gauge_fix()                                            # p2w:533-536
 
-        # free parameter groups as (parameters, gradient) tensor pairs
-        self.groups = []
-        if self.masks[0]:
-            self.groups.append((shard.X.view(-1), shard.gX.view(-1)))
-        if self.cam_range:
-            self.groups.append((shard.cam[lo:hi], shard.red[lo:hi]))
-        self.release = [p.clone() for p, _ in self.groups]              # p2w:463-464
+        self.release = (shard.X, shard.cam)                              # p2w:463-464
         self.adam = optimizer == 'Adam'
+        self.mom_x = self.mom_cam = self.mom_x_tmp = self.mom_cam_tmp = None
         if self.adam:                                                    # p2w:469-473
-            self.s = [p.new_zeros(p.shape) for p, _ in self.groups]
-            self.r = [p.new_zeros(p.shape) for p, _ in self.groups]
-            self.t = 1
-            self.s_tmp = [p.new_zeros(p.shape) for p, _ in self.groups]
-            self.r_tmp = [p.new_zeros(p.shape) for p, _ in self.groups]
-            self.t_tmp = 1
+            self.mom_x, self.mom_cam = self._zero_moments()
+            self.mom_x_tmp, self.mom_cam_tmp = self._zero_moments()
+            self.t = self.t_tmp = 1
         self.all_iters = self.max_iters * [None] if ret_all_iters else None
 
         self.E = np.zeros(self.max_iters)                                # p2w:592-599
@@ -71,30 +74,28 @@ class SceneFit:
         self.began_decreasing = self.increased = False
         self.iters = 0
         self.finished = False
-        self._snapshot = False      # a snapshot of the current parameters is due with the next update
+        self._intervened = False    # the schedule changed lr / moments / parameters in this pass
 
     # ---- optimiser state moves (p2w:411-414, 439-446) -----------------------------------------
+    def _zero_moments(self):
+        sh = self.sh
+        zx = (sh.X.new_zeros(sh.X.shape), sh.X.new_zeros(sh.X.shape)) if self.masks[0] else None
+        zc = (sh.cam.new_zeros(sh.cam.shape), sh.cam.new_zeros(sh.cam.shape)) if self.cam_range else None
+        return zx, zc
+
     def _adam_reset(self):
         if self.adam:
-            for s, r in zip(self.s, self.r):
-                s.zero_()
-                r.zero_()
+            self.mom_x, self.mom_cam = self._zero_moments()
             self.t = 1
 
     def _adam_stash_and_reset(self):
         if self.adam:
-            for k in range(len(self.groups)):
-                self.s_tmp[k].copy_(self.s[k])
-                self.r_tmp[k].copy_(self.r[k])
-            self.t_tmp = self.t
+            self.mom_x_tmp, self.mom_cam_tmp, self.t_tmp = self.mom_x, self.mom_cam, self.t
             self._adam_reset()
 
     def _adam_restore(self):
         if self.adam:
-            for k in range(len(self.groups)):
-                self.s[k].copy_(self.s_tmp[k])
-                self.r[k].copy_(self.r_tmp[k])
-            self.t = self.t_tmp
+            self.mom_x, self.mom_cam, self.t = self.mom_x_tmp, self.mom_cam_tmp, self.t_tmp
 
     def _evaluate(self):
         timed = self.timed_every > 0 and self._passes % self.timed_every == 0
@@ -111,9 +112,7 @@ class SceneFit:
         elif e < self.E_min:
             self.E_min = e
             self.began_decreasing = True
-            # release <- main (p2w:397-398); the copy is written by the update kernels, which read
-            # the old parameters anyway.  Nothing reads `release` before the next call of _manage.
-            self._snapshot = True
+            self.release = (self.sh.X, self.sh.cam)      # release <- main (p2w:397-398), by reference
             self.patience_timer = self.patience
             if self.success_timer > 0:
                 self.success_timer -= 1
@@ -124,6 +123,7 @@ class SceneFit:
                 self.increased = True
                 self.E_min_temp = self.E_min
                 self._adam_stash_and_reset()
+                self._intervened = True
         elif e > self.E_min:
             if self.increased:
                 self.patience_timer = 0
@@ -138,17 +138,25 @@ class SceneFit:
                     self.iters -= 1
                 self.print(f'{self.iters} : Decrease LR to {self.lr / self.factor}')
                 self.lr /= self.factor
-                for rel, (p, _) in zip(self.release, self.groups):
-                    p.copy_(rel)
-                self.sh.invalidate_table()
+                self.sh.adopt(*self.release)          # main <- release (p2w:430-431)
                 self._evaluate()          # gradients at the rolled-back parameters
                 if (not self.increased) or (self.E_min_temp > self.E_min):
                     self._adam_reset()
                 else:
                     self._adam_restore()
                     self.increased = False
+                self._intervened = True
         if self.ret_all_iters:
-            self.all_iters[entry] = [p.clone() for p, _ in self.groups]
+            self.all_iters[entry] = self._free_tensors()
+
+    def _free_tensors(self):
+        """The free parameter groups of the current state (X; free slice of [C | Theta | phi_x])."""
+        out = []
+        if self.masks[0]:
+            out.append(self.sh.X.view(-1))
+        if self.cam_range:
+            out.append(self.sh.cam[self.cam_range[0]:self.cam_range[1]])
+        return out
 
     # ---- one pass of the loop body (p2w:600-714) ----------------------------------------------
     def step(self):
@@ -156,7 +164,9 @@ class SceneFit:
             self.finished = True
             return False
         self._evaluate()
-        self.E[self.iters] = self.sh.energy()
+        queued = self._queue_update() if self.speculate else None
+        self.E[self.iters] = self.sh.wait_energy()
+        self._intervened = False
         self._manage()
 
         it = self.iters
@@ -177,24 +187,25 @@ class SceneFit:
         if it % self.print_step == 0:
             self.print(f'{it} : {self.E_min}')
 
-        self.update()
+        if queued is None or self._intervened:
+            if queued is not None:
+                self.dropped += 1
+            queued = self._queue_update()
+        X, cam, self.mom_x, self.mom_cam = queued
+        self.sh.adopt(X, cam)
+        if self.adam:
+            self.t += 1
         self.iters += 1
         return True
 
-    def update(self):
-        """Update rule on every free group, pending snapshot, gauge fix (p2w:704-712)."""
+    def _queue_update(self):
+        """Update rule on every free group and gauge fix (p2w:704-712) from the current state into
+        new tensors; returns them without making them current."""
         bc1 = bc2 = 1.0
         if self.adam:
             bc1, bc2 = 1.0 - RHO_1 ** self.t, 1.0 - RHO_2 ** self.t
-        gx = 0 if self.masks[0] else None                 # index of the X group
-        gc = (1 if self.masks[0] else 0) if self.cam_range else None
-        mom = lambda k: (self.s[k], self.r[k]) if (self.adam and k is not None) else None
-        rel = lambda k: self.release[k] if (self._snapshot and k is not None) else None
-        self.sh.step_update(2 if self.adam else 1, self.lr, bc1, bc2, self.masks[0], self.cam_range,
-                            mom(gx), mom(gc), rel(gx), rel(gc), self.gauge)
-        self._snapshot = False
-        if self.adam:
-            self.t += 1
+        return self.sh.step_update(2 if self.adam else 1, self.lr, bc1, bc2, self.masks[0], self.cam_range,
+                                   self.mom_x, self.mom_cam, self.gauge)
 
     def _finish(self):
         self.finished = True
@@ -215,5 +226,6 @@ class SceneFit:
         (X; then the free slice of [C | Theta | phi_x])."""
         if not self.ret_all_iters:
             return None
+        n_groups = (1 if self.masks[0] else 0) + (1 if self.cam_range else 0)
         return [[None if snap is None else snap[k].cpu().numpy() for snap in self.all_iters]
-                for k in range(len(self.groups))]
+                for k in range(n_groups)]

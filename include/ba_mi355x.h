@@ -44,8 +44,9 @@ enum ba_eval_flags {
     BA_EVAL_TIMED = 32,     /* record HIP events around the observation-pass kernel (see ba_eval_timing) */
     BA_EVAL_DEBUG_MASK = 64 | 128 | 256, /* diagnostics only: skip parts of the pass (results are wrong) */
     BA_EVAL_UNTILED = 512,  /* use the wave-chunk kernel even when the scene has LDS tiles */
-    BA_EVAL_REUSE_TABLE = 1024 /* the handle's camera table already describes C, Theta, phi (left there by
+    BA_EVAL_REUSE_TABLE = 1024, /* the handle's camera table already describes C, Theta, phi (left there by
                                   ba_camera_step); skip rebuilding it */
+    BA_EVAL_POST = 2048     /* also post E_sum to the handle's host mailbox (see ba_wait_energy) */
 };
 
 const char *ba_last_error(void);
@@ -84,6 +85,15 @@ int ba_eval(ba_problem *p, const double *X, const double *C, const double *Theta
  * branches on (E[iters] at p2w:612 is a host value in the reference). */
 int ba_fetch_double(const double *src, double *h_out, void *stream);
 
+/* Energy mailbox: two doubles of host memory mapped into the device.  A ba_eval with BA_EVAL_POST
+ * (or ba_post_energy, for a sum completed elsewhere, e.g. by a cross-GPU reduction) makes the GPU
+ * store the energy sum there; ba_wait_energy spins on the host until the LATEST post has landed
+ * and returns it.  Unlike ba_fetch_double it does not wait for work queued behind the post, so the
+ * caller can queue the next update before it reads the energy that the LR schedule (p2w:365-454)
+ * branches on.  Fails (instead of spinning forever) if the stream drains without the post. */
+int ba_post_energy(ba_problem *p, const double *E_sum, void *stream);
+int ba_wait_energy(ba_problem *p, double *h_E_sum, void *stream);
+
 /* Durations in milliseconds of the observation-pass kernel of the ba_eval calls made with
  * BA_EVAL_TIMED since the last call of this function (at most 256 are kept), measured with HIP
  * events recorded on the launch stream around that kernel.  Synchronises on the events. */
@@ -108,19 +118,23 @@ int ba_gauge_fix(int64_t N, int64_t K, double *X, double *C, double *Theta, doub
                  double *gauge_out, void *stream);
 
 /* ---- one optimiser step, fused (p2w:704-712): the same arithmetic as ba_adam_step / ba_sgd_step
- * followed by ba_gauge_fix, in two launches and one pass over each array.
+ * followed by ba_gauge_fix, in two launches and one pass over each array.  Parameters and moments
+ * have an input and an output pointer each: the same buffer (in place) or disjoint ones.  With
+ * disjoint buffers the inputs survive, which gives the caller the snapshot lr_manager takes at
+ * p2w:397-398 for free, and lets it drop a step it queued before it knew the energy.
  * ba_camera_step: update rule (0 none, 1 SGD, 2 Adam) on the slice [lo, hi) of
- *   cam = [C (3K) | Theta (3K) | phi_x (1)] (g, s, r, release in the same packing), then, if
- *   `gauge`, the camera half of the gauge fix; it also leaves the handle's camera table and
- *   scalars valid for the new parameters (see BA_EVAL_REUSE_TABLE).
- * ba_points_step: update rule on X with optional snapshot, then, if `gauge` (the record written by
- *   ba_camera_step) is given, X <- ((X - C0) @ R0) * factor. */
-int ba_camera_step(ba_problem *p, double *cam, const double *g, double *s, double *r, double *release,
-                   int64_t lo, int64_t hi, int rule, double lr, double gscale, double bc1, double bc2,
-                   int gauge, double *R_out, double *gauge_out, void *stream);
-int ba_points_step(int64_t N, double *X, const double *gX, double *s, double *r, double *release,
-                   int rule, double lr, double gscale, double bc1, double bc2, const double *gauge,
-                   void *stream);
+ *   cam = [C (3K) | Theta (3K) | phi_x (1)] (g, s, r in the same packing; entries outside the slice
+ *   are copied), then, if `gauge`, the camera half of the gauge fix; it also leaves the handle's
+ *   camera table and scalars valid for cam_out (see BA_EVAL_REUSE_TABLE).
+ * ba_points_step: update rule on X, then, if `gauge` (the record written by ba_camera_step) is
+ *   given, X <- ((X - C0) @ R0) * factor. */
+int ba_camera_step(ba_problem *p, const double *cam_in, double *cam_out, const double *g, const double *s_in,
+                   double *s_out, const double *r_in, double *r_out, int64_t lo, int64_t hi, int rule,
+                   double lr, double gscale, double bc1, double bc2, int gauge, double *R_out,
+                   double *gauge_out, void *stream);
+int ba_points_step(int64_t N, const double *X_in, double *X_out, const double *gX, const double *s_in,
+                   double *s_out, const double *r_in, double *r_out, int rule, double lr, double gscale,
+                   double bc1, double bc2, const double *gauge, void *stream);
 
 /* ---- second-order extension: NO counterpart in the reference (its optimiser is first-order, p2w:336-362).
  * Gauss-Newton / Levenberg-Marquardt on the same energy.  All quantities un-normalised (J^T J, J^T r).

@@ -19,10 +19,19 @@ class MockShard:
         K3 = 3 * K
         z = lambda *s: torch.zeros(*s, dtype=torch.float64)
         self.X, self.cam, self.gX, self.red = z(N, 3), z(2 * K3 + 1), z(N, 3), z(2 * K3 + 2)
-        self.C, self.Theta, self.phi = self.cam[:K3].view(K, 3), self.cam[K3:2 * K3].view(K, 3), self.cam[2 * K3:]
         self.gC, self.gTheta = self.red[:K3].view(K, 3), self.red[K3:2 * K3].view(K, 3)
         self.gphi, self.E_sum = self.red[2 * K3:2 * K3 + 1], self.red[2 * K3 + 1:]
         self.evals = 0
+
+    C = property(lambda self: self.cam[:3 * self.K].view(self.K, 3))
+    Theta = property(lambda self: self.cam[3 * self.K:6 * self.K].view(self.K, 3))
+    phi = property(lambda self: self.cam[6 * self.K:])
+
+    def adopt(self, X, cam):
+        self.X, self.cam = X, cam
+
+    def wait_energy(self):
+        return self.energy()
 
     def set_params(self, X, C, Theta, phi_x):
         self.X.copy_(torch.from_numpy(np.asarray(X)))
@@ -62,27 +71,39 @@ class MockShard:
         self.C.copy_(torch.from_numpy(C))
         self.Theta.copy_(torch.from_numpy(Th))
 
-    def _apply(self, rule, x, g, mom, rel, lr, t_pow):
-        if rel is not None:
-            rel.copy_(x)
+    def _apply(self, rule, x, g, mom, lr, t_pow):
+        """(new x, new moments) of one update rule; inputs untouched."""
         g = g.numpy() / self.nV
         if rule == 2:
             s, r = mom
             bc1, bc2 = t_pow
-            sn = 0.9 * s.numpy() + (1.0 - 0.9) * g
-            rn = 0.999 * r.numpy() + (1.0 - 0.999) * g ** 2
+            sn = 0.9 * s.numpy().reshape(-1) + (1.0 - 0.9) * g
+            rn = 0.999 * r.numpy().reshape(-1) + (1.0 - 0.999) * g ** 2
             xn = x.numpy() - lr * (sn / bc1) / (1e-12 + np.sqrt(rn / bc2))
-            s.copy_(torch.from_numpy(sn))
-            r.copy_(torch.from_numpy(rn))
-        else:
-            xn = x.numpy() - lr * g
-        x.copy_(torch.from_numpy(xn))
+            return torch.from_numpy(xn), (torch.from_numpy(sn).view(s.shape), torch.from_numpy(rn).view(r.shape))
+        return torch.from_numpy(x.numpy() - lr * g), mom
 
-    def step_update(self, rule, lr, bc1, bc2, x_free, cam_range, mom_x, mom_cam, rel_x, rel_cam, gauge):
+    def step_update(self, rule, lr, bc1, bc2, x_free, cam_range, mom_x, mom_cam, gauge, in_place=False):
+        X, cam = self.X, self.cam
         if x_free:
-            self._apply(rule, self.X.view(-1), self.gX.view(-1), mom_x, rel_x, lr, (bc1, bc2))
+            xn, mom_x = self._apply(rule, X.view(-1), self.gX.view(-1), mom_x, lr, (bc1, bc2))
+            X = xn.view(self.N, 3)
         if cam_range is not None:
             lo, hi = cam_range
-            self._apply(rule, self.cam[lo:hi], self.red[lo:hi], mom_cam, rel_cam, lr, (bc1, bc2))
+            sl = None if mom_cam is None else (mom_cam[0][lo:hi], mom_cam[1][lo:hi])
+            cn, sl = self._apply(rule, cam[lo:hi], self.red[lo:hi], sl, lr, (bc1, bc2))
+            cam = cam.clone()
+            cam[lo:hi] = cn
+            if mom_cam is not None:
+                mom_cam = (mom_cam[0].clone(), mom_cam[1].clone())
+                mom_cam[0][lo:hi], mom_cam[1][lo:hi] = sl
         if gauge:
-            self.gauge_fix()
+            K3 = 3 * self.K
+            Xg, Cg, Th = orc.align_scene(X.numpy(), cam[:K3].view(self.K, 3).numpy(),
+                                         Theta=cam[K3:2 * K3].view(self.K, 3).numpy())
+            Xg, Cg = orc.normalize_scene(Xg, Cg)
+            X = torch.from_numpy(np.ascontiguousarray(Xg))
+            cam = cam.clone()
+            cam[:K3] = torch.from_numpy(np.ascontiguousarray(Cg)).reshape(-1)
+            cam[K3:2 * K3] = torch.from_numpy(np.ascontiguousarray(Th)).reshape(-1)
+        return X, cam, mom_x, mom_cam
