@@ -18,6 +18,7 @@ EVAL_GRAD_X, EVAL_GRAD_CAM, EVAL_GRAD_PHI, EVAL_CAM_ATOMICS, EVAL_TIMED = 1, 2, 
 EVAL_UNTILED = 512
 EVAL_REUSE_TABLE = 1024
 EVAL_POST = 2048
+EVAL_POINT_MAJOR = 4096
 
 _p = C.c_void_p
 _i64 = C.c_int64

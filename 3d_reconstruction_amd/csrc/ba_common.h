@@ -71,6 +71,13 @@ struct ba_problem {
     int32_t *cam_list = nullptr;
     uint32_t *opack = nullptr;        // nV: (point - tile's first point) << 16 | camera slot in the tile's list
     void *tile_meta = nullptr;        // n_tiles x TileMeta
+    // camera-run layout of the tiles (see ba_runpass.h); null when the scene does not tile
+    uint32_t *rpack = nullptr;        // total_runs x 8 records
+    double2 *ruv = nullptr;
+    int64_t *run_ptr = nullptr;       // n_tiles + 1
+    int64_t total_runs = 0;
+    int run_pt_stride = 0;            // LDS point capacity / 8
+    int run_rep_grad = 1, run_rep_jtj = 1;   // copies of the camera accumulators per pass
     // scratch owned by the handle (device)
     double *cam_table = nullptr;  // K x CAM_ROW
     double *cam_sums = nullptr;   // 6 x K camera-frame sums (SoA: component-major), zero between passes

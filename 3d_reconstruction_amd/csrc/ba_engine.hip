@@ -19,6 +19,7 @@
 #include <atomic>
 #include <chrono>
 #include "ba_device.h"
+#include "ba_runpass.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -730,6 +731,109 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_tile_fill(const int32_t *__restr
     }
 }
 
+// ---- gradient pass on camera runs (see ba_runpass.h) --------------------------------------------
+struct GradOp {
+    static constexpr int NCV = 6, NPV = 3, NPART = 2, NOUT = 1;
+    __host__ __device__ static constexpr int out_width(int) { return 3; }
+    __host__ __device__ static constexpr int out_offset(int) { return 0; }
+    double f, pcx, pcy;
+    __device__ explicit GradOp(const double *scalars) : f(scalars[SC_F]), pcx(scalars[SC_CX]), pcy(scalars[SC_CY]) {}
+    // cv: camera-frame force (3) and torque (3); pv: world-frame dE/dX_i part; part: r.r, m.r
+    __device__ __forceinline__ void obs(const double (&x)[3], const double2 (&rw)[6], double2 uv, double (&cv)[6],
+                                        double (&pv)[3], double (&part)[2]) const {
+        const double R00 = rw[0].x, R01 = rw[0].y, R02 = rw[1].x, R10 = rw[1].y, R11 = rw[2].x, R12 = rw[2].y,
+                     R20 = rw[3].x, R21 = rw[3].y, R22 = rw[4].x;
+        const double d0 = x[0] - rw[4].y, d1 = x[1] - rw[5].x, d2 = x[2] - rw[5].y;
+        const double q0 = R00 * d0 + R10 * d1 + R20 * d2;
+        const double q1 = R01 * d0 + R11 * d1 + R21 * d2;
+        const double q2 = R02 * d0 + R12 * d1 + R22 * d2;
+        const double inv = 1.0 / q2;
+        const double m0 = q0 * inv, m1 = q1 * inv;
+        const double r0 = f * m0 + pcx - uv.x;
+        const double r1 = f * m1 + pcy - uv.y;
+        part[0] += r0 * r0 + r1 * r1;
+        const double mr = m0 * r0 + m1 * r1;
+        part[1] += mr;
+        const double fi = f * inv;
+        const double a0 = fi * r0, a1 = fi * r1, a2 = -fi * mr;
+        pv[0] = R00 * a0 + R01 * a1 + R02 * a2;
+        pv[1] = R10 * a0 + R11 * a1 + R12 * a2;
+        pv[2] = R20 * a0 + R21 * a1 + R22 * a2;
+        cv[0] += a0;
+        cv[1] += a1;
+        cv[2] += a2;
+        cv[3] += q1 * a2 - q2 * a1;
+        cv[4] += q2 * a0 - q0 * a2;
+        cv[5] += q0 * a1 - q1 * a0;
+    }
+};
+
+// Run layout, pass 1: runs per tile = sum over its cameras of ceil(observations / RUN_LEN).
+__global__ void __launch_bounds__(TILE_BLOCK) k_run_count(const uint32_t *__restrict__ opack,
+                                                          const TileMeta *__restrict__ meta,
+                                                          int64_t *__restrict__ counts, int *__restrict__ max_obs) {
+    extern __shared__ int hist[];
+    __shared__ int total;
+    const TileMeta tm = meta[blockIdx.x];
+    for (int c = threadIdx.x; c < tm.nc; c += TILE_BLOCK) hist[c] = 0;
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    for (int e = tm.e0 + threadIdx.x; e < tm.e1; e += TILE_BLOCK) atomicAdd(&hist[opack[e] & 0xffffu], 1);
+    __syncthreads();
+    int runs = 0;
+    for (int c = threadIdx.x; c < tm.nc; c += TILE_BLOCK) runs += (hist[c] + RUN_LEN - 1) / RUN_LEN;
+    if (runs) atomicAdd(&total, runs);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        counts[blockIdx.x] = total;
+        atomicMax(max_obs, tm.e1 - tm.e0);
+    }
+}
+
+// Pass 2: every camera of the tile copies its observations, in point order, into its runs.
+// LDS: per-camera counts, then first runs (nc + 1), then the tile's packed records.
+__global__ void __launch_bounds__(TILE_BLOCK) k_run_fill(const uint32_t *__restrict__ opack,
+                                                         const double2 *__restrict__ ouv,
+                                                         const TileMeta *__restrict__ meta,
+                                                         const int64_t *__restrict__ run_ptr, int cam_cap,
+                                                         uint32_t *__restrict__ rpack, double2 *__restrict__ ruv) {
+    extern __shared__ int sm[];
+    int *hist = sm, *first = sm + cam_cap;
+    uint32_t *spack = (uint32_t *)(sm + 2 * cam_cap + 1);
+    const TileMeta tm = meta[blockIdx.x];
+    const int n = tm.e1 - tm.e0;
+    const int64_t rb = run_ptr[blockIdx.x];
+    const int nruns = (int)(run_ptr[blockIdx.x + 1] - rb);
+    for (int c = threadIdx.x; c < tm.nc; c += TILE_BLOCK) hist[c] = 0;
+    __syncthreads();
+    for (int e = threadIdx.x; e < n; e += TILE_BLOCK) {
+        const uint32_t pk = opack[tm.e0 + e];
+        spack[e] = pk;
+        atomicAdd(&hist[pk & 0xffffu], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int c = 0; c < tm.nc; ++c) {
+            first[c] = acc;
+            acc += (hist[c] + RUN_LEN - 1) / RUN_LEN;
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < tm.nc; c += TILE_BLOCK) {
+        int q = 0;
+        const int f0 = first[c];
+        for (int e = 0; e < n; ++e) {
+            const uint32_t pk = spack[e];
+            if ((int)(pk & 0xffffu) != c) continue;
+            const int64_t idx = rb * RUN_LEN + (int64_t)(q % RUN_LEN) * nruns + f0 + q / RUN_LEN;
+            rpack[idx] = pk;
+            ruv[idx] = ouv[tm.e0 + e];
+            ++q;
+        }
+    }
+}
+
 // partial sums -> sums[2]; camera-frame sums -> dE/dC, dE/dTheta (un-normalised).  The camera-frame
 // sums are consumed here and left at zero for the next observation pass.  With a mailbox (host
 // memory mapped into the device) the energy sum is also posted there, followed by `seq`, so that
@@ -1432,6 +1536,62 @@ int ba::camera_table(ba_problem *p, const double *C, const double *Theta, const 
     return BA_OK;
 }
 
+// Regroups every tile's observations into camera runs (see ba_runpass.h).
+static int build_runs(ba_problem *p) {
+    const int nt = p->n_tiles;
+    int *max_obs = p->flag;
+    BA_HIP(hipMemset(max_obs, 0, 4));
+    BA_HIP(hipMalloc(&p->run_ptr, sizeof(int64_t) * (nt + 1)));
+    hipLaunchKernelGGL(k_run_count, dim3(nt), dim3(TILE_BLOCK), sizeof(int) * p->cam_cap, 0, p->opack,
+                       (const TileMeta *)p->tile_meta, p->run_ptr, max_obs);
+    BA_HIP(hipGetLastError());
+    int h_max_obs = 0;
+    BA_HIP(hipMemcpy(&h_max_obs, max_obs, 4, hipMemcpyDeviceToHost));
+    const int n_scan_tiles = cdiv(nt, SCAN_TILE);
+    int64_t *tile_sums = nullptr;
+    BA_HIP(hipMalloc(&tile_sums, sizeof(int64_t) * (n_scan_tiles + 1)));
+    hipLaunchKernelGGL(k_scan_tiles, dim3(n_scan_tiles), dim3(1024), 0, 0, p->run_ptr, (int64_t)nt, p->run_ptr, tile_sums);
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(1), dim3(1024), 0, 0, tile_sums, n_scan_tiles);
+    hipLaunchKernelGGL(k_scan_add, dim3(cdiv(nt, 256)), dim3(256), 0, 0, p->run_ptr, (int64_t)nt, tile_sums, n_scan_tiles);
+    hipError_t e = hipMemcpy(&p->total_runs, p->run_ptr + nt, sizeof(int64_t), hipMemcpyDeviceToHost);
+    hipFree(tile_sums);
+    BA_HIP(e);
+    const size_t fill_lds = sizeof(int) * (2 * (size_t)p->cam_cap + 1) + sizeof(uint32_t) * (size_t)h_max_obs;
+    if (fill_lds > 64 * 1024 || p->total_runs == 0) {   // leave the point-major tiles in charge
+        hipFree(p->run_ptr);
+        p->run_ptr = nullptr;
+        p->total_runs = 0;
+        return BA_OK;
+    }
+    const size_t n_rec = (size_t)p->total_runs * RUN_LEN;
+    BA_HIP(hipMalloc(&p->rpack, sizeof(uint32_t) * n_rec));
+    BA_HIP(hipMalloc(&p->ruv, sizeof(double2) * n_rec));
+    BA_HIP(hipMemset(p->rpack, 0xff, sizeof(uint32_t) * n_rec));
+    BA_HIP(hipMemset(p->ruv, 0, sizeof(double2) * n_rec));
+    hipLaunchKernelGGL(k_run_fill, dim3(nt), dim3(TILE_BLOCK), fill_lds, 0, p->opack, p->ouv,
+                       (const TileMeta *)p->tile_meta, p->run_ptr, p->cam_cap, p->rpack, p->ruv);
+    BA_HIP(hipGetLastError());
+    p->run_pt_stride = ((p->pt_cap + 7) / 8) | 1;
+    // copies of the camera accumulators: as many as keep the workgroup near a quarter of the LDS budget
+    const size_t budget = 64 * 1024;
+    auto pick_rep = [&](int ncv, int npv, size_t limit, const char *env_name) {
+        int rep = 8;
+        if (const char *env = getenv(env_name)) rep = atoi(env);
+        if (rep < 1) rep = 1;
+        while (rep > 1 && sizeof(double) * ((size_t)p->cam_cap * (ROW_LDS + ncv * rep) +
+                                             (size_t)(3 + npv) * 8 * p->run_pt_stride) > limit)
+            rep >>= 1;
+        return rep;
+    };
+    p->run_rep_grad = pick_rep(6, 3, budget / 2, "BA_CAM_REP");
+    p->run_rep_jtj = pick_rep(33, 12, 78 * 1024, "BA_CAM_REP_JTJ");   // two workgroups per CU
+    if (getenv("BA_VERBOSE"))
+        fprintf(stderr, "[ba] runs: total=%lld (%.3f x nV/8) pt_stride=%d rep_grad=%d rep_jtj=%d\n",
+                (long long)p->total_runs, (double)p->total_runs * RUN_LEN / (double)p->nV, p->run_pt_stride,
+                p->run_rep_grad, p->run_rep_jtj);
+    return BA_OK;
+}
+
 // Cuts the observation list into LDS tiles (see k_eval_tiled).  The tile is halved until the
 // camera rows, the points and both accumulator sets of the largest tile fit the LDS budget of a
 // workgroup; scenes whose tiles would each need most of the cameras keep p->tiled == 0 and run
@@ -1440,7 +1600,7 @@ static int build_tiles(ba_problem *p) {
     const int64_t K = p->K, nV = p->nV;
     const int n_words = (int)((K + 31) >> 5);
     const size_t lds_budget = 64 * 1024;
-    int tobs = 2048;
+    int tobs = 3968;   // two camera runs per thread of the run pass ((2 * 256 - cameras of a tile) * 8)
     if (const char *env = getenv("BA_TILE_OBS")) tobs = atoi(env);
     if (tobs < 64 || (size_t)n_words * 8 > lds_budget) return BA_OK;
     int *maxima = p->flag;  // 2 ints of the handle's flag buffer
@@ -1503,6 +1663,9 @@ static int build_tiles(ba_problem *p) {
                            p->tile_cam_ptr, (int)K, p->oi, nV, p->N, p->cam_list, p->opack, (TileMeta *)p->tile_meta);
         BA_HIP(hipGetLastError());
         p->tiled = 1;
+    }
+    if (p->tiles_worth) {
+        if (int rc = build_runs(p)) return rc;
     }
     if (getenv("BA_VERBOSE"))
         fprintf(stderr, "[ba] tiles: tiled=%d worth=%d n_tiles=%d target_obs=%d cam_cap=%d pt_cap=%d rep=%d lds=%zu B cams/tile=%.1f\n",
@@ -1576,6 +1739,9 @@ int ba_problem_destroy(ba_problem *p) {
     hipFree(p->cam_list);
     hipFree(p->opack);
     hipFree(p->tile_meta);
+    hipFree(p->rpack);
+    hipFree(p->ruv);
+    hipFree(p->run_ptr);
     hipFree(p->cam_table);
     hipFree(p->cam_sums);
     hipFree(p->partials);
@@ -1752,8 +1918,33 @@ int ba_eval(ba_problem *p, const double *X, const double *C, const double *Theta
     const bool use_lds = !(flags & BA_EVAL_CAM_ATOMICS) && lds_bytes <= (size_t)p->lds_limit;
     const bool timed = (flags & BA_EVAL_TIMED) != 0 && p->ev_count < TIMING_RING;
     int n_partials = p->grid * EVAL_WAVES;
+    const bool use_runs = use_tiles && p->rpack && !(flags & BA_EVAL_POINT_MAJOR) && a.debug == 0;
     if (timed) BA_HIP(hipEventRecord(p->ev_begin[p->ev_count], st));
-    if (use_tiles) {
+    if (use_runs) {
+        RunArgs ra;
+        ra.rpack = p->rpack;
+        ra.ruv = p->ruv;
+        ra.run_ptr = p->run_ptr;
+        ra.meta = (const TileMeta *)p->tile_meta;
+        ra.cam_list = p->cam_list;
+        ra.K = (int)K;
+        ra.cam_cap = p->cam_cap;
+        ra.pt_stride = p->run_pt_stride;
+        ra.cam_rep = p->run_rep_grad;
+        ra.X = X;
+        ra.T = p->cam_table;
+        ra.scalars = p->scalars;
+        ra.out[0] = a.gX;
+        ra.out[1] = ra.out[2] = nullptr;
+        ra.cam_sums = p->cam_sums;
+        ra.partials = p->partials;
+        n_partials = p->n_tiles;
+        const size_t lds = sizeof(double) * run_pass_lds_doubles<GradOp>(p->cam_cap, p->run_pt_stride, p->run_rep_grad);
+        if (lds > 64 * 1024)
+            BA_HIP(hipFuncSetAttribute((const void *)k_run_pass<GradOp>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds));
+        hipLaunchKernelGGL(k_run_pass<GradOp>, dim3(p->n_tiles), dim3(TILE_BLOCK), lds, st, ra);
+    } else if (use_tiles) {
         TileArgs ta;
         ta.opack = p->opack;
         ta.ouv = p->ouv;

@@ -15,6 +15,7 @@
 // so per camera the blocks are accumulated in the camera frame (B' = sum G^T G, b' = sum G^T m) and
 // rotated once per camera afterwards.
 #include "ba_device.h"
+#include "ba_runpass.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -224,6 +225,59 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_jtj_tiled(JtjArgs a) {
                                __HIP_MEMORY_SCOPE_AGENT);
     }
 }
+
+// The same pass on camera runs (see ba_runpass.h): 33 camera sums in registers over a run, 12 point
+// sums as conflict-free LDS atomics.
+struct JtjOp {
+    static constexpr int NCV = CAMV, NPV = PTV, NPART = 3, NOUT = 3;
+    // per-point sums: gradient (3) -> gX, V upper triangle (6) -> V, point x phi (3) -> Xphi
+    __host__ __device__ static constexpr int out_width(int o) { return o == 1 ? 6 : 3; }
+    __host__ __device__ static constexpr int out_offset(int o) { return o == 0 ? 0 : (o == 1 ? 3 : 9); }
+    double f, pcx, pcy, dphi;
+    __device__ explicit JtjOp(const double *scalars)
+        : f(scalars[SC_F]), pcx(scalars[SC_CX]), pcy(scalars[SC_CY]), dphi(scalars[SC_DPHI]) {}
+    __device__ __forceinline__ void obs(const double (&x)[3], const double2 (&rw)[6], double2 uv, double (&cv)[CAMV],
+                                        double (&pv)[PTV], double (&part)[3]) const {
+        const ObsJac o = obs_jacobian(x, rw, f, pcx, pcy, uv);
+        const double r0 = o.r0, r1 = o.r1;
+        part[0] += r0 * r0 + r1 * r1;
+        part[1] += o.m0 * r0 + o.m1 * r1;
+        part[2] += o.m0 * o.m0 + o.m1 * o.m1;
+        // G0[1] = G1[0] = 0 and G0[0] = G1[1] = -fi: the products with them are written out
+        const double fi = o.fi;
+        cv[0] += fi * r0;
+        cv[1] += fi * r1;
+#pragma unroll
+        for (int k = 2; k < 6; ++k) cv[k] -= o.G0[k] * r0 + o.G1[k] * r1;
+        const double fi2 = fi * fi;
+        cv[6] += fi2;                               // (0,0)
+        // (0,1) stays zero
+#pragma unroll
+        for (int q = 2; q < 6; ++q) cv[6 + q] -= fi * o.G0[q];    // (0,q)
+        cv[12] += fi2;                              // (1,1)
+#pragma unroll
+        for (int q = 2; q < 6; ++q) cv[11 + q] -= fi * o.G1[q];   // (1,q)
+        int idx = 17;
+#pragma unroll
+        for (int p = 2; p < 6; ++p)
+#pragma unroll
+            for (int q = p; q < 6; ++q) cv[idx++] += o.G0[p] * o.G0[q] + o.G1[p] * o.G1[q];
+        cv[27] -= fi * o.m0;
+        cv[28] -= fi * o.m1;
+#pragma unroll
+        for (int k = 2; k < 6; ++k) cv[27 + k] += o.G0[k] * o.m0 + o.G1[k] * o.m1;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pv[k] = o.jx0[k] * r0 + o.jx1[k] * r1;
+        pv[3] = o.jx0[0] * o.jx0[0] + o.jx1[0] * o.jx1[0];
+        pv[4] = o.jx0[0] * o.jx0[1] + o.jx1[0] * o.jx1[1];
+        pv[5] = o.jx0[0] * o.jx0[2] + o.jx1[0] * o.jx1[2];
+        pv[6] = o.jx0[1] * o.jx0[1] + o.jx1[1] * o.jx1[1];
+        pv[7] = o.jx0[1] * o.jx0[2] + o.jx1[1] * o.jx1[2];
+        pv[8] = o.jx0[2] * o.jx0[2] + o.jx1[2] * o.jx1[2];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pv[9 + k] = dphi * (o.jx0[k] * o.m0 + o.jx1[k] * o.m1);
+    }
+};
 
 // T = blockdiag(R^T, A), A = [a_x a_y a_z] columns: row mu, column alpha of the 6x6 frame change
 __device__ __forceinline__ void camera_frame_change(const double *row, double T[6][6]) {
@@ -766,7 +820,10 @@ int ba_eval_jtj(ba_problem *p, const double *X, const double *C, const double *T
     }
     hipStream_t st = (hipStream_t)stream;
     const int64_t K = p->K;
-    const size_t lds = sizeof(double) * ((size_t)(ROW_LDS + CAMV) * p->cam_cap + (size_t)(3 + PTV) * p->pt_cap);
+    const size_t lds_runs = sizeof(double) * run_pass_lds_doubles<JtjOp>(p->cam_cap, p->run_pt_stride, p->run_rep_jtj);
+    const bool use_runs = p->rpack && !(flags & BA_EVAL_POINT_MAJOR) && lds_runs <= 160 * 1024 - 256;
+    const size_t lds = use_runs ? lds_runs
+                                : sizeof(double) * ((size_t)(ROW_LDS + CAMV) * p->cam_cap + (size_t)(3 + PTV) * p->pt_cap);
     if (lds > 160 * 1024 - 256) {
         set_error("ba_eval_jtj: tile accumulators exceed the LDS of a workgroup");
         return BA_ERR_STATE;
@@ -792,11 +849,31 @@ int ba_eval_jtj(ba_problem *p, const double *X, const double *C, const double *T
     a.Xphi = Xphi;
     a.cam_sums = p->cam_sums_jtj;
     a.partials = p->partials_jtj;
+    RunArgs ra;
+    ra.rpack = p->rpack;
+    ra.ruv = p->ruv;
+    ra.run_ptr = p->run_ptr;
+    ra.meta = a.meta;
+    ra.cam_list = p->cam_list;
+    ra.K = (int)K;
+    ra.cam_cap = p->cam_cap;
+    ra.pt_stride = p->run_pt_stride;
+    ra.cam_rep = p->run_rep_jtj;
+    ra.X = X;
+    ra.T = p->cam_table;
+    ra.scalars = p->scalars;
+    ra.out[0] = gX;
+    ra.out[1] = V;
+    ra.out[2] = Xphi;
+    ra.cam_sums = p->cam_sums_jtj;
+    ra.partials = p->partials_jtj;
     if (lds > 64 * 1024)
-        BA_HIP(hipFuncSetAttribute((const void *)k_jtj_tiled, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        BA_HIP(hipFuncSetAttribute(use_runs ? (const void *)k_run_pass<JtjOp> : (const void *)k_jtj_tiled,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const bool timed = (flags & BA_EVAL_TIMED) != 0 && p->ev_count < TIMING_RING;
     if (timed) BA_HIP(hipEventRecord(p->ev_begin[p->ev_count], st));
-    hipLaunchKernelGGL(k_jtj_tiled, dim3(p->n_tiles), dim3(TILE_BLOCK), lds, st, a);
+    if (use_runs) hipLaunchKernelGGL(k_run_pass<JtjOp>, dim3(p->n_tiles), dim3(TILE_BLOCK), lds, st, ra);
+    else hipLaunchKernelGGL(k_jtj_tiled, dim3(p->n_tiles), dim3(TILE_BLOCK), lds, st, a);
     BA_HIP(hipGetLastError());
     if (timed) {
         BA_HIP(hipEventRecord(p->ev_end[p->ev_count], st));

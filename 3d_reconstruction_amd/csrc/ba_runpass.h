@@ -1,0 +1,178 @@
+// Observation pass on LDS tiles in "camera-run" layout (internal).
+//
+// A tile is a range of consecutive points with all their observations (about 2000 of them), its
+// points and camera rows staged in LDS.  Inside the tile the observations are regrouped by camera
+// and cut into RUNS of up to 8 observations of ONE camera; a thread owns a run.  That choice
+// decides where the two reductions of the pass happen:
+//   * per camera (6 sums for the gradient, 33 with the J^T J blocks): in the owning thread's
+//     registers over the run, flushed once per run to the tile's LDS accumulators;
+//   * per point (3 / 12 sums): LDS atomics straight from the lanes.  Lanes of a wave hold
+//     different points of (mostly) the same camera, so the addresses differ and the atomics do not
+//     serialise - the opposite of the point-major order, where the lanes of a wave share cameras
+//     and the 6 / 33 camera sums collide.
+// Records are stored per tile as 8 planes of n_runs entries (plane k holds the k-th observation
+// of every run), so lane r of a wave reads consecutive addresses in every plane: the record
+// stream stays fully coalesced although each thread walks its own run.  A camera's last run is
+// padded with empty records (pack = 0xffffffff).
+//
+// Point data in LDS is indexed through pt_swz(): consecutive runs of a camera hold points 8 apart,
+// which would land on two banks only.
+#pragma once
+
+#include "ba_device.h"
+
+namespace ba {
+
+constexpr int RUN_LEN = 8;
+constexpr uint32_t RUN_EMPTY = 0xffffffffu;
+
+struct RunArgs {
+    const uint32_t *rpack;    // per record: (point index - tile's first point) << 16 | camera slot
+    const double2 *ruv;       // pixel centre
+    const int64_t *run_ptr;   // n_tiles + 1: first run of every tile
+    const TileMeta *meta;     // n_tiles
+    const int32_t *cam_list;  // distinct cameras of every tile, ascending
+    int K;
+    int cam_cap;              // LDS capacity in cameras (max over tiles)
+    int pt_stride;            // S: LDS capacity in points is 8 * S
+    int cam_rep;              // copies of the camera accumulators (power of two)
+    const double *X;
+    const double *T;
+    const double *scalars;
+    double *out[3];           // per-point outputs (see the Op), any may be null
+    double *cam_sums;         // Op::NCV x K, component-major, accumulated with atomics
+    double *partials;         // Op::NPART per tile
+};
+
+__device__ __forceinline__ int pt_swz(int p, int S) { return (p & 7) * S + (p >> 3); }
+
+// LDS doubles a workgroup of the pass needs
+template <class Op>
+__host__ __device__ inline size_t run_pass_lds_doubles(int cam_cap, int pt_stride, int rep) {
+    return (size_t)cam_cap * ROW_LDS + (size_t)cam_cap * Op::NCV * rep + (size_t)(3 + Op::NPV) * 8 * pt_stride;
+}
+
+// Op supplies:  Op(scalars), NCV, NPV, NPART, NOUT, out_width(o), out_offset(o) (slices of the per-point sums),
+//   obs(x[3], rw[6], uv, cv[NCV] (+=), pv[NPV] (=), part[NPART] (+=))
+template <class Op>
+__global__ void __launch_bounds__(TILE_BLOCK) k_run_pass(RunArgs a) {
+    constexpr int NCV = Op::NCV, NPV = Op::NPV, NPART = Op::NPART;
+    extern __shared__ double lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int t = blockIdx.x;
+    const TileMeta tm = a.meta[t];
+    const int p0 = tm.p0, np = tm.np, nc = tm.nc;
+    const int64_t cb = tm.cb;
+    const int64_t rb = a.run_ptr[t];
+    const int nruns = (int)(a.run_ptr[t + 1] - rb);
+    __shared__ double red[NPART][TILE_WAVES];
+    if (nruns == 0) {
+        if (tid < NPART) a.partials[NPART * (int64_t)t + tid] = 0.0;
+        return;
+    }
+    // this thread's first run: issue the record loads before anything else
+    uint32_t pk[RUN_LEN];
+    double2 uv[RUN_LEN];
+    {
+        const int r = tid < nruns ? tid : nruns - 1;
+        const int64_t base = rb * RUN_LEN + r;
+#pragma unroll
+        for (int k = 0; k < RUN_LEN; ++k) {
+            pk[k] = a.rpack[base + (int64_t)k * nruns];
+            uv[k] = a.ruv[base + (int64_t)k * nruns];
+        }
+    }
+
+    const int rep = a.cam_rep, S = a.pt_stride, PS = 8 * S;
+    double *rows = lds;                                         // cam_cap x ROW_LDS
+    double *cacc = rows + (size_t)a.cam_cap * ROW_LDS;          // rep x NCV x nc (component-major)
+    double *xs = cacc + (size_t)a.cam_cap * NCV * rep;          // 3 x PS (component-major, swizzled)
+    double *pacc = xs + 3 * (size_t)PS;                         // NPV x PS
+
+    for (int idx = tid; idx < nc * (ROW_LDS / 2); idx += TILE_BLOCK) {
+        const int row = idx / (ROW_LDS / 2), piece = idx - row * (ROW_LDS / 2);
+        const int j = tm.j0 >= 0 ? tm.j0 + row : a.cam_list[cb + row];
+        ((double2 *)rows)[idx] = ((const double2 *)(a.T + (int64_t)j * CAM_ROW))[piece];
+    }
+    for (int idx = tid; idx < NCV * nc * rep; idx += TILE_BLOCK) cacc[idx] = 0.0;
+    for (int idx = tid; idx < 3 * np; idx += TILE_BLOCK) {
+        const int pt = idx / 3, comp = idx - 3 * pt;
+        xs[comp * PS + pt_swz(pt, S)] = a.X[3 * (int64_t)p0 + idx];
+    }
+    for (int idx = tid; idx < NPV * PS; idx += TILE_BLOCK) pacc[idx] = 0.0;
+    double *cacc_lane = cacc + (size_t)(lane & (rep - 1)) * NCV * nc;
+    const Op op(a.scalars);
+    __syncthreads();
+
+    double part[NPART];
+#pragma unroll
+    for (int k = 0; k < NPART; ++k) part[k] = 0.0;
+
+    for (int r = tid; r < nruns; r += TILE_BLOCK) {
+        if (r != tid) {
+            const int64_t base = rb * RUN_LEN + r;
+#pragma unroll
+            for (int k = 0; k < RUN_LEN; ++k) {
+                pk[k] = a.rpack[base + (int64_t)k * nruns];
+                uv[k] = a.ruv[base + (int64_t)k * nruns];
+            }
+        }
+        const int slot = (int)(pk[0] & 0xffffu);   // a run is never empty and has one camera
+        double2 rw[6];
+        {
+            const double2 *src = (const double2 *)(rows + slot * ROW_LDS);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) rw[k] = src[k];
+        }
+        double cv[NCV];
+#pragma unroll
+        for (int k = 0; k < NCV; ++k) cv[k] = 0.0;
+#pragma unroll
+        for (int k = 0; k < RUN_LEN; ++k) {
+            if (pk[k] != RUN_EMPTY) {
+                const int sw = pt_swz((int)(pk[k] >> 16), S);
+                const double x[3] = {xs[sw], xs[PS + sw], xs[2 * PS + sw]};
+                double pv[NPV];
+                op.obs(x, rw, uv[k], cv, pv, part);
+#pragma unroll
+                for (int v = 0; v < NPV; ++v)
+                    __hip_atomic_fetch_add(pacc + v * PS + sw, pv[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        double *acc = cacc_lane + slot;
+#pragma unroll
+        for (int k = 0; k < NCV; ++k)
+            __hip_atomic_fetch_add(acc + k * nc, cv[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+
+#pragma unroll
+    for (int k = 0; k < NPART; ++k) {
+        const double v = wave_sum(part[k]);
+        if (lane == 0) red[k][wid] = v;
+    }
+    __syncthreads();
+    if (tid < NPART) a.partials[NPART * (int64_t)t + tid] = (red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]);
+
+    // every point is written by exactly one tile: its own points and the unobserved ones up to the
+    // next tile's first point (zeros)
+    const int lo = tm.wlo - p0, hi = tm.whi - p0;
+#pragma unroll
+    for (int o = 0; o < Op::NOUT; ++o) {
+        double *dst = a.out[o];
+        if (!dst) continue;
+        const int w = Op::out_width(o), off = Op::out_offset(o);
+        for (int idx = w * lo + tid; idx < w * hi; idx += TILE_BLOCK) {
+            const int pt = idx >= 0 ? idx / w : -1, k = idx - w * pt;
+            dst[(int64_t)w * p0 + idx] = (idx >= 0 && pt < np) ? pacc[(off + k) * PS + pt_swz(pt, S)] : 0.0;
+        }
+    }
+    for (int idx = tid; idx < NCV * nc; idx += TILE_BLOCK) {
+        const int comp = idx / nc, slot = idx - comp * nc;
+        const int j = tm.j0 >= 0 ? tm.j0 + slot : a.cam_list[cb + slot];
+        double v = cacc[idx];
+        for (int r = 1; r < rep; ++r) v += cacc[idx + (size_t)r * NCV * nc];
+        __hip_atomic_fetch_add(a.cam_sums + (int64_t)comp * a.K + j, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+}  // namespace ba

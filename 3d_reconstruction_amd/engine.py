@@ -175,12 +175,14 @@ class Shard:
         self._table_cam = None
 
     # ---- kernels ----------------------------------------------------------------------------
-    def eval(self, grad_x=True, grad_cam=True, grad_phi=True, timed=False, cam_atomics=False, untiled=False):
+    def eval(self, grad_x=True, grad_cam=True, grad_phi=True, timed=False, cam_atomics=False, untiled=False,
+             point_major=False):
         """Queues one fused observation pass at the current parameters.  Leaves un-normalised
         gradients in gX / red and posts the energy sum for `wait_energy()`."""
         flags = (_lib.EVAL_GRAD_X if grad_x else 0) | (_lib.EVAL_GRAD_CAM if grad_cam else 0) | \
                 (_lib.EVAL_GRAD_PHI if grad_phi else 0) | (_lib.EVAL_TIMED if timed else 0) | \
                 (_lib.EVAL_CAM_ATOMICS if cam_atomics else 0) | (_lib.EVAL_UNTILED if untiled else 0) | \
+                (_lib.EVAL_POINT_MAJOR if point_major else 0) | \
                 (_lib.EVAL_REUSE_TABLE if self._table_cam is self.cam else 0) | \
                 (0 if self.distributed else _lib.EVAL_POST)
         c = self.cam.data_ptr()
@@ -278,10 +280,11 @@ class Shard:
             self.S, self.rhs = z(self.ld_red, self.ld_red), z(self.ld_red)
             self.dX, self.dcam = z(self.N, 3), z(6 * self.K + 1)
 
-    def eval_jtj(self, timed=False):
+    def eval_jtj(self, timed=False, point_major=False):
         """Fused pass that also leaves the Gauss-Newton blocks V, Xphi, B, bphi, hphi."""
         self._lm_buffers()
-        flags = (_lib.EVAL_TIMED if timed else 0) | (_lib.EVAL_REUSE_TABLE if self.table_valid else 0)
+        flags = (_lib.EVAL_TIMED if timed else 0) | (_lib.EVAL_REUSE_TABLE if self.table_valid else 0) | \
+                (_lib.EVAL_POINT_MAJOR if point_major else 0)
         with torch.cuda.device(self.device):
             check(self.lib.ba_eval_jtj(self.handle, ptr(self.X), ptr(self.C), ptr(self.Theta), ptr(self.phi), flags,
                                        ptr(self.E_sum), ptr(self.gX), ptr(self.gC), ptr(self.gTheta), ptr(self.gphi),

@@ -46,7 +46,8 @@ enum ba_eval_flags {
     BA_EVAL_UNTILED = 512,  /* use the wave-chunk kernel even when the scene has LDS tiles */
     BA_EVAL_REUSE_TABLE = 1024, /* the handle's camera table already describes C, Theta, phi (left there by
                                   ba_camera_step); skip rebuilding it */
-    BA_EVAL_POST = 2048     /* also post E_sum to the handle's host mailbox (see ba_wait_energy) */
+    BA_EVAL_POST = 2048,    /* also post E_sum to the handle's host mailbox (see ba_wait_energy) */
+    BA_EVAL_POINT_MAJOR = 4096 /* use the point-major tile kernel instead of the camera-run one */
 };
 
 const char *ba_last_error(void);

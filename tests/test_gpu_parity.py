@@ -5,6 +5,7 @@ Tolerances (the contract): energy and gradients within 1e-9 relative per evaluat
 reference's own iterates (teacher-forced), final parameters within 1e-6 after a fixed free run,
 visibility indexing bit-exact."""
 import io
+import os
 import contextlib
 
 import numpy as np
@@ -64,8 +65,8 @@ def _eval_all(ba, sh, nv, **kw):
             sh.gphi.cpu().numpy() / nv)
 
 
-@pytest.mark.parametrize('variant', [dict(), dict(untiled=True), dict(cam_atomics=True)],
-                         ids=['lds-tiles', 'wave-chunks', 'global-atomics'])
+@pytest.mark.parametrize('variant', [dict(), dict(point_major=True), dict(untiled=True), dict(cam_atomics=True)],
+                         ids=['camera-runs', 'point-major-tiles', 'wave-chunks', 'global-atomics'])
 def test_eval_teacher_forced_moscow(ba, golden, variant):
     g = golden('f2_moscow_ride.npz')
     W, H = int(g['W']), int(g['H'])
@@ -114,10 +115,15 @@ def test_eval_ragged_and_empty_points(ba):
     X = rng.normal(0, 1, (N, 3)) + np.array([0, 0, 30.0])
     uv = rng.uniform(0, 1000, (i.size, 2))
     E_ref, gX_r, gC_r, gT_r, gp_r = orc.energy_and_gradients(X, C, Th, np.array([1.1]), 1920, 1080, i, j, uv)
-    for reorder in (True, False):
-        sh = ba.engine.Shard(i, j, uv, N, K, 1920, 1080, DEV, reorder=reorder)
+    for reorder, force_tiles in ((True, False), (False, False), (True, True)):
+        if force_tiles:     # tiles even though they do not pay off on a scene like this
+            os.environ['BA_FORCE_TILES'] = '1'
+        try:
+            sh = ba.engine.Shard(i, j, uv, N, K, 1920, 1080, DEV, reorder=reorder)
+        finally:
+            os.environ.pop('BA_FORCE_TILES', None)
         sh.set_params(X, C, Th, 1.1)
-        for kw in (dict(), dict(untiled=True), dict(cam_atomics=True)):
+        for kw in (dict(), dict(point_major=True), dict(untiled=True), dict(cam_atomics=True)):
             sh.gX.fill_(123.0)       # stale content must not survive
             E, gX, gC, gT, gp = _eval_all(ba, sh, i.size, **kw)
             assert abs(E - E_ref) / E_ref < TOL, (reorder, kw)
@@ -228,6 +234,50 @@ def test_fit_scene_lr_events(ba, golden):
     assert rel_err(out[-1][:100], g['E'][:100]) < 1e-8
 
 
+def test_queued_updates_do_not_change_the_trajectory(ba, golden):
+    """The loop queues each update before it knows the energy and drops it when the LR schedule
+    intervenes; it must walk the same trajectory as the run that waits every time (up to the
+    summation-order noise of the floating-point atomics, which two identical runs also show)."""
+    g = golden('f3_lr_events.npz')
+    oi, oj, uv, _ = ba.engine.visibility_coo(g['X_pix'], DEV)
+    N, K = g['X_pix'].shape[:2]
+    runs = []
+    for spec in (True, False):
+        sh = ba.engine.Shard(oi, oj, uv, N, K, int(g['W']), int(g['H']), DEV)
+        sh.set_params(g['X_0'], g['C_0'], g['Theta_0'], float(g['phi_x_0']))
+        fit = ba.SceneFit(sh, 1e-3, 200, patience=20, printer=lambda *a: None, speculate=spec).run()
+        runs.append((fit.energies(), sh.X.cpu().numpy(), sh.cam.cpu().numpy(), fit.dropped))
+        sh.close()
+    assert runs[0][3] > 0 and runs[1][3] == 0          # the schedule did overrule queued updates
+    assert runs[0][0].shape == runs[1][0].shape
+    assert rel_err(runs[0][0][:100], runs[1][0][:100]) < 1e-9
+    assert rel_err(runs[0][0], g['E']) < 1e-6
+
+
+def test_step_update_in_place_equals_out_of_place(ba, golden):
+    import torch
+    g = golden('f6_medium.npz')
+    N, K = int(g['N']), int(g['K'])
+    sh = ba.engine.Shard(g['obs_i'], g['obs_j'], g['obs_xy'] + 0.5, N, K, int(g['W']), int(g['H']), DEV)
+    sh.set_params(g['X_0'], g['C_0'], g['Theta_0'], float(g['phi_x_0']))
+    sh.gauge_fix()
+    X0, cam0 = sh.X.clone(), sh.cam.clone()
+    mx = (torch.full_like(sh.X, 1e-3), torch.full_like(sh.X, 1e-5))
+    mc = (torch.full_like(sh.cam, 1e-3), torch.full_like(sh.cam, 1e-5))
+    sh.eval()
+    assert sh.wait_energy() == sh.energy()
+    args = (2, 1e-3, 0.1, 0.001, True, (0, 6 * K + 1))
+    X, cam, mx2, mc2 = sh.step_update(*args, mx, mc, True)
+    assert torch.equal(sh.X, X0) and torch.equal(sh.cam, cam0)          # inputs untouched
+    assert float(mx[0].max()) == 1e-3 and float(mc[1].min()) == 1e-5
+    assert not torch.equal(X, X0)
+    Xi, cami, mxi, mci = sh.step_update(*args, mx, mc, True, in_place=True)
+    assert Xi is sh.X and cami is sh.cam and mxi[0] is mx[0] and mci[1] is mc[1]
+    for a, b in ((X, Xi), (cam, cami), (mx2[0], mxi[0]), (mx2[1], mxi[1]), (mc2[0], mci[0]), (mc2[1], mci[1])):
+        assert torch.equal(a, b)
+    sh.close()
+
+
 def test_fit_scene_errors_match_reference_messages(ba, golden):
     g = golden('f1_tiny_masks.npz')
     args = [g['X_pix'], int(g['W']), int(g['H']), 1e-3, 5, g['X_0'], g['C_0'], g['Theta_0'], float(g['phi_x_0'])]
@@ -283,7 +333,7 @@ def test_full_size_invariants(ba):
     tot = gX.sum(0) + sh.gC.sum(0)
     assert float(tot.abs().max()) < 1e-7 * float(gX.abs().sum())
     # the three forms of the pass agree (different summation orders only)
-    for kw in (dict(untiled=True), dict(cam_atomics=True)):
+    for kw in (dict(point_major=True), dict(untiled=True), dict(cam_atomics=True)):
         sh.eval(**kw)
         assert abs(sh.energy() - E1) / E1 < 1e-12
         assert float((sh.red - red).abs().max()) <= 1e-10 * float(red.abs().max())

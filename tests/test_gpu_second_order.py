@@ -24,10 +24,11 @@ def _scene(ba, N=300, K=80, seed=4):
     return sc, sh, r, J
 
 
-def test_jtj_blocks_match_dense_normal_equations(ba):
+@pytest.mark.parametrize('point_major', [False, True], ids=['camera-runs', 'point-major-tiles'])
+def test_jtj_blocks_match_dense_normal_equations(ba, point_major):
     sc, sh, r, J = _scene(ba)
     N, K = sc['N_local'], sc['K']
-    sh.eval_jtj()
+    sh.eval_jtj(point_major=point_major)
     H, g = J.T @ J, J.T @ r
     back = lambda t: sh.points_to_caller(t).cpu().numpy()
     assert abs(float(sh.E_sum.item()) - r @ r) / (r @ r) < 1e-12
