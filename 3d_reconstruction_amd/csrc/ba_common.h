@@ -72,8 +72,10 @@ struct ba_problem {
     uint32_t *opack = nullptr;        // nV: (point - tile's first point) << 16 | camera slot in the tile's list
     void *tile_meta = nullptr;        // n_tiles x TileMeta
     // camera-run layout of the tiles (see ba_runpass.h); null when the scene does not tile
+    int compact = 0;                  // every pixel centre is int16 + 0.5: 8-byte records (rrec), else rpack + ruv
     uint32_t *rpack = nullptr;        // total_runs x 8 records
     double2 *ruv = nullptr;
+    uint2 *rrec = nullptr;
     int64_t *run_ptr = nullptr;       // n_tiles + 1
     int64_t total_runs = 0;
     int run_pt_stride = 0;            // LDS point capacity / 8

@@ -153,14 +153,21 @@ __global__ void k_scan_add(int64_t *__restrict__ out, int64_t n, const int64_t *
 // --------------------------------------------------------------------------------------------
 // problem set-up kernels
 // --------------------------------------------------------------------------------------------
-// flag bit 0: index out of range, bit 1: not sorted by point
-__global__ void k_validate_obs(const int32_t *__restrict__ oi, const int32_t *__restrict__ oj, int64_t nV, int64_t N,
-                               int64_t K, int *flag, unsigned long long *heads) {
+// flag bit 0: index out of range, bit 1: not sorted by point, bit 2: some pixel centre is not
+// (integer in (-32768, 32767]) + 0.5
+__global__ void k_validate_obs(const int32_t *__restrict__ oi, const int32_t *__restrict__ oj,
+                               const double2 *__restrict__ ouv, int64_t nV, int64_t N, int64_t K, int *flag,
+                               unsigned long long *heads) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool head = false;
     if (e < nV) {
         const int i = oi[e], j = oj[e];
         if (i < 0 || i >= N || j < 0 || j >= K) atomicOr(flag, 1);
+        const double2 uv = ouv[e];
+        const double px = uv.x - 0.5, py = uv.y - 0.5;
+        const bool fits = px == floor(px) && py == floor(py) && px > -32768.0 && px <= 32767.0 && py > -32768.0 &&
+                          py <= 32767.0;
+        if (!fits) atomicOr(flag, 4);
         if (e > 0) {
             const int ip = oi[e - 1];
             if (ip > i) atomicOr(flag, 2);
@@ -739,8 +746,8 @@ struct GradOp {
     double f, pcx, pcy;
     __device__ explicit GradOp(const double *scalars) : f(scalars[SC_F]), pcx(scalars[SC_CX]), pcy(scalars[SC_CY]) {}
     // cv: camera-frame force (3) and torque (3); pv: world-frame dE/dX_i part; part: r.r, m.r
-    __device__ __forceinline__ void obs(const double (&x)[3], const double2 (&rw)[6], double2 uv, double (&cv)[6],
-                                        double (&pv)[3], double (&part)[2]) const {
+    __device__ __forceinline__ void obs(bool valid, const double (&x)[3], const double2 (&rw)[6], double2 uv,
+                                        double (&cv)[6], double (&pv)[3], double (&part)[2]) const {
         const double R00 = rw[0].x, R01 = rw[0].y, R02 = rw[1].x, R10 = rw[1].y, R11 = rw[2].x, R12 = rw[2].y,
                      R20 = rw[3].x, R21 = rw[3].y, R22 = rw[4].x;
         const double d0 = x[0] - rw[4].y, d1 = x[1] - rw[5].x, d2 = x[2] - rw[5].y;
@@ -749,8 +756,8 @@ struct GradOp {
         const double q2 = R02 * d0 + R12 * d1 + R22 * d2;
         const double inv = 1.0 / q2;
         const double m0 = q0 * inv, m1 = q1 * inv;
-        const double r0 = f * m0 + pcx - uv.x;
-        const double r1 = f * m1 + pcy - uv.y;
+        const double r0 = valid ? f * m0 + pcx - uv.x : 0.0;
+        const double r1 = valid ? f * m1 + pcy - uv.y : 0.0;
         part[0] += r0 * r0 + r1 * r1;
         const double mr = m0 * r0 + m1 * r1;
         part[1] += mr;
@@ -790,21 +797,24 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_run_count(const uint32_t *__rest
     }
 }
 
-// Pass 2: every camera of the tile copies its observations, in point order, into its runs.
-// LDS: per-camera counts, then first runs (nc + 1), then the tile's packed records.
+// Pass 2: every camera of the tile copies its observations, in point order, into its runs (order of
+// the runs and of the observations inside a run: see ba_runpass.h).
+// LDS: runs per camera (nc), first run of every batch of 8 cameras, then the tile's packed records.
 __global__ void __launch_bounds__(TILE_BLOCK) k_run_fill(const uint32_t *__restrict__ opack,
                                                          const double2 *__restrict__ ouv,
                                                          const TileMeta *__restrict__ meta,
                                                          const int64_t *__restrict__ run_ptr, int cam_cap,
-                                                         uint32_t *__restrict__ rpack, double2 *__restrict__ ruv) {
+                                                         uint32_t *__restrict__ rpack, double2 *__restrict__ ruv,
+                                                         uint2 *__restrict__ rrec) {
     extern __shared__ int sm[];
-    int *hist = sm, *first = sm + cam_cap;
-    uint32_t *spack = (uint32_t *)(sm + 2 * cam_cap + 1);
+    int *hist = sm, *batch_first = sm + cam_cap;
+    const int n_batches_cap = (cam_cap + 7) / 8;
+    uint32_t *spack = (uint32_t *)(sm + cam_cap + n_batches_cap + 1);
     const TileMeta tm = meta[blockIdx.x];
-    const int n = tm.e1 - tm.e0;
+    const int n = tm.e1 - tm.e0, nc = tm.nc;
     const int64_t rb = run_ptr[blockIdx.x];
     const int nruns = (int)(run_ptr[blockIdx.x + 1] - rb);
-    for (int c = threadIdx.x; c < tm.nc; c += TILE_BLOCK) hist[c] = 0;
+    for (int c = threadIdx.x; c < nc; c += TILE_BLOCK) hist[c] = 0;
     __syncthreads();
     for (int e = threadIdx.x; e < n; e += TILE_BLOCK) {
         const uint32_t pk = opack[tm.e0 + e];
@@ -812,24 +822,59 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_run_fill(const uint32_t *__restr
         atomicAdd(&hist[pk & 0xffffu], 1);
     }
     __syncthreads();
+    for (int c = threadIdx.x; c < nc; c += TILE_BLOCK) hist[c] = (hist[c] + RUN_LEN - 1) / RUN_LEN;   // runs
+    __syncthreads();
     if (threadIdx.x == 0) {
         int acc = 0;
-        for (int c = 0; c < tm.nc; ++c) {
-            first[c] = acc;
-            acc += (hist[c] + RUN_LEN - 1) / RUN_LEN;
+        for (int b = 0; 8 * b < nc; ++b) {
+            batch_first[b] = acc;
+            for (int c = 8 * b; c < nc && c < 8 * b + 8; ++c) acc += hist[c];
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < tm.nc; c += TILE_BLOCK) {
-        int q = 0;
-        const int f0 = first[c];
+    for (int c = threadIdx.x; c < nc; c += TILE_BLOCK) {
+        const int b = c >> 3, c_lo = 8 * b, c_hi = min(nc, c_lo + 8);
+        const int my_runs = hist[c];
+        // position of (c, rho): runs of the batch in earlier rounds + cameras before c still running in rho
+        auto run_index = [&](int rho) {
+            int pos = batch_first[b];
+            for (int o = c_lo; o < c_hi; ++o) pos += min(hist[o], rho) + ((o < c && hist[o] > rho) ? 1 : 0);
+            return pos;
+        };
+        int q = 0, rho = -1, run = 0;
+        uint32_t first_pk = 0;
         for (int e = 0; e < n; ++e) {
             const uint32_t pk = spack[e];
             if ((int)(pk & 0xffffu) != c) continue;
-            const int64_t idx = rb * RUN_LEN + (int64_t)(q % RUN_LEN) * nruns + f0 + q / RUN_LEN;
-            rpack[idx] = pk;
-            ruv[idx] = ouv[tm.e0 + e];
+            if ((q % RUN_LEN) == 0) {
+                ++rho;
+                run = run_index(rho);
+                first_pk = pk;
+            }
+            const int plane = ((q % RUN_LEN) - c) & (RUN_LEN - 1);
+            const int64_t idx = rb * RUN_LEN + (int64_t)plane * nruns + run;
+            const uint32_t word = (pk & 0xffff0000u) | ((uint32_t)(rho & 15) << RUN_SLOT_BITS) | (uint32_t)c;
+            const double2 uv = ouv[tm.e0 + e];
+            if (rrec) {
+                const int px = (int)(uv.x - 0.5), py = (int)(uv.y - 0.5);
+                rrec[idx] = make_uint2(word, ((uint32_t)px & 0xffffu) | ((uint32_t)py << 16));
+            } else {
+                rpack[idx] = word;
+                ruv[idx] = uv;
+            }
             ++q;
+        }
+        // zero-weight records up to the end of the camera's last run
+        for (; my_runs > 0 && q < my_runs * RUN_LEN; ++q) {
+            const int plane = ((q % RUN_LEN) - c) & (RUN_LEN - 1);
+            const int64_t idx = rb * RUN_LEN + (int64_t)plane * nruns + run;
+            const uint32_t word = (first_pk & 0xffff0000u) | ((uint32_t)(rho & 15) << RUN_SLOT_BITS) | (uint32_t)c;
+            if (rrec) {
+                rrec[idx] = make_uint2(word, 0x8000u);
+            } else {
+                rpack[idx] = word;
+                ruv[idx] = make_double2(__longlong_as_double(0x7ff8000000000000ll), 0.0);
+            }
         }
     }
 }
@@ -1556,26 +1601,29 @@ static int build_runs(ba_problem *p) {
     hipError_t e = hipMemcpy(&p->total_runs, p->run_ptr + nt, sizeof(int64_t), hipMemcpyDeviceToHost);
     hipFree(tile_sums);
     BA_HIP(e);
-    const size_t fill_lds = sizeof(int) * (2 * (size_t)p->cam_cap + 1) + sizeof(uint32_t) * (size_t)h_max_obs;
-    if (fill_lds > 64 * 1024 || p->total_runs == 0) {   // leave the point-major tiles in charge
+    const size_t fill_lds = sizeof(int) * ((size_t)p->cam_cap + (p->cam_cap + 7) / 8 + 1) + sizeof(uint32_t) * (size_t)h_max_obs;
+    if (fill_lds > 64 * 1024 || p->total_runs == 0 || p->cam_cap > RUN_MAX_CAMS) {   // leave the point-major tiles in charge
         hipFree(p->run_ptr);
         p->run_ptr = nullptr;
         p->total_runs = 0;
         return BA_OK;
     }
     const size_t n_rec = (size_t)p->total_runs * RUN_LEN;
-    BA_HIP(hipMalloc(&p->rpack, sizeof(uint32_t) * n_rec));
-    BA_HIP(hipMalloc(&p->ruv, sizeof(double2) * n_rec));
-    BA_HIP(hipMemset(p->rpack, 0xff, sizeof(uint32_t) * n_rec));
-    BA_HIP(hipMemset(p->ruv, 0, sizeof(double2) * n_rec));
+    if (p->compact) {
+        BA_HIP(hipMalloc(&p->rrec, sizeof(uint2) * n_rec));
+    } else {
+        BA_HIP(hipMalloc(&p->rpack, sizeof(uint32_t) * n_rec));
+        BA_HIP(hipMalloc(&p->ruv, sizeof(double2) * n_rec));
+    }
     hipLaunchKernelGGL(k_run_fill, dim3(nt), dim3(TILE_BLOCK), fill_lds, 0, p->opack, p->ouv,
-                       (const TileMeta *)p->tile_meta, p->run_ptr, p->cam_cap, p->rpack, p->ruv);
+                       (const TileMeta *)p->tile_meta, p->run_ptr, p->cam_cap, p->rpack, p->ruv, p->rrec);
     BA_HIP(hipGetLastError());
-    p->run_pt_stride = ((p->pt_cap + 7) / 8) | 1;
+    p->run_pt_stride = (p->pt_cap + 7) / 8;
+    while ((p->run_pt_stride & 3) != 2) ++p->run_pt_stride;   // 2 * odd, see pt_swz
     // copies of the camera accumulators: as many as keep the workgroup near a quarter of the LDS budget
     const size_t budget = 64 * 1024;
     auto pick_rep = [&](int ncv, int npv, size_t limit, const char *env_name) {
-        int rep = 8;
+        int rep = 2;
         if (const char *env = getenv(env_name)) rep = atoi(env);
         if (rep < 1) rep = 1;
         while (rep > 1 && sizeof(double) * ((size_t)p->cam_cap * (ROW_LDS + ncv * rep) +
@@ -1586,8 +1634,8 @@ static int build_runs(ba_problem *p) {
     p->run_rep_grad = pick_rep(6, 3, budget / 2, "BA_CAM_REP");
     p->run_rep_jtj = pick_rep(33, 12, 78 * 1024, "BA_CAM_REP_JTJ");   // two workgroups per CU
     if (getenv("BA_VERBOSE"))
-        fprintf(stderr, "[ba] runs: total=%lld (%.3f x nV/8) pt_stride=%d rep_grad=%d rep_jtj=%d\n",
-                (long long)p->total_runs, (double)p->total_runs * RUN_LEN / (double)p->nV, p->run_pt_stride,
+        fprintf(stderr, "[ba] runs: records=%s total=%lld (%.3f x nV/8) pt_stride=%d rep_grad=%d rep_jtj=%d\n",
+                p->compact ? "i16" : "f64", (long long)p->total_runs, (double)p->total_runs * RUN_LEN / (double)p->nV, p->run_pt_stride,
                 p->run_rep_grad, p->run_rep_jtj);
     return BA_OK;
 }
@@ -1740,6 +1788,7 @@ int ba_problem_destroy(ba_problem *p) {
     hipFree(p->opack);
     hipFree(p->tile_meta);
     hipFree(p->rpack);
+    hipFree(p->rrec);
     hipFree(p->ruv);
     hipFree(p->run_ptr);
     hipFree(p->cam_table);
@@ -1801,7 +1850,7 @@ int ba_problem_create(int64_t N, int64_t K, int64_t nV, const int32_t *i, const 
     // validation + number of distinct points
     BA_TRY(hipMalloc(&p->flag, 16));
     BA_TRY(hipMemset(p->flag, 0, 16));
-    hipLaunchKernelGGL(k_validate_obs, dim3(cdiv(nV, 256)), dim3(256), 0, 0, p->oi, p->oj, nV, N, K, p->flag,
+    hipLaunchKernelGGL(k_validate_obs, dim3(cdiv(nV, 256)), dim3(256), 0, 0, p->oi, p->oj, p->ouv, nV, N, K, p->flag,
                        (unsigned long long *)(p->flag + 2));
     BA_TRY(hipGetLastError());
     struct {
@@ -1818,6 +1867,10 @@ int ba_problem_create(int64_t N, int64_t K, int64_t nV, const int32_t *i, const 
         return fail(BA_ERR_ARG);
     }
     p->n_points_seen = (int64_t)h.heads;
+    p->compact = !(h.flag & 4);
+    if (const char *env = getenv("BA_RECORDS")) {   // "f64" forces the long records (diagnostics)
+        if (!strcmp(env, "f64")) p->compact = 0;
+    }
 
     // launch geometry: one workgroup of 16 waves per compute unit, every wave walks whole chunks
     // of ~768 observations whose boundaries fall on point boundaries
@@ -1918,12 +1971,13 @@ int ba_eval(ba_problem *p, const double *X, const double *C, const double *Theta
     const bool use_lds = !(flags & BA_EVAL_CAM_ATOMICS) && lds_bytes <= (size_t)p->lds_limit;
     const bool timed = (flags & BA_EVAL_TIMED) != 0 && p->ev_count < TIMING_RING;
     int n_partials = p->grid * EVAL_WAVES;
-    const bool use_runs = use_tiles && p->rpack && !(flags & BA_EVAL_POINT_MAJOR) && a.debug == 0;
+    const bool use_runs = use_tiles && p->run_ptr && !(flags & BA_EVAL_POINT_MAJOR) && a.debug == 0;
     if (timed) BA_HIP(hipEventRecord(p->ev_begin[p->ev_count], st));
     if (use_runs) {
         RunArgs ra;
         ra.rpack = p->rpack;
         ra.ruv = p->ruv;
+        ra.rrec = p->rrec;
         ra.run_ptr = p->run_ptr;
         ra.meta = (const TileMeta *)p->tile_meta;
         ra.cam_list = p->cam_list;
@@ -1940,10 +1994,10 @@ int ba_eval(ba_problem *p, const double *X, const double *C, const double *Theta
         ra.partials = p->partials;
         n_partials = p->n_tiles;
         const size_t lds = sizeof(double) * run_pass_lds_doubles<GradOp>(p->cam_cap, p->run_pt_stride, p->run_rep_grad);
-        if (lds > 64 * 1024)
-            BA_HIP(hipFuncSetAttribute((const void *)k_run_pass<GradOp>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds));
-        hipLaunchKernelGGL(k_run_pass<GradOp>, dim3(p->n_tiles), dim3(TILE_BLOCK), lds, st, ra);
+        const void *fn = p->compact ? (const void *)k_run_pass<GradOp, RecI16> : (const void *)k_run_pass<GradOp, RecF64>;
+        if (lds > 64 * 1024) BA_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (p->compact) hipLaunchKernelGGL((k_run_pass<GradOp, RecI16>), dim3(p->n_tiles), dim3(TILE_BLOCK), lds, st, ra);
+        else hipLaunchKernelGGL((k_run_pass<GradOp, RecF64>), dim3(p->n_tiles), dim3(TILE_BLOCK), lds, st, ra);
     } else if (use_tiles) {
         TileArgs ta;
         ta.opack = p->opack;

@@ -236,13 +236,14 @@ struct JtjOp {
     double f, pcx, pcy, dphi;
     __device__ explicit JtjOp(const double *scalars)
         : f(scalars[SC_F]), pcx(scalars[SC_CX]), pcy(scalars[SC_CY]), dphi(scalars[SC_DPHI]) {}
-    __device__ __forceinline__ void obs(const double (&x)[3], const double2 (&rw)[6], double2 uv, double (&cv)[CAMV],
-                                        double (&pv)[PTV], double (&part)[3]) const {
-        const ObsJac o = obs_jacobian(x, rw, f, pcx, pcy, uv);
-        const double r0 = o.r0, r1 = o.r1;
+    __device__ __forceinline__ void obs(bool valid, const double (&x)[3], const double2 (&rw)[6], double2 uv,
+                                        double (&cv)[CAMV], double (&pv)[PTV], double (&part)[3]) const {
+        // a zero-weight record acts through f = 0: every Jacobian entry carries the factor f / q2
+        const ObsJac o = obs_jacobian(x, rw, valid ? f : 0.0, pcx, pcy, uv);
+        const double r0 = valid ? o.r0 : 0.0, r1 = valid ? o.r1 : 0.0;
         part[0] += r0 * r0 + r1 * r1;
         part[1] += o.m0 * r0 + o.m1 * r1;
-        part[2] += o.m0 * o.m0 + o.m1 * o.m1;
+        part[2] += valid ? o.m0 * o.m0 + o.m1 * o.m1 : 0.0;
         // G0[1] = G1[0] = 0 and G0[0] = G1[1] = -fi: the products with them are written out
         const double fi = o.fi;
         cv[0] += fi * r0;
@@ -821,7 +822,7 @@ int ba_eval_jtj(ba_problem *p, const double *X, const double *C, const double *T
     hipStream_t st = (hipStream_t)stream;
     const int64_t K = p->K;
     const size_t lds_runs = sizeof(double) * run_pass_lds_doubles<JtjOp>(p->cam_cap, p->run_pt_stride, p->run_rep_jtj);
-    const bool use_runs = p->rpack && !(flags & BA_EVAL_POINT_MAJOR) && lds_runs <= 160 * 1024 - 256;
+    const bool use_runs = p->run_ptr && !(flags & BA_EVAL_POINT_MAJOR) && lds_runs <= 160 * 1024 - 256;
     const size_t lds = use_runs ? lds_runs
                                 : sizeof(double) * ((size_t)(ROW_LDS + CAMV) * p->cam_cap + (size_t)(3 + PTV) * p->pt_cap);
     if (lds > 160 * 1024 - 256) {
@@ -852,6 +853,7 @@ int ba_eval_jtj(ba_problem *p, const double *X, const double *C, const double *T
     RunArgs ra;
     ra.rpack = p->rpack;
     ra.ruv = p->ruv;
+    ra.rrec = p->rrec;
     ra.run_ptr = p->run_ptr;
     ra.meta = a.meta;
     ra.cam_list = p->cam_list;
@@ -867,13 +869,17 @@ int ba_eval_jtj(ba_problem *p, const double *X, const double *C, const double *T
     ra.out[2] = Xphi;
     ra.cam_sums = p->cam_sums_jtj;
     ra.partials = p->partials_jtj;
-    if (lds > 64 * 1024)
-        BA_HIP(hipFuncSetAttribute(use_runs ? (const void *)k_run_pass<JtjOp> : (const void *)k_jtj_tiled,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const void *fn = !use_runs ? (const void *)k_jtj_tiled
+                     : p->compact ? (const void *)k_run_pass<JtjOp, RecI16> : (const void *)k_run_pass<JtjOp, RecF64>;
+    if (lds > 64 * 1024) BA_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const bool timed = (flags & BA_EVAL_TIMED) != 0 && p->ev_count < TIMING_RING;
     if (timed) BA_HIP(hipEventRecord(p->ev_begin[p->ev_count], st));
-    if (use_runs) hipLaunchKernelGGL(k_run_pass<JtjOp>, dim3(p->n_tiles), dim3(TILE_BLOCK), lds, st, ra);
-    else hipLaunchKernelGGL(k_jtj_tiled, dim3(p->n_tiles), dim3(TILE_BLOCK), lds, st, a);
+    if (use_runs && p->compact)
+        hipLaunchKernelGGL((k_run_pass<JtjOp, RecI16>), dim3(p->n_tiles), dim3(TILE_BLOCK), lds, st, ra);
+    else if (use_runs)
+        hipLaunchKernelGGL((k_run_pass<JtjOp, RecF64>), dim3(p->n_tiles), dim3(TILE_BLOCK), lds, st, ra);
+    else
+        hipLaunchKernelGGL(k_jtj_tiled, dim3(p->n_tiles), dim3(TILE_BLOCK), lds, st, a);
     BA_HIP(hipGetLastError());
     if (timed) {
         BA_HIP(hipEventRecord(p->ev_end[p->ev_count], st));

@@ -10,13 +10,22 @@
 //     different points of (mostly) the same camera, so the addresses differ and the atomics do not
 //     serialise - the opposite of the point-major order, where the lanes of a wave share cameras
 //     and the 6 / 33 camera sums collide.
-// Records are stored per tile as 8 planes of n_runs entries (plane k holds the k-th observation
-// of every run), so lane r of a wave reads consecutive addresses in every plane: the record
-// stream stays fully coalesced although each thread walks its own run.  A camera's last run is
-// padded with empty records (pack = 0xffffffff).
+// Records are stored per tile as 8 planes of n_runs entries (plane k holds one observation of
+// every run), so lane r of a wave reads consecutive addresses in every plane: the record stream
+// stays fully coalesced although each thread walks its own run.  A camera's last run is padded
+// with records of zero weight (a copy of a real record's point and camera, pixel x = NaN), so the
+// loop over a run has no branches and the eight bodies can overlap.
 //
-// Point data in LDS is indexed through pt_swz(): consecutive runs of a camera hold points 8 apart,
-// which would land on two banks only.
+// Order of the runs inside a tile: cameras are taken in batches of 8; inside a batch the runs go
+// round by round (round rho holds the rho-th run of each of the 8 cameras), and a run of camera c
+// stores its observations rotated by c (plane k holds observation (k + c) mod 8).  For tracks of
+// a video (every camera of the tile sees nearly every point of the tile, in order) the 16 lanes
+// the LDS serves per cycle then hold 8 cameras x 2 rounds and, in every plane, 16 different
+// points: the point atomics never collide, and two copies of the camera accumulators (selected by
+// the round's parity, stored in the record) keep the flush collision-free as well.
+//
+// Point data in LDS is indexed through pt_swz(): point p lives at (p mod 8) * S + p / 8 with
+// S = 2 * odd, which maps those 16 points to 16 different bank pairs.
 #pragma once
 
 #include "ba_device.h"
@@ -24,11 +33,38 @@
 namespace ba {
 
 constexpr int RUN_LEN = 8;
-constexpr uint32_t RUN_EMPTY = 0xffffffffu;
+constexpr int RUN_SLOT_BITS = 12;    // record: point << 16 | (round & 15) << 12 | camera slot
+constexpr int RUN_MAX_CAMS = 1 << RUN_SLOT_BITS;
+
+// Two record formats.  RecF64: the pack word and the pixel centre as two doubles (20 bytes).
+// RecI16: for pixel centres of the form integer + 0.5 with the integer in (-32768, 32767] - what
+// floor()-ed pixel tracks give - the pack word and both integers as int16 in one 8-byte word; the
+// stream is 2.5 times shorter.  Zero-weight records: x = NaN, resp. x = -32768.
+struct RunArgs;
+struct RecF64 {
+    struct raw_t {
+        uint32_t pack;
+        double2 uv;
+    };
+    static __device__ __forceinline__ raw_t load(const RunArgs &a, int64_t idx);
+    static __device__ __forceinline__ uint32_t pack(const raw_t &r) { return r.pack; }
+    static __device__ __forceinline__ bool valid(const raw_t &r) { return r.uv.x == r.uv.x; }
+    static __device__ __forceinline__ double2 uv(const raw_t &r) { return r.uv; }
+};
+struct RecI16 {
+    typedef uint2 raw_t;    // x: pack, y: pixel x (low half) and y (high half) as int16
+    static __device__ __forceinline__ raw_t load(const RunArgs &a, int64_t idx);
+    static __device__ __forceinline__ uint32_t pack(const raw_t &r) { return r.x; }
+    static __device__ __forceinline__ bool valid(const raw_t &r) { return (r.y & 0xffffu) != 0x8000u; }
+    static __device__ __forceinline__ double2 uv(const raw_t &r) {
+        return make_double2((double)(int)(short)(r.y & 0xffffu) + 0.5, (double)((int)r.y >> 16) + 0.5);
+    }
+};
 
 struct RunArgs {
-    const uint32_t *rpack;    // per record: (point index - tile's first point) << 16 | camera slot
-    const double2 *ruv;       // pixel centre
+    const uint32_t *rpack;    // RecF64: (point index - tile's first point) << 16 | (round & 15) << 12 | camera slot
+    const double2 *ruv;       // RecF64: pixel centre
+    const uint2 *rrec;        // RecI16 records
     const int64_t *run_ptr;   // n_tiles + 1: first run of every tile
     const TileMeta *meta;     // n_tiles
     const int32_t *cam_list;  // distinct cameras of every tile, ascending
@@ -44,6 +80,14 @@ struct RunArgs {
     double *partials;         // Op::NPART per tile
 };
 
+__device__ __forceinline__ RecF64::raw_t RecF64::load(const RunArgs &a, int64_t idx) {
+    raw_t r;
+    r.pack = a.rpack[idx];
+    r.uv = a.ruv[idx];
+    return r;
+}
+__device__ __forceinline__ RecI16::raw_t RecI16::load(const RunArgs &a, int64_t idx) { return a.rrec[idx]; }
+
 __device__ __forceinline__ int pt_swz(int p, int S) { return (p & 7) * S + (p >> 3); }
 
 // LDS doubles a workgroup of the pass needs
@@ -53,8 +97,8 @@ __host__ __device__ inline size_t run_pass_lds_doubles(int cam_cap, int pt_strid
 }
 
 // Op supplies:  Op(scalars), NCV, NPV, NPART, NOUT, out_width(o), out_offset(o) (slices of the per-point sums),
-//   obs(x[3], rw[6], uv, cv[NCV] (+=), pv[NPV] (=), part[NPART] (+=))
-template <class Op>
+//   obs(valid, x[3], rw[6], uv, cv[NCV] (+=), pv[NPV] (=), part[NPART] (+=)); everything it adds is zero when !valid
+template <class Op, class Rec>
 __global__ void __launch_bounds__(TILE_BLOCK) k_run_pass(RunArgs a) {
     constexpr int NCV = Op::NCV, NPV = Op::NPV, NPART = Op::NPART;
     extern __shared__ double lds[];
@@ -71,16 +115,12 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_run_pass(RunArgs a) {
         return;
     }
     // this thread's first run: issue the record loads before anything else
-    uint32_t pk[RUN_LEN];
-    double2 uv[RUN_LEN];
+    typename Rec::raw_t rec[RUN_LEN];
     {
         const int r = tid < nruns ? tid : nruns - 1;
         const int64_t base = rb * RUN_LEN + r;
 #pragma unroll
-        for (int k = 0; k < RUN_LEN; ++k) {
-            pk[k] = a.rpack[base + (int64_t)k * nruns];
-            uv[k] = a.ruv[base + (int64_t)k * nruns];
-        }
+        for (int k = 0; k < RUN_LEN; ++k) rec[k] = Rec::load(a, base + (int64_t)k * nruns);
     }
 
     const int rep = a.cam_rep, S = a.pt_stride, PS = 8 * S;
@@ -100,7 +140,6 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_run_pass(RunArgs a) {
         xs[comp * PS + pt_swz(pt, S)] = a.X[3 * (int64_t)p0 + idx];
     }
     for (int idx = tid; idx < NPV * PS; idx += TILE_BLOCK) pacc[idx] = 0.0;
-    double *cacc_lane = cacc + (size_t)(lane & (rep - 1)) * NCV * nc;
     const Op op(a.scalars);
     __syncthreads();
 
@@ -112,12 +151,10 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_run_pass(RunArgs a) {
         if (r != tid) {
             const int64_t base = rb * RUN_LEN + r;
 #pragma unroll
-            for (int k = 0; k < RUN_LEN; ++k) {
-                pk[k] = a.rpack[base + (int64_t)k * nruns];
-                uv[k] = a.ruv[base + (int64_t)k * nruns];
-            }
+            for (int k = 0; k < RUN_LEN; ++k) rec[k] = Rec::load(a, base + (int64_t)k * nruns);
         }
-        const int slot = (int)(pk[0] & 0xffffu);   // a run is never empty and has one camera
+        const int slot = (int)(Rec::pack(rec[0]) & (RUN_MAX_CAMS - 1));   // one camera per run
+        const int round = (int)(Rec::pack(rec[0]) >> RUN_SLOT_BITS) & 15;
         double2 rw[6];
         {
             const double2 *src = (const double2 *)(rows + slot * ROW_LDS);
@@ -129,17 +166,15 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_run_pass(RunArgs a) {
         for (int k = 0; k < NCV; ++k) cv[k] = 0.0;
 #pragma unroll
         for (int k = 0; k < RUN_LEN; ++k) {
-            if (pk[k] != RUN_EMPTY) {
-                const int sw = pt_swz((int)(pk[k] >> 16), S);
-                const double x[3] = {xs[sw], xs[PS + sw], xs[2 * PS + sw]};
-                double pv[NPV];
-                op.obs(x, rw, uv[k], cv, pv, part);
+            const int sw = pt_swz((int)(Rec::pack(rec[k]) >> 16), S);
+            const double x[3] = {xs[sw], xs[PS + sw], xs[2 * PS + sw]};
+            double pv[NPV];
+            op.obs(Rec::valid(rec[k]), x, rw, Rec::uv(rec[k]), cv, pv, part);
 #pragma unroll
-                for (int v = 0; v < NPV; ++v)
-                    __hip_atomic_fetch_add(pacc + v * PS + sw, pv[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
+            for (int v = 0; v < NPV; ++v)
+                __hip_atomic_fetch_add(pacc + v * PS + sw, pv[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        double *acc = cacc_lane + slot;
+        double *acc = cacc + (size_t)(round & (rep - 1)) * NCV * nc + slot;
 #pragma unroll
         for (int k = 0; k < NCV; ++k)
             __hip_atomic_fetch_add(acc + k * nc, cv[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

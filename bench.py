@@ -35,7 +35,10 @@ def measured_traffic(points_per_gpu, cameras, track_len):
     if (points_per_gpu, cameras, track_len) != (1_000_000, 2000, 10) or not os.path.exists(path):
         return None
     with open(path) as fh:
-        return json.load(fh).get('ba::k_eval_tiled', {}).get('hbm_bytes_per_launch')
+        for kernel, row in json.load(fh).items():
+            if 'k_run_pass<ba::GradOp>' in kernel:
+                return row.get('hbm_bytes_per_launch')
+    return None
 
 
 def cpu_baseline(sc, budget_s=15.0):
@@ -140,7 +143,7 @@ def main():
                        'points': N_total, 'cameras': K, 'observations': nv_total,
                        'parallelism': f'point-sharded x{world}, cameras replicated',
                        'energy_first_timed': E_first, 'energy_last_timed': E_last},
-            'roofline': {'bound': 'hbm', 'kernel': 'ba::k_eval_tiled (fused observation pass, gradient)',
+            'roofline': {'bound': 'hbm', 'kernel': 'ba::k_run_pass<ba::GradOp> (fused observation pass, gradient)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS,
                          'traffic': measured_traffic(args.points_per_gpu, args.cameras, args.track_len),

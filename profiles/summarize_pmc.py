@@ -15,7 +15,7 @@ import sys
 
 
 def per_kernel(dirname, counter):
-    f = glob.glob(dirname + '/*/*counter_collection.csv')[0]
+    f = glob.glob(dirname + '/**/*counter_collection.csv', recursive=True)[0]
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r['Counter_Name'] == counter:

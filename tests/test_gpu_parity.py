@@ -101,6 +101,39 @@ def test_eval_teacher_forced_f3_and_f6(ba, golden):
         sh.close()
 
 
+def test_record_formats_agree(ba):
+    """Pixel centres of the form int16 + 0.5 travel as 8-byte records, anything else as pack word +
+    two doubles; both must give the oracle's numbers (negative pixels, the int16 limits and a
+    non-representable pixel included)."""
+    rng = np.random.default_rng(11)
+    N, K = 400, 12
+    C, Th, R = ba.scenes.orbit_cameras(K, seed=5)
+    mask = rng.random((N, K)) < 0.7
+    mask[:, 0] = True
+    i, j = np.nonzero(mask)
+    i, j = i.astype(np.int32), j.astype(np.int32)
+    X = rng.normal(0, 1, (N, 3)) + np.array([0, 0, 30.0])
+    pix = rng.integers(-200, 4000, (i.size, 2)).astype(np.float64)
+    pix[0] = (-32767, 32767)
+    pix[1] = (32767, -32767)
+    for label, uv, records in (('i16', pix + 0.5, None), ('i16 forced to f64', pix + 0.5, 'f64'),
+                               ('quarter pixel -> f64', pix + 0.25, None),
+                               ('one pixel out of int16 range -> f64', np.vstack([[40000.5, 3.5], (pix + 0.5)[1:]]), None)):
+        E_ref, gX_r, gC_r, gT_r, gp_r = orc.energy_and_gradients(X, C, Th, np.array([1.1]), 1920, 1080, i, j, uv)
+        if records:
+            os.environ['BA_RECORDS'] = records
+        try:
+            sh = ba.engine.Shard(i, j, uv, N, K, 1920, 1080, DEV)
+        finally:
+            os.environ.pop('BA_RECORDS', None)
+        sh.set_params(X, C, Th, 1.1)
+        E, gX, gC, gT, gp = _eval_all(ba, sh, i.size)
+        assert abs(E - E_ref) / E_ref < TOL, label
+        assert rel_err(gX, gX_r) < TOL and rel_err(gC, gC_r) < TOL, label
+        assert rel_err(gT, gT_r) < TOL and rel_err(gp, gp_r) < TOL, label
+        sh.close()
+
+
 def test_eval_ragged_and_empty_points(ba):
     """Points without observations get a zero gradient; long tracks span several waves."""
     rng = np.random.default_rng(3)
