@@ -40,6 +40,9 @@ SIGNATURES = {
     'ba_schur_build': (_int, [_p, _p, _dbl] + [_p] * 12),
     'ba_cholesky_solve': (_int, [_i64, _i64, _p, _p, C.POINTER(_int), _p]),
     'ba_backsubstitute': (_int, [_p, _p, _dbl, _p, _p, _p, _p, _p, _p, _p]),
+    'ba_can_fuse_update': (_int, [_p]),
+    'ba_eval_update': (_int, [_p] * 6 + [_int] + [_p] * 5 + [_int, _dbl, _dbl, _dbl, _dbl] + [_p] * 6),
+    'ba_gauge_points': (_int, [_i64, _p, _p, _p, _p]),
     'ba_fetch_double': (_int, [_p, C.POINTER(_dbl), _p]),
     'ba_post_energy': (_int, [_p, _p, _p]),
     'ba_wait_energy': (_int, [_p, C.POINTER(_dbl), _p]),

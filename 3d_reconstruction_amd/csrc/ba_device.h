@@ -46,6 +46,26 @@ __device__ __forceinline__ void rotation_yxz(double tx, double ty, double tz, do
     *sz_out = sz;
 }
 
+// update rules (p2w:336-360)
+struct UpdateRule {
+    int mode;  // 0 = leave unchanged, 1 = SGD (p2w:336-342), 2 = Adam (p2w:344-360)
+    double lr, gscale, bc1, bc2;
+};
+
+// one parameter: returns the new value, updates the moments in place
+__device__ __forceinline__ double apply_rule(const UpdateRule &u, double x, double g, double *s, double *r) {
+    const double rho1 = 0.9, rho2 = 0.999;
+    const double gr = g * u.gscale;
+    if (u.mode == 2) {
+        const double sn = rho1 * *s + (1.0 - rho1) * gr;
+        const double rn = rho2 * *r + (1.0 - rho2) * (gr * gr);
+        *s = sn;
+        *r = rn;
+        return x - u.lr * (sn / u.bc1) / (1e-12 + sqrt(rn / u.bc2));
+    }
+    return x - u.lr * gr;
+}
+
 // Everything a workgroup needs to know about its tile, fetched with one scalar load.
 struct TileMeta {
     int32_t e0, e1;   // observation range

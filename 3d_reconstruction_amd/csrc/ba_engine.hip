@@ -740,7 +740,7 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_tile_fill(const int32_t *__restr
 
 // ---- gradient pass on camera runs (see ba_runpass.h) --------------------------------------------
 struct GradOp {
-    static constexpr int NCV = 6, NPV = 3, NPART = 2, NOUT = 1;
+    static constexpr int NCV = 6, NPV = 3, NPART = 2, NOUT = 1, WAVES_PER_EU = 4;
     __host__ __device__ static constexpr int out_width(int) { return 3; }
     __host__ __device__ static constexpr int out_offset(int) { return 0; }
     double f, pcx, pcy;
@@ -954,25 +954,6 @@ __global__ void k_post_energy(const double *__restrict__ E_sum, volatile double 
 // --------------------------------------------------------------------------------------------
 // K6: update rules (p2w:336-360)
 // --------------------------------------------------------------------------------------------
-struct UpdateRule {
-    int mode;  // 0 = leave unchanged, 1 = SGD (p2w:336-342), 2 = Adam (p2w:344-360)
-    double lr, gscale, bc1, bc2;
-};
-
-// one parameter: returns the new value, updates the moments in place
-__device__ __forceinline__ double apply_rule(const UpdateRule &u, double x, double g, double *s, double *r) {
-    const double rho1 = 0.9, rho2 = 0.999;
-    const double gr = g * u.gscale;
-    if (u.mode == 2) {
-        const double sn = rho1 * *s + (1.0 - rho1) * gr;
-        const double rn = rho2 * *r + (1.0 - rho2) * (gr * gr);
-        *s = sn;
-        *r = rn;
-        return x - u.lr * (sn / u.bc1) / (1e-12 + sqrt(rn / u.bc2));
-    }
-    return x - u.lr * gr;
-}
-
 // elementwise update of n parameters; `release` (optional) receives the values before the update
 __global__ void k_update(int64_t n, double *__restrict__ x, const double *__restrict__ g, double *__restrict__ s,
                          double *__restrict__ r, double *__restrict__ release, UpdateRule u) {
@@ -1515,14 +1496,15 @@ __global__ void __launch_bounds__(256) k_camera_step_mb(CameraStep a, CameraStep
     }
 }
 
-__global__ void k_gauge_points(int64_t N, double *__restrict__ X, const double *__restrict__ gauge) {
+// X_out = ((X - C0) @ R0) * factor; X_out may be X
+__global__ void k_gauge_points(int64_t N, const double *X, double *X_out, const double *__restrict__ gauge) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     const double d0 = X[3 * i + 0] - gauge[9], d1 = X[3 * i + 1] - gauge[10], d2 = X[3 * i + 2] - gauge[11];
     const double factor = gauge[12];
-    X[3 * i + 0] = (d0 * gauge[0] + d1 * gauge[3] + d2 * gauge[6]) * factor;
-    X[3 * i + 1] = (d0 * gauge[1] + d1 * gauge[4] + d2 * gauge[7]) * factor;
-    X[3 * i + 2] = (d0 * gauge[2] + d1 * gauge[5] + d2 * gauge[8]) * factor;
+    X_out[3 * i + 0] = (d0 * gauge[0] + d1 * gauge[3] + d2 * gauge[6]) * factor;
+    X_out[3 * i + 1] = (d0 * gauge[1] + d1 * gauge[4] + d2 * gauge[7]) * factor;
+    X_out[3 * i + 2] = (d0 * gauge[2] + d1 * gauge[5] + d2 * gauge[8]) * factor;
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1932,8 +1914,21 @@ int ba_problem_create(int64_t N, int64_t K, int64_t nV, const int32_t *i, const 
     return BA_OK;
 }
 
-int ba_eval(ba_problem *p, const double *X, const double *C, const double *Theta, const double *phi, int flags,
-            double *E_sum, double *gX, double *gC, double *gTheta, double *gphi, void *stream) {
+}  // extern "C"
+
+static UpdateRule make_rule(int mode, double lr, double gscale, double bc1, double bc2);
+
+// optional extras of the camera-run pass: pending gauge of X and the fused point update
+struct FusedUpdate {
+    const double *X_gauge = nullptr;
+    UpdateRule rule = {0, 0.0, 0.0, 1.0, 1.0};
+    const double *s_in = nullptr, *r_in = nullptr;
+    double *X_out = nullptr, *s_out = nullptr, *r_out = nullptr;
+};
+
+static int eval_impl(ba_problem *p, const double *X, const double *C, const double *Theta, const double *phi, int flags,
+                     double *E_sum, double *gX, double *gC, double *gTheta, double *gphi, const FusedUpdate *fu,
+                     void *stream) {
     BA_REQUIRE(p, "ba_eval: null problem");
     BA_REQUIRE(X && C && Theta && phi && E_sum, "ba_eval: null parameter or E_sum pointer");
     BA_REQUIRE(!(flags & BA_EVAL_GRAD_PHI) || gphi, "ba_eval: BA_EVAL_GRAD_PHI needs gphi");
@@ -1972,6 +1967,10 @@ int ba_eval(ba_problem *p, const double *X, const double *C, const double *Theta
     const bool timed = (flags & BA_EVAL_TIMED) != 0 && p->ev_count < TIMING_RING;
     int n_partials = p->grid * EVAL_WAVES;
     const bool use_runs = use_tiles && p->run_ptr && !(flags & BA_EVAL_POINT_MAJOR) && a.debug == 0;
+    if (fu && !use_runs) {
+        set_error("ba_eval_update: needs the camera-run layout of the observation pass");
+        return BA_ERR_STATE;
+    }
     if (timed) BA_HIP(hipEventRecord(p->ev_begin[p->ev_count], st));
     if (use_runs) {
         RunArgs ra;
@@ -1986,6 +1985,13 @@ int ba_eval(ba_problem *p, const double *X, const double *C, const double *Theta
         ra.pt_stride = p->run_pt_stride;
         ra.cam_rep = p->run_rep_grad;
         ra.X = X;
+        ra.X_gauge = fu ? fu->X_gauge : nullptr;
+        ra.upd = fu ? fu->rule : UpdateRule{0, 0.0, 0.0, 1.0, 1.0};
+        ra.s_in = fu ? fu->s_in : nullptr;
+        ra.r_in = fu ? fu->r_in : nullptr;
+        ra.X_out = fu ? fu->X_out : nullptr;
+        ra.s_out = fu ? fu->s_out : nullptr;
+        ra.r_out = fu ? fu->r_out : nullptr;
         ra.T = p->cam_table;
         ra.scalars = p->scalars;
         ra.out[0] = a.gX;
@@ -2041,6 +2047,44 @@ int ba_eval(ba_problem *p, const double *X, const double *C, const double *Theta
     hipLaunchKernelGGL(k_finalize, dim3(cdiv(K, 256)), dim3(256), 0, st, K, n_partials, p->partials, p->cam_sums,
                        p->cam_table, p->scalars, E_sum, (flags & BA_EVAL_GRAD_PHI) ? gphi : nullptr,
                        want_cam ? gC : nullptr, want_cam ? gTheta : nullptr, mailbox, seq);
+    BA_HIP(hipGetLastError());
+    return BA_OK;
+}
+
+extern "C" {
+
+int ba_eval(ba_problem *p, const double *X, const double *C, const double *Theta, const double *phi, int flags,
+            double *E_sum, double *gX, double *gC, double *gTheta, double *gphi, void *stream) {
+    return eval_impl(p, X, C, Theta, phi, flags, E_sum, gX, gC, gTheta, gphi, nullptr, stream);
+}
+
+int ba_can_fuse_update(const ba_problem *p) { return p && p->tiled && p->tiles_worth && p->run_ptr ? 1 : 0; }
+
+int ba_eval_update(ba_problem *p, const double *X, const double *X_gauge, const double *C, const double *Theta,
+                   const double *phi, int flags, double *E_sum, double *gX, double *gC, double *gTheta, double *gphi,
+                   int rule, double lr, double gscale, double bc1, double bc2, const double *s_in, double *s_out,
+                   const double *r_in, double *r_out, double *X_out, void *stream) {
+    BA_REQUIRE(p, "ba_eval_update: null problem");
+    BA_REQUIRE(rule == 1 || rule == 2, "ba_eval_update: rule must be 1 (SGD) or 2 (Adam)");
+    BA_REQUIRE(X_out && (rule != 2 || (s_in && s_out && r_in && r_out)), "ba_eval_update: null pointer");
+    BA_REQUIRE(X_out != X || !X_gauge, "ba_eval_update: a pending gauge needs X_out different from X");
+    BA_REQUIRE(!(flags & (BA_EVAL_CAM_ATOMICS | BA_EVAL_UNTILED | BA_EVAL_POINT_MAJOR | BA_EVAL_DEBUG_MASK)),
+               "ba_eval_update: only the camera-run pass can fuse the update");
+    FusedUpdate fu;
+    fu.X_gauge = X_gauge;
+    fu.rule = make_rule(rule, lr, gscale, bc1, bc2);
+    fu.s_in = s_in;
+    fu.r_in = r_in;
+    fu.X_out = X_out;
+    fu.s_out = s_out;
+    fu.r_out = r_out;
+    const int f = gX ? (flags | BA_EVAL_GRAD_X) : (flags & ~BA_EVAL_GRAD_X);   // gX is optional here
+    return eval_impl(p, X, C, Theta, phi, f, E_sum, gX, gC, gTheta, gphi, &fu, stream);
+}
+
+int ba_gauge_points(int64_t N, const double *X_in, double *X_out, const double *gauge, void *stream) {
+    BA_REQUIRE(N >= 0 && (N == 0 || (X_in && X_out)) && gauge, "ba_gauge_points: null pointer");
+    if (N > 0) hipLaunchKernelGGL(k_gauge_points, dim3(cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, N, X_in, X_out, gauge);
     BA_HIP(hipGetLastError());
     return BA_OK;
 }
@@ -2214,7 +2258,7 @@ int ba_gauge_fix(int64_t N, int64_t K, double *X, double *C, double *Theta, doub
     a.R_out = R_out;
     a.gauge = gauge_out;
     hipLaunchKernelGGL(k_camera_step, dim3(1), dim3(1024), 0, st, a);
-    if (N > 0) hipLaunchKernelGGL(k_gauge_points, dim3(cdiv(N, 256)), dim3(256), 0, st, N, X, gauge_out);
+    if (N > 0) hipLaunchKernelGGL(k_gauge_points, dim3(cdiv(N, 256)), dim3(256), 0, st, N, X, X, gauge_out);
     BA_HIP(hipGetLastError());
     return BA_OK;
 }

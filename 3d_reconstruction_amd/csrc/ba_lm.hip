@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_jtj_tiled(JtjArgs a) {
 // The same pass on camera runs (see ba_runpass.h): 33 camera sums in registers over a run, 12 point
 // sums as conflict-free LDS atomics.
 struct JtjOp {
-    static constexpr int NCV = CAMV, NPV = PTV, NPART = 3, NOUT = 3;
+    static constexpr int NCV = CAMV, NPV = PTV, NPART = 3, NOUT = 3, WAVES_PER_EU = 2;
     // per-point sums: gradient (3) -> gX, V upper triangle (6) -> V, point x phi (3) -> Xphi
     __host__ __device__ static constexpr int out_width(int o) { return o == 1 ? 6 : 3; }
     __host__ __device__ static constexpr int out_offset(int o) { return o == 0 ? 0 : (o == 1 ? 3 : 9); }

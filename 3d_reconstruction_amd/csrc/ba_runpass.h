@@ -62,22 +62,29 @@ struct RecI16 {
 };
 
 struct RunArgs {
-    const uint32_t *rpack;    // RecF64: (point index - tile's first point) << 16 | (round & 15) << 12 | camera slot
-    const double2 *ruv;       // RecF64: pixel centre
-    const uint2 *rrec;        // RecI16 records
-    const int64_t *run_ptr;   // n_tiles + 1: first run of every tile
-    const TileMeta *meta;     // n_tiles
-    const int32_t *cam_list;  // distinct cameras of every tile, ascending
-    int K;
-    int cam_cap;              // LDS capacity in cameras (max over tiles)
-    int pt_stride;            // S: LDS capacity in points is 8 * S
-    int cam_rep;              // copies of the camera accumulators (power of two)
-    const double *X;
-    const double *T;
-    const double *scalars;
-    double *out[3];           // per-point outputs (see the Op), any may be null
-    double *cam_sums;         // Op::NCV x K, component-major, accumulated with atomics
-    double *partials;         // Op::NPART per tile
+    const uint32_t *rpack = nullptr;    // RecF64: (point index - tile's first point) << 16 | (round & 15) << 12 | camera slot
+    const double2 *ruv = nullptr;       // RecF64: pixel centre
+    const uint2 *rrec = nullptr;        // RecI16 records
+    const int64_t *run_ptr = nullptr;   // n_tiles + 1: first run of every tile
+    const TileMeta *meta = nullptr;     // n_tiles
+    const int32_t *cam_list = nullptr;  // distinct cameras of every tile, ascending
+    int K = 0;
+    int cam_cap = 0;              // LDS capacity in cameras (max over tiles)
+    int pt_stride = 0;            // S: LDS capacity in points is 8 * S
+    int cam_rep = 1;              // copies of the camera accumulators (power of two)
+    const double *X = nullptr;
+    const double *X_gauge = nullptr;    // optional: the true points are ((X - C0) @ R0) * factor of this record
+                              // (R0 row-major [0..8], C0 [9..11], factor [12]); applied while loading
+    const double *T = nullptr;
+    const double *scalars = nullptr;
+    // optional fused point update (upd.mode != 0): every point's gradient is complete when its
+    // tile ends, so the tile applies the update rule right there and writes X_out / s_out / r_out
+    UpdateRule upd = {0, 0.0, 0.0, 1.0, 1.0};
+    const double *s_in = nullptr, *r_in = nullptr;
+    double *X_out = nullptr, *s_out = nullptr, *r_out = nullptr;
+    double *out[3] = {nullptr, nullptr, nullptr};           // per-point outputs (see the Op), any may be null
+    double *cam_sums = nullptr;         // Op::NCV x K, component-major, accumulated with atomics
+    double *partials = nullptr;         // Op::NPART per tile
 };
 
 __device__ __forceinline__ RecF64::raw_t RecF64::load(const RunArgs &a, int64_t idx) {
@@ -96,10 +103,10 @@ __host__ __device__ inline size_t run_pass_lds_doubles(int cam_cap, int pt_strid
     return (size_t)cam_cap * ROW_LDS + (size_t)cam_cap * Op::NCV * rep + (size_t)(3 + Op::NPV) * 8 * pt_stride;
 }
 
-// Op supplies:  Op(scalars), NCV, NPV, NPART, NOUT, out_width(o), out_offset(o) (slices of the per-point sums),
+// Op supplies:  Op(scalars), WAVES_PER_EU (register budget), NCV, NPV, NPART, NOUT, out_width(o), out_offset(o) (slices of the per-point sums),
 //   obs(valid, x[3], rw[6], uv, cv[NCV] (+=), pv[NPV] (=), part[NPART] (+=)); everything it adds is zero when !valid
 template <class Op, class Rec>
-__global__ void __launch_bounds__(TILE_BLOCK) k_run_pass(RunArgs a) {
+__global__ void __launch_bounds__(TILE_BLOCK, Op::WAVES_PER_EU) k_run_pass(RunArgs a) {
     constexpr int NCV = Op::NCV, NPV = Op::NPV, NPART = Op::NPART;
     extern __shared__ double lds[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -135,9 +142,22 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_run_pass(RunArgs a) {
         ((double2 *)rows)[idx] = ((const double2 *)(a.T + (int64_t)j * CAM_ROW))[piece];
     }
     for (int idx = tid; idx < NCV * nc * rep; idx += TILE_BLOCK) cacc[idx] = 0.0;
-    for (int idx = tid; idx < 3 * np; idx += TILE_BLOCK) {
-        const int pt = idx / 3, comp = idx - 3 * pt;
-        xs[comp * PS + pt_swz(pt, S)] = a.X[3 * (int64_t)p0 + idx];
+    if (a.X_gauge) {
+        const double *G = a.X_gauge;
+        const double c0 = G[9], c1 = G[10], c2 = G[11], factor = G[12];
+        for (int pt = tid; pt < np; pt += TILE_BLOCK) {
+            const double *x = a.X + 3 * (int64_t)(p0 + pt);
+            const double d0 = x[0] - c0, d1 = x[1] - c1, d2 = x[2] - c2;
+            const int sw = pt_swz(pt, S);
+#pragma unroll
+            for (int comp = 0; comp < 3; ++comp)
+                xs[comp * PS + sw] = (d0 * G[comp] + d1 * G[3 + comp] + d2 * G[6 + comp]) * factor;
+        }
+    } else {
+        for (int idx = tid; idx < 3 * np; idx += TILE_BLOCK) {
+            const int pt = idx / 3, comp = idx - 3 * pt;
+            xs[comp * PS + pt_swz(pt, S)] = a.X[3 * (int64_t)p0 + idx];
+        }
     }
     for (int idx = tid; idx < NPV * PS; idx += TILE_BLOCK) pacc[idx] = 0.0;
     const Op op(a.scalars);
@@ -191,6 +211,33 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_run_pass(RunArgs a) {
     // every point is written by exactly one tile: its own points and the unobserved ones up to the
     // next tile's first point (zeros)
     const int lo = tm.wlo - p0, hi = tm.whi - p0;
+    if (a.upd.mode) {
+        for (int64_t gi = 3 * (int64_t)tm.wlo + tid; gi < 3 * (int64_t)tm.whi; gi += TILE_BLOCK) {
+            const int64_t gpt = gi / 3;
+            const int comp = (int)(gi - 3 * gpt), pt = (int)(gpt - p0);
+            double x, g = 0.0;
+            if (pt >= 0 && pt < np) {
+                const int sw = comp * PS + pt_swz(pt, S);
+                x = xs[sw];
+                g = pacc[sw];     // the gradient is the first slice of the per-point sums
+            } else if (a.X_gauge) {   // a point nobody observes: only the stored value changes frame
+                const double *G = a.X_gauge, *xp = a.X + 3 * gpt;
+                x = ((xp[0] - G[9]) * G[comp] + (xp[1] - G[10]) * G[3 + comp] + (xp[2] - G[11]) * G[6 + comp]) * G[12];
+            } else {
+                x = a.X[gi];
+            }
+            double sv = 0.0, rv = 0.0;
+            if (a.upd.mode == 2) {
+                sv = a.s_in[gi];
+                rv = a.r_in[gi];
+            }
+            a.X_out[gi] = apply_rule(a.upd, x, g, &sv, &rv);
+            if (a.upd.mode == 2) {
+                a.s_out[gi] = sv;
+                a.r_out[gi] = rv;
+            }
+        }
+    }
 #pragma unroll
     for (int o = 0; o < Op::NOUT; ++o) {
         double *dst = a.out[o];

@@ -76,7 +76,11 @@ class Shard:
         # Current parameters.  X and cam are REBOUND, not overwritten, by the optimiser step
         # (step_update returns new tensors, adopt() binds them), so a tensor a caller kept - the
         # snapshot the LR schedule rolls back to - stays valid without a copy.
-        self.X = z(self.N, 3)
+        # The points may carry a pending gauge record: the true points are then
+        # ((X_buf - C0) @ R0) * factor; the fused pass applies it while loading, `X` applies it
+        # on demand.
+        self._X_buf = z(self.N, 3)
+        self._X_gauge = None
         self.cam = z(2 * K3 + 1)
         self.gX = z(self.N, 3)
         self.red = z(2 * K3 + 2)
@@ -94,6 +98,33 @@ class Shard:
             torch.distributed.get_world_size(group) > 1
         self._out_ptrs = [t.data_ptr() for t in (self.E_sum, self.gX, self.gC, self.gTheta, self.gphi)]
         self._E_host = C.c_double(0.0)
+
+    @property
+    def X(self):
+        """Current points (N,3) in engine order; a pending gauge record is applied first."""
+        if self._X_gauge is not None:
+            out = torch.empty_like(self._X_buf)
+            check(self.lib.ba_gauge_points(self.N, self._X_buf.data_ptr(), out.data_ptr(), self._X_gauge.data_ptr(),
+                                           self.stream))
+            self._X_buf, self._X_gauge = out, None
+        return self._X_buf
+
+    @X.setter
+    def X(self, value):
+        self._X_buf, self._X_gauge = value, None
+
+    def snapshot(self):
+        """The current parameters as references (nothing is copied; current tensors are never
+        written in place by the optimiser steps)."""
+        return (self._X_buf, self._X_gauge, self.cam)
+
+    def restore(self, snap):
+        self._X_buf, self._X_gauge, self.cam = snap
+
+    @property
+    def can_fuse(self):
+        """The observation pass can apply the point update itself (eval_update)."""
+        return bool(self.lib.ba_can_fuse_update(self.handle))
 
     # views of the current camera buffer
     @property
@@ -166,9 +197,9 @@ class Shard:
         self.cam = cam
         self._table_cam = None
 
-    def adopt(self, X, cam):
-        """Make X / cam (tensors returned by step_update, or kept from an earlier state) current."""
-        self.X, self.cam = X, cam
+    def adopt(self, X, cam, X_gauge=None):
+        """Make X / cam (tensors returned by step_update / eval_update + camera_update) current."""
+        self._X_buf, self._X_gauge, self.cam = X, X_gauge, cam
 
     def invalidate_table(self):
         """Call after writing into the current camera buffer in place."""
@@ -230,6 +261,56 @@ class Shard:
                                     ptr(self.gauge), self.stream))
         self._table_cam = None
 
+    def eval_update(self, rule, lr, bc1, bc2, mom_x, grad_cam=True, grad_phi=True, timed=False):
+        """Queues the observation pass at the current parameters WITH the update of X fused in (see
+        ba_eval_update): leaves the camera-side gradient in `red`, posts the energy, and returns
+        (X_new, mom_x_new) - new tensors holding the updated points BEFORE the gauge fix of this
+        step; they become current through adopt(X_new, cam_new, gauge record of camera_update)."""
+        flags = (_lib.EVAL_GRAD_CAM if grad_cam else 0) | (_lib.EVAL_GRAD_PHI if grad_phi else 0) | \
+                (_lib.EVAL_TIMED if timed else 0) | (_lib.EVAL_REUSE_TABLE if self._table_cam is self.cam else 0) | \
+                (0 if self.distributed else _lib.EVAL_POST)
+        X_new = torch.empty_like(self._X_buf)
+        if mom_x is not None:
+            s_in, r_in = mom_x
+            mom_x = (torch.empty_like(s_in), torch.empty_like(r_in))
+            mp = (s_in.data_ptr(), mom_x[0].data_ptr(), r_in.data_ptr(), mom_x[1].data_ptr())
+        else:
+            mp = (None, None, None, None)
+        c = self.cam.data_ptr()
+        K24 = 24 * self.K
+        o = self._out_ptrs
+        check(self.lib.ba_eval_update(self.handle, self._X_buf.data_ptr(),
+                                      None if self._X_gauge is None else self._X_gauge.data_ptr(), c, c + K24,
+                                      c + 2 * K24, flags, o[0], None, o[2], o[3], o[4], rule, float(lr),
+                                      1.0 / self.nV, float(bc1), float(bc2), *mp, X_new.data_ptr(), self.stream))
+        self._table_cam = self.cam
+        if self.distributed:
+            allreduce_sum_(self.red, self.group)
+            check(self.lib.ba_post_energy(self.handle, o[0], self.stream))
+        return X_new, mom_x
+
+    def camera_update(self, rule, lr, bc1, bc2, cam_range, mom_cam, gauge, in_place=False):
+        """Queues the camera side of one step (update rule on the free slice of [C | Theta | phi_x],
+        camera half of the gauge fix, camera table of the new parameters).  Returns
+        (cam_new, mom_cam_new, gauge record or None); the record (a new 16-double tensor) is what
+        the points still have to go through."""
+        new = (lambda t: t) if in_place else torch.empty_like
+        lo, hi = cam_range if cam_range is not None else (0, 0)
+        cam_new = new(self.cam)
+        if mom_cam is not None:
+            s_in, r_in = mom_cam
+            mom_cam = (new(s_in), new(r_in))
+            mp = (s_in.data_ptr(), mom_cam[0].data_ptr(), r_in.data_ptr(), mom_cam[1].data_ptr())
+        else:
+            mp = (None, None, None, None)
+        rec = torch.empty(16, dtype=F64, device=self.device) if gauge else None
+        check(self.lib.ba_camera_step(self.handle, self.cam.data_ptr(), cam_new.data_ptr(), self.red.data_ptr(),
+                                      *mp, lo, hi, rule, float(lr), 1.0 / self.nV, float(bc1), float(bc2),
+                                      int(bool(gauge)), self.R_gauge.data_ptr(),
+                                      rec.data_ptr() if gauge else None, self.stream))
+        self._table_cam = cam_new
+        return cam_new, mom_cam, rec
+
     def step_update(self, rule, lr, bc1, bc2, x_free, cam_range, mom_x, mom_cam, gauge, in_place=False):
         """Queues one optimiser step for every free group plus the gauge fix, in two launches
         (p2w:704-712), reading the current parameters and the gradients of the last `eval`.
@@ -238,34 +319,22 @@ class Shard:
         None.  Returns (X, cam, mom_x, mom_cam) AFTER the step: new tensors (the inputs are left
         untouched, so keeping them is a snapshot) unless in_place.  The results become current
         with `adopt`; dropping them instead discards the step."""
-        gs = 1.0 / self.nV
-        lr, bc1, bc2 = float(lr), float(bc1), float(bc2)
         new = (lambda t: t) if in_place else torch.empty_like
-        X_new, cam_new = self.X, self.cam
+        X_cur = self.X          # applies a pending gauge record
+        X_new, cam_new, rec = X_cur, self.cam, None
         if cam_range is not None or gauge:
-            lo, hi = cam_range if cam_range is not None else (0, 0)
-            cam_new = new(self.cam)
-            if mom_cam is not None:
-                s_in, r_in = mom_cam
-                mom_cam = (new(s_in), new(r_in))
-                mp = (s_in.data_ptr(), mom_cam[0].data_ptr(), r_in.data_ptr(), mom_cam[1].data_ptr())
-            else:
-                mp = (None, None, None, None)
-            check(self.lib.ba_camera_step(self.handle, self.cam.data_ptr(), cam_new.data_ptr(), self.red.data_ptr(),
-                                          *mp, lo, hi, rule, lr, gs, bc1, bc2, int(bool(gauge)),
-                                          self.R_gauge.data_ptr(), self.gauge.data_ptr(), self.stream))
-            self._table_cam = cam_new
+            cam_new, mom_cam, rec = self.camera_update(rule, lr, bc1, bc2, cam_range, mom_cam, gauge, in_place)
         if x_free or gauge:
-            X_new = new(self.X)
+            X_new = new(X_cur)
             if x_free and mom_x is not None:
                 s_in, r_in = mom_x
                 mom_x = (new(s_in), new(r_in))
                 mp = (s_in.data_ptr(), mom_x[0].data_ptr(), r_in.data_ptr(), mom_x[1].data_ptr())
             else:
                 mp = (None, None, None, None)
-            check(self.lib.ba_points_step(self.N, self.X.data_ptr(), X_new.data_ptr(), self.gX.data_ptr(), *mp,
-                                          rule if x_free else 0, lr, gs, bc1, bc2,
-                                          self.gauge.data_ptr() if gauge else None, self.stream))
+            check(self.lib.ba_points_step(self.N, X_cur.data_ptr(), X_new.data_ptr(), self.gX.data_ptr(), *mp,
+                                          rule if x_free else 0, float(lr), 1.0 / self.nV, float(bc1), float(bc2),
+                                          rec.data_ptr() if gauge else None, self.stream))
         return X_new, cam_new, mom_x, mom_cam
 
     # ---- second-order extension (no reference counterpart) ---------------------------------------

@@ -9,7 +9,12 @@ evaluation is queued BEFORE the energy is read, with the learning rate and momen
 will use unless it changes them (LR increase, LR decrease with rollback, a stopping rule).  The
 step writes new buffers and leaves its inputs alone, so when the schedule does intervene the
 queued step is simply dropped and the loop continues from the untouched state: the sequence of
-parameters is the one the reference computes either way."""
+parameters is the one the reference computes either way.
+
+When the shard's observation pass can apply the point update itself (`can_fuse`), the queued step
+is: pass with the X update fused in, then the camera-side step; the rigid part of the gauge fix
+stays pending on the new points (a 16-double record) and is applied by the next pass while it
+loads them."""
 from __future__ import annotations
 
 import numpy as np
@@ -34,7 +39,7 @@ class SceneFit:
 
     def __init__(self, shard, lr, max_iters, X_mask=True, C_Theta_mask=True, phi_x_mask=True,
                  optimizer='Adam', patience=1000, factor=2.0, stop_value=0.0, stop_diff=1e-12,
-                 print_step=1000, ret_all_iters=False, printer=print, speculate=True):
+                 print_step=1000, ret_all_iters=False, printer=print, speculate=True, fuse=True):
         if optimizer not in gd_func_dict:
             raise ValueError(f'Unkown name of the optmizer, choose one from {[key for key in gd_func_dict]}')
         self.sh = shard
@@ -46,6 +51,10 @@ class SceneFit:
         self.ret_all_iters = ret_all_iters
         self.print = printer
         self.speculate = bool(speculate)   # queue the update before the energy is known
+        # let the observation pass apply the X update (only as a queued step: the update is then
+        # part of the pass that produces the energy)
+        self.fuse = bool(fuse) and self.speculate and bool(X_mask) and bool(getattr(shard, 'can_fuse', False))
+        self._grad_x_valid = False         # gX holds the gradient at the current parameters
         self.dropped = 0                   # queued updates the schedule overruled
         self.timed_every = 0        # record HIP events around the observation-pass kernel of every n-th pass
         self._passes = 0
@@ -59,7 +68,7 @@ class SceneFit:
         if self.gauge:
             shard.gauge_fix()                                            # p2w:533-536
 
-        self.release = (shard.X, shard.cam)                              # p2w:463-464
+        self.release = shard.snapshot()                                  # p2w:463-464
         self.adam = optimizer == 'Adam'
         self.mom_x = self.mom_cam = self.mom_x_tmp = self.mom_cam_tmp = None
         if self.adam:                                                    # p2w:469-473
@@ -101,6 +110,7 @@ class SceneFit:
         timed = self.timed_every > 0 and self._passes % self.timed_every == 0
         self._passes += 1
         self.sh.eval(grad_x=self.masks[0], grad_cam=self.masks[1], grad_phi=self.masks[2], timed=timed)
+        self._grad_x_valid = True
 
     # ---- learning-rate schedule ---------------------------------------------------------------
     def _manage(self):
@@ -112,7 +122,7 @@ class SceneFit:
         elif e < self.E_min:
             self.E_min = e
             self.began_decreasing = True
-            self.release = (self.sh.X, self.sh.cam)      # release <- main (p2w:397-398), by reference
+            self.release = self.sh.snapshot()            # release <- main (p2w:397-398), by reference
             self.patience_timer = self.patience
             if self.success_timer > 0:
                 self.success_timer -= 1
@@ -138,7 +148,7 @@ class SceneFit:
                     self.iters -= 1
                 self.print(f'{self.iters} : Decrease LR to {self.lr / self.factor}')
                 self.lr /= self.factor
-                self.sh.adopt(*self.release)          # main <- release (p2w:430-431)
+                self.sh.restore(self.release)         # main <- release (p2w:430-431)
                 self._evaluate()          # gradients at the rolled-back parameters
                 if (not self.increased) or (self.E_min_temp > self.E_min):
                     self._adam_reset()
@@ -163,8 +173,11 @@ class SceneFit:
         if self.finished or not (self.iters < self.max_iters):
             self.finished = True
             return False
-        self._evaluate()
-        queued = self._queue_update() if self.speculate else None
+        if self.fuse:
+            queued = self._queue_fused()
+        else:
+            self._evaluate()
+            queued = self._queue_update() if self.speculate else None
         self.E[self.iters] = self.sh.wait_energy()
         self._intervened = False
         self._manage()
@@ -190,9 +203,11 @@ class SceneFit:
         if queued is None or self._intervened:
             if queued is not None:
                 self.dropped += 1
+            if not self._grad_x_valid:        # the fused pass kept the point gradient to itself
+                self._evaluate()
             queued = self._queue_update()
-        X, cam, self.mom_x, self.mom_cam = queued
-        self.sh.adopt(X, cam)
+        X, cam, self.mom_x, self.mom_cam, X_gauge = queued
+        self.sh.adopt(X, cam, X_gauge)
         if self.adam:
             self.t += 1
         self.iters += 1
@@ -205,7 +220,23 @@ class SceneFit:
         if self.adam:
             bc1, bc2 = 1.0 - RHO_1 ** self.t, 1.0 - RHO_2 ** self.t
         return self.sh.step_update(2 if self.adam else 1, self.lr, bc1, bc2, self.masks[0], self.cam_range,
-                                   self.mom_x, self.mom_cam, self.gauge)
+                                   self.mom_x, self.mom_cam, self.gauge) + (None,)
+
+    def _queue_fused(self):
+        """The same step with the X update inside the observation pass: pass + camera-side step."""
+        bc1 = bc2 = 1.0
+        if self.adam:
+            bc1, bc2 = 1.0 - RHO_1 ** self.t, 1.0 - RHO_2 ** self.t
+        rule = 2 if self.adam else 1
+        timed = self.timed_every > 0 and self._passes % self.timed_every == 0
+        self._passes += 1
+        X, mom_x = self.sh.eval_update(rule, self.lr, bc1, bc2, self.mom_x, grad_cam=self.masks[1],
+                                       grad_phi=self.masks[2], timed=timed)
+        self._grad_x_valid = False
+        cam, mom_cam, rec = self.sh.cam, self.mom_cam, None
+        if self.cam_range is not None:
+            cam, mom_cam, rec = self.sh.camera_update(rule, self.lr, bc1, bc2, self.cam_range, self.mom_cam, self.gauge)
+        return X, cam, mom_x, mom_cam, rec
 
     def _finish(self):
         self.finished = True

@@ -82,6 +82,22 @@ int ba_problem_destroy(ba_problem *p);
 int ba_eval(ba_problem *p, const double *X, const double *C, const double *Theta, const double *phi,
             int flags, double *E_sum, double *gX, double *gC, double *gTheta, double *gphi, void *stream);
 
+/* ---- observation pass with the point update fused in (p2w:704-708 for the group X inside the pass
+ * of p2w:544-702).  Available when ba_can_fuse_update(p) (the scene cuts into LDS tiles): every
+ * point's gradient is complete when its tile ends, so the tile applies the update rule (1 SGD,
+ * 2 Adam, as ba_adam_step) there and writes X_out (and s_out, r_out), saving the gX round trip.
+ * X_gauge (optional, 16 doubles as written by ba_camera_step's gauge_out) says that the true points
+ * are ((X - C0) @ R0) * factor: it is applied while X is loaded, so the rigid part of the gauge
+ * fix (p2w:285-293, 327) needs no pass of its own either.  X_out then holds the updated points
+ * BEFORE the next gauge fix; pair it with the gauge record of the camera step that follows.
+ * gX may be NULL.  ba_gauge_points applies a gauge record: X_out = ((X_in - C0) @ R0) * factor. */
+int ba_can_fuse_update(const ba_problem *p);
+int ba_eval_update(ba_problem *p, const double *X, const double *X_gauge, const double *C, const double *Theta,
+                   const double *phi, int flags, double *E_sum, double *gX, double *gC, double *gTheta,
+                   double *gphi, int rule, double lr, double gscale, double bc1, double bc2, const double *s_in,
+                   double *s_out, const double *r_in, double *r_out, double *X_out, void *stream);
+int ba_gauge_points(int64_t N, const double *X_in, double *X_out, const double *gauge, void *stream);
+
 /* Copies one double from the device to *h_out and waits for it: the energy read-back the LR schedule
  * branches on (E[iters] at p2w:612 is a host value in the reference). */
 int ba_fetch_double(const double *src, double *h_out, void *stream);

@@ -27,8 +27,17 @@ class MockShard:
     Theta = property(lambda self: self.cam[3 * self.K:6 * self.K].view(self.K, 3))
     phi = property(lambda self: self.cam[6 * self.K:])
 
-    def adopt(self, X, cam):
+    can_fuse = False
+
+    def adopt(self, X, cam, X_gauge=None):
+        assert X_gauge is None
         self.X, self.cam = X, cam
+
+    def snapshot(self):
+        return (self.X, self.cam)
+
+    def restore(self, snap):
+        self.X, self.cam = snap
 
     def wait_energy(self):
         return self.energy()

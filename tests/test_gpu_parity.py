@@ -311,6 +311,43 @@ def test_step_update_in_place_equals_out_of_place(ba, golden):
     sh.close()
 
 
+def test_fused_update_equals_separate_steps(ba, golden):
+    """Pass with the X update fused in + camera step + pending gauge record, against
+    pass, camera step, points step: three consecutive iterations."""
+    import torch
+    g = golden('f6_medium.npz')
+    N, K = int(g['N']), int(g['K'])
+    states = []
+    for fused in (True, False):
+        sh = ba.engine.Shard(g['obs_i'], g['obs_j'], g['obs_xy'] + 0.5, N, K, int(g['W']), int(g['H']), DEV)
+        assert sh.can_fuse
+        sh.set_params(g['X_0'], g['C_0'], g['Theta_0'], float(g['phi_x_0']))
+        sh.gauge_fix()
+        mx = (torch.zeros_like(sh.X), torch.zeros_like(sh.X))
+        mc = (torch.zeros_like(sh.cam), torch.zeros_like(sh.cam))
+        E = []
+        for t in range(1, 4):
+            bc1, bc2 = 1 - 0.9 ** t, 1 - 0.999 ** t
+            if fused:
+                X, mx = sh.eval_update(2, 1e-3, bc1, bc2, mx)
+                cam, mc, rec = sh.camera_update(2, 1e-3, bc1, bc2, (0, 6 * K + 1), mc, True)
+                E.append(sh.wait_energy())
+                sh.adopt(X, cam, rec)
+            else:
+                sh.eval()
+                E.append(sh.wait_energy())
+                X, cam, mx, mc = sh.step_update(2, 1e-3, bc1, bc2, True, (0, 6 * K + 1), mx, mc, True)
+                sh.adopt(X, cam)
+        if fused:
+            assert sh._X_gauge is not None          # the last gauge record is still pending
+        states.append([E] + [t.cpu().numpy() for t in (sh.X, sh.cam, mx[0], mx[1], mc[0], mc[1])])
+        assert sh._X_gauge is None
+        sh.close()
+    assert rel_err(np.array(states[0][0]), np.array(states[1][0])) < 1e-12
+    for a, b in zip(states[0][1:], states[1][1:]):
+        assert np.abs(a - b).max() <= 1e-11 * max(1.0, np.abs(b).max())
+
+
 def test_fit_scene_errors_match_reference_messages(ba, golden):
     g = golden('f1_tiny_masks.npz')
     args = [g['X_pix'], int(g['W']), int(g['H']), 1e-3, 5, g['X_0'], g['C_0'], g['Theta_0'], float(g['phi_x_0'])]
