@@ -19,6 +19,7 @@ EVAL_UNTILED = 512
 EVAL_REUSE_TABLE = 1024
 EVAL_POST = 2048
 EVAL_POINT_MAJOR = 4096
+EVAL_DEFER_FINALIZE = 8192
 
 _p = C.c_void_p
 _i64 = C.c_int64
@@ -50,6 +51,7 @@ SIGNATURES = {
     'ba_adam_step': (_int, [_i64, _p, _p, _p, _p, _dbl, _dbl, _dbl, _dbl, _p, _p]),
     'ba_sgd_step': (_int, [_i64, _p, _p, _dbl, _dbl, _p, _p]),
     'ba_camera_step': (_int, [_p] * 8 + [_i64, _i64, _int, _dbl, _dbl, _dbl, _dbl, _int, _p, _p, _p]),
+    'ba_camera_step_finalize': (_int, [_p, _p, _p, _p, _int] + [_p] * 4 + [_i64, _i64, _int, _dbl, _dbl, _dbl, _dbl, _p, _p, _p]),
     'ba_points_step': (_int, [_i64] + [_p] * 7 + [_int, _dbl, _dbl, _dbl, _dbl, _p, _p]),
     'ba_gauge_fix': (_int, [_i64, _i64, _p, _p, _p, _p, _p, _p]),
     'ba_project': (_int, [_i64, _i64, _i64, _p, _p, _p, _p, _p, _dbl, _dbl, _dbl, _int, _int, _p, _p]),

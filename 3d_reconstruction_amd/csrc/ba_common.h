@@ -92,6 +92,7 @@ struct ba_problem {
     // energy mailbox: 2 doubles of host memory mapped into the device, [0] = energy sum, [1] = post number
     double *mailbox_host = nullptr, *mailbox_dev = nullptr;
     uint64_t post_seq = 0;        // posts requested so far
+    int pending_partials = 0;     // partial sums of a pass whose finalisation was deferred to the camera step
     // second-order extension (allocated on first use)
     double *cam_sums_jtj = nullptr;  // 33 x K
     double *partials_jtj = nullptr;  // 3 per tile

@@ -1496,6 +1496,364 @@ __global__ void __launch_bounds__(256) k_camera_step_mb(CameraStep a, CameraStep
     }
 }
 
+// --------------------------------------------------------------------------------------------
+// Camera step with the gauge fix, four lanes per camera.  The step is a chain of long fp64
+// routines per camera (update rule, three sincos, three atan2): one thread per camera leaves a
+// wave waiting on that chain, so lane `comp` (0..2) of a quad handles component `comp` of the
+// centre and of the angles, runs ONE sincos and ONE atan2, and the quad exchanges the results
+// with DPP quad broadcasts.  Quad 63 of EVERY workgroup recomputes camera 0 (whose new pose
+// defines the rigid motion) from its old parameters; quads 0..62 own cameras 1 + 63 b + q.
+// Camera 0's own results are staged and written by the workgroup that draws the last ticket,
+// together with the scale factor (see k_camera_step_mb for the protocol), because every
+// workgroup reads camera 0's OLD values.
+// FINALIZE: the kernel also finishes the observation pass (sum of the per-tile partials -> energy,
+// d E / d phi_x; camera-frame sums -> d E / d C, d E / d Theta; energy mailbox) instead of a
+// separate k_finalize launch, and leaves the camera-frame sums at zero.
+// --------------------------------------------------------------------------------------------
+struct FinalizeArgs {
+    const double *partials = nullptr;   // 2 per tile
+    int n_partials = 0;
+    double *cam_sums = nullptr;         // 6 x K
+    double *g_out = nullptr;            // [gC (3K) | gTheta (3K) | gphi | E_sum]
+    volatile double *mailbox = nullptr;
+    double seq = 0.0;
+};
+
+template <int Q>
+__device__ __forceinline__ double quad_bcast(double v) {
+    constexpr int ctrl = Q | (Q << 2) | (Q << 4) | (Q << 6);   // quad_perm:[Q,Q,Q,Q]
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+constexpr int STAGE_DOUBLES = 32;   // camera 0: Theta (3), s (6), r (6), table row R (9) + cos/sin theta_z (2)
+
+template <bool FINALIZE>
+__global__ void __launch_bounds__(256) k_camera_step_quad(CameraStep a, CameraStepShared sh, FinalizeArgs fz) {
+    __shared__ double sR0[9], sC0[3];
+    __shared__ double red_v[4];
+    __shared__ long long red_j[4];
+    __shared__ double red_e[2][4];
+    __shared__ int s_last;
+    __shared__ double s_factor;
+    const int64_t K = a.K;
+    const int tid = threadIdx.x;
+    const int quad = tid >> 2, comp = tid & 3;
+    const bool is_c0 = quad == 63;
+    const int64_t j = is_c0 ? 0 : 1 + (int64_t)blockIdx.x * 63 + quad;
+    const bool live = j < K && comp < 3;
+    const bool own = live && !is_c0;                 // writes its results directly
+    const bool stage0 = live && is_c0 && blockIdx.x == 0;   // camera 0's results, staged
+    const int64_t jj = j < K ? j : 0;
+    const int cc = comp < 3 ? comp : 0;
+
+    if (FINALIZE && blockIdx.x == 0) {
+        double e = 0.0, ps = 0.0;
+        const double2 *pp = (const double2 *)fz.partials;
+        for (int t = tid; t < fz.n_partials; t += 256) {
+            const double2 v = pp[t];
+            e += v.x;
+            ps += v.y;
+        }
+        e = wave_sum(e);
+        ps = wave_sum(ps);
+        if ((tid & 63) == 0) {
+            red_e[0][tid >> 6] = e;
+            red_e[1][tid >> 6] = ps;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const double e_sum = (red_e[0][0] + red_e[0][1]) + (red_e[0][2] + red_e[0][3]);
+            fz.g_out[6 * K + 1] = e_sum;
+            fz.g_out[6 * K] = a.scalars[SC_DPHI] * ((red_e[1][0] + red_e[1][1]) + (red_e[1][2] + red_e[1][3]));
+            if (fz.mailbox) {
+                fz.mailbox[0] = e_sum;
+                __threadfence_system();
+                fz.mailbox[1] = fz.seq;
+            }
+        }
+    }
+
+    // ---- un-normalised gradient of C[comp], Theta[comp] of this quad's camera
+    double gc, gt;
+    if (FINALIZE) {
+        const double *row = a.T + jj * CAM_ROW;
+        const double s0 = fz.cam_sums[0 * K + jj], s1 = fz.cam_sums[1 * K + jj], s2 = fz.cam_sums[2 * K + jj];
+        const double w0 = fz.cam_sums[3 * K + jj], w1 = fz.cam_sums[4 * K + jj], w2 = fz.cam_sums[5 * K + jj];
+        gc = -(row[3 * cc + 0] * s0 + row[3 * cc + 1] * s1 + row[3 * cc + 2] * s2);
+        gt = cc == 0 ? -(row[12] * w0 - row[13] * w1) : (cc == 1 ? -(row[3] * w0 + row[4] * w1 + row[5] * w2) : -w2);
+        if (own || stage0) {
+            fz.g_out[3 * jj + cc] = gc;
+            fz.g_out[3 * K + 3 * jj + cc] = gt;
+        }
+    } else {
+        gc = a.g ? a.g[3 * jj + cc] : 0.0;
+        gt = a.g ? a.g[3 * K + 3 * jj + cc] : 0.0;
+    }
+
+    // ---- update rule (p2w:704-708) on the two parameters of this lane
+    double pnew[2], snew[2] = {0.0, 0.0}, rnew[2] = {0.0, 0.0};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int64_t t = (h == 0 ? 0 : 3 * K) + 3 * jj + cc;
+        const double xo = a.cam_in[t];
+        double xn = xo;
+        if (a.rule.mode && t >= a.lo && t < a.hi) {
+            if (a.rule.mode == 2) {
+                snew[h] = a.s_in[t];
+                rnew[h] = a.r_in[t];
+            }
+            xn = apply_rule(a.rule, xo, h == 0 ? gc : gt, &snew[h], &rnew[h]);
+            if (own && a.rule.mode == 2) {
+                a.s[t] = snew[h];
+                a.r[t] = rnew[h];
+            }
+        }
+        pnew[h] = xn;
+    }
+    double sn, cs;
+    sincos(pnew[1], &sn, &cs);
+    const double sx = quad_bcast<0>(sn), cx = quad_bcast<0>(cs), sy = quad_bcast<1>(sn), cy = quad_bcast<1>(cs),
+                 sz = quad_bcast<2>(sn), cz = quad_bcast<2>(cs);
+    const double c0v = quad_bcast<0>(pnew[0]), c1v = quad_bcast<1>(pnew[0]), c2v = quad_bcast<2>(pnew[0]);
+    double R[9];   // Ry Rx Rz (p2w:114-140)
+    {
+        const double sysx = sy * sx, cysx = cy * sx;
+        R[0] = cy * cz + sysx * sz;
+        R[1] = -cy * sz + sysx * cz;
+        R[2] = sy * cx;
+        R[3] = cx * sz;
+        R[4] = cx * cz;
+        R[5] = -sx;
+        R[6] = -sy * cz + cysx * sz;
+        R[7] = sy * sz + cysx * cz;
+        R[8] = cy * cx;
+    }
+    if (is_c0 && comp == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) sR0[k] = R[k];
+        sC0[0] = c0v;
+        sC0[1] = c1v;
+        sC0[2] = c2v;
+    }
+    __syncthreads();
+    double R0[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R0[k] = sR0[k];
+    const double c00 = sC0[0], c01 = sC0[1], c02 = sC0[2];
+
+    // ---- gauge fix of this camera (p2w:270-333): centre (C - C0) @ R0, rotation R0^T R
+    const double d0 = c0v - c00, d1 = c1v - c01, d2 = c2v - c02;
+    const double n0 = d0 * R0[0] + d1 * R0[3] + d2 * R0[6];
+    const double n1 = d0 * R0[1] + d1 * R0[4] + d2 * R0[7];
+    const double n2 = d0 * R0[2] + d1 * R0[5] + d2 * R0[8];
+    double Rn[9];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) Rn[3 * p + q] = R0[p] * R[q] + R0[3 + p] * R[3 + q] + R0[6 + p] * R[6 + q];
+    const double Cx = sqrt(Rn[3] * Rn[3] + Rn[4] * Rn[4]);   // get_rotations (p2w:260-266)
+    const double ay = cc == 0 ? -Rn[5] : (cc == 1 ? Rn[2] / Cx : Rn[3] / Cx);
+    const double ax = cc == 0 ? Cx : (cc == 1 ? Rn[8] / Cx : Rn[4] / Cx);
+    const double th_g = atan2(ay, ax);
+    const double n_own = cc == 0 ? n0 : (cc == 1 ? n1 : n2);
+    if (own) {
+        a.cam[3 * j + cc] = n_own;              // scaled by the last workgroup
+        a.cam[3 * K + 3 * j + cc] = th_g;
+        if (a.R_out) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) a.R_out[9 * j + 3 * cc + k] = Rn[3 * cc + k];
+        }
+        if (a.T) {
+            double *row = a.T + j * CAM_ROW;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) row[3 * cc + k] = Rn[3 * cc + k];
+            if (cc == 0) {
+                row[12] = Rn[4] / Cx;  // cos(theta_z), p2w:674
+                row[13] = Rn[3] / Cx;  // sin(theta_z), p2w:675
+            }
+        }
+    }
+    if (stage0) {
+        sh.stage[cc] = th_g;
+        sh.stage[3 + cc] = snew[0];
+        sh.stage[6 + cc] = snew[1];
+        sh.stage[9 + cc] = rnew[0];
+        sh.stage[12 + cc] = rnew[1];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sh.stage[15 + 3 * cc + k] = Rn[3 * cc + k];
+        if (cc == 0) {
+            sh.stage[24] = Rn[4] / Cx;
+            sh.stage[25] = Rn[3] / Cx;
+        }
+        if (a.R_out) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) a.R_out[3 * cc + k] = Rn[3 * cc + k];
+        }
+    }
+
+    // ---- longest baseline from camera 0: argmax with ties to the smaller index (p2w:322)
+    double best = (own && cc == 0) ? n0 * n0 + n1 * n1 + n2 * n2 : -1.0;
+    long long best_j = (own && cc == 0) ? j : K;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_xor(best, off);
+        const long long oj = __shfl_xor(best_j, off);
+        if (ov > best || (ov == best && oj < best_j)) {
+            best = ov;
+            best_j = oj;
+        }
+    }
+    if ((tid & 63) == 0) {
+        red_v[tid >> 6] = best;
+        red_j[tid >> 6] = best_j;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w) {
+            if (red_v[w] > best || (red_v[w] == best && red_j[w] < best_j)) {
+                best = red_v[w];
+                best_j = red_j[w];
+            }
+        }
+        sh.block_best[2 * blockIdx.x + 0] = best;
+        sh.block_best[2 * blockIdx.x + 1] = (double)best_j;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int ticket = __hip_atomic_fetch_add(sh.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = ticket == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    // every load below is issued before its first use: the caches were just invalidated, and a
+    // chain of dependent misses is what this tail costs
+    double bv = -1.0;
+    long long bj = K;
+    for (int b = tid; b < (int)gridDim.x; b += 256) {
+        const double v = sh.block_best[2 * b + 0];
+        const long long vj = (long long)sh.block_best[2 * b + 1];
+        if (v > bv || (v == bv && vj < bj)) {
+            bv = v;
+            bj = vj;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_xor(bv, off);
+        const long long oj = __shfl_xor(bj, off);
+        if (ov > bv || (ov == bv && oj < bj)) {
+            bv = ov;
+            bj = oj;
+        }
+    }
+    if ((tid & 63) == 0) {
+        red_v[tid >> 6] = bv;
+        red_j[tid >> 6] = bj;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w) {
+            if (red_v[w] > bv || (red_v[w] == bv && red_j[w] < bj)) {
+                bv = red_v[w];
+                bj = red_j[w];
+            }
+        }
+        const double factor = 1.0 / sqrt(bv);
+        s_factor = factor;
+        if (a.gauge) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) a.gauge[k] = R0[k];
+            a.gauge[9] = c00;
+            a.gauge[10] = c01;
+            a.gauge[11] = c02;
+            a.gauge[12] = factor;
+            a.gauge[13] = (double)bj;
+            a.gauge[14] = 0.0;
+            a.gauge[15] = 0.0;
+        }
+        *sh.counter = 0;
+    }
+    if (tid >= 32 && tid < 35) {   // camera 0: new moments, gauge-fixed pose, table row
+        const int k = tid - 32;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int64_t t = (h == 0 ? 0 : 3 * K) + k;
+            if (a.rule.mode == 2 && t >= a.lo && t < a.hi) {
+                a.s[t] = sh.stage[3 + 3 * h + k];
+                a.r[t] = sh.stage[9 + 3 * h + k];
+            }
+        }
+        a.cam[k] = 0.0;
+        a.cam[3 * K + k] = sh.stage[k];
+        if (a.T) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) a.T[3 * k + q] = sh.stage[15 + 3 * k + q];
+            a.T[9 + k] = 0.0;
+            if (k == 0) {
+                a.T[12] = sh.stage[24];
+                a.T[13] = sh.stage[25];
+            }
+        }
+    }
+    if (tid == 64) {  // phi_x and the scalars that depend on it
+        const int64_t t = 6 * K;
+        double ph = a.cam_in[t];
+        if (a.rule.mode && t >= a.lo && t < a.hi) {
+            double sv = 0.0, rv = 0.0;
+            if (a.rule.mode == 2) {
+                sv = a.s_in[t];
+                rv = a.r_in[t];
+            }
+            ph = apply_rule(a.rule, ph, FINALIZE ? fz.g_out[t] : a.g[t], &sv, &rv);
+            if (a.rule.mode == 2) {
+                a.s[t] = sv;
+                a.r[t] = rv;
+            }
+        }
+        a.cam[t] = ph;
+        if (a.scalars) {
+            const double f = a.W / 2.0 / tan(ph / 2.0);
+            a.scalars[SC_F] = f;
+            a.scalars[SC_CX] = a.W / 2.0;
+            a.scalars[SC_CY] = a.H / 2.0;
+            a.scalars[SC_DPHI] = -f / sin(ph);
+        }
+    }
+    if (FINALIZE) {
+        for (int64_t idx = tid; idx < 6 * K; idx += 256) fz.cam_sums[idx] = 0.0;
+    }
+    __syncthreads();
+    const double factor = s_factor;
+    for (int64_t base = 3; base < 3 * K; base += 8 * 256) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t idx = base + u * 256 + tid;
+            v[u] = idx < 3 * K ? a.cam[idx] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t idx = base + u * 256 + tid;
+            if (idx < 3 * K) {
+                const double c = v[u] * factor;
+                a.cam[idx] = c;
+                if (a.T) a.T[(idx / 3) * CAM_ROW + 9 + (idx % 3)] = c;
+            }
+        }
+    }
+}
+
 // X_out = ((X - C0) @ R0) * factor; X_out may be X
 __global__ void k_gauge_points(int64_t N, const double *X, double *X_out, const double *__restrict__ gauge) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1895,8 +2253,8 @@ int ba_problem_create(int64_t N, int64_t K, int64_t nV, const int32_t *i, const 
     BA_TRY(hipMalloc(&p->scalars, sizeof(double) * SC_COUNT));
     BA_TRY(hipMalloc(&p->step_counter, 16));
     BA_TRY(hipMemset(p->step_counter, 0, 16));
-    BA_TRY(hipMalloc(&p->step_best, sizeof(double) * 2 * cdiv(K, 256)));
-    BA_TRY(hipMalloc(&p->step_stage, sizeof(double) * 16));
+    BA_TRY(hipMalloc(&p->step_best, sizeof(double) * 2 * (cdiv(K, 63) + 1)));
+    BA_TRY(hipMalloc(&p->step_stage, sizeof(double) * STAGE_DOUBLES));
     p->ev_begin.resize(TIMING_RING);
     p->ev_end.resize(TIMING_RING);
     for (int t = 0; t < TIMING_RING; ++t) {
@@ -2038,6 +2396,11 @@ static int eval_impl(ba_problem *p, const double *X, const double *C, const doub
         p->ev_count++;
     }
     const bool want_cam = (flags & BA_EVAL_GRAD_CAM) != 0;
+    if (flags & BA_EVAL_DEFER_FINALIZE) {   // ba_camera_step_finalize finishes the pass
+        BA_REQUIRE(want_cam && (flags & BA_EVAL_GRAD_PHI), "ba_eval: BA_EVAL_DEFER_FINALIZE needs the camera and phi gradients");
+        p->pending_partials = n_partials;
+        return BA_OK;
+    }
     double *mailbox = nullptr;
     double seq = 0.0;
     if (flags & BA_EVAL_POST) {
@@ -2197,12 +2560,13 @@ int ba_points_step(int64_t N, const double *X_in, double *X_out, const double *g
     return BA_OK;
 }
 
-int ba_camera_step(ba_problem *p, const double *cam_in, double *cam_out, const double *g, const double *s_in,
-                   double *s_out, const double *r_in, double *r_out, int64_t lo, int64_t hi, int rule, double lr,
-                   double gscale, double bc1, double bc2, int gauge, double *R_out, double *gauge_out, void *stream) {
+static int camera_step_impl(ba_problem *p, const double *cam_in, double *cam_out, const double *g, double *g_out,
+                            int finalize, int post, const double *s_in, double *s_out, const double *r_in,
+                            double *r_out, int64_t lo, int64_t hi, int rule, double lr, double gscale, double bc1,
+                            double bc2, int gauge, double *R_out, double *gauge_out, void *stream) {
     BA_REQUIRE(p && cam_in && cam_out, "ba_camera_step: null pointer");
     BA_REQUIRE(rule >= 0 && rule <= 2 && lo >= 0 && hi <= 6 * p->K + 1, "ba_camera_step: bad rule or range");
-    BA_REQUIRE(rule == 0 || lo >= hi || (g && (rule != 2 || (s_in && s_out && r_in && r_out))),
+    BA_REQUIRE(rule == 0 || lo >= hi || ((g || finalize) && (rule != 2 || (s_in && s_out && r_in && r_out))),
                "ba_camera_step: null pointer");
     BA_REQUIRE(!gauge || (p->K >= 2 && gauge_out), "ba_camera_step: the gauge fix needs two cameras and gauge_out");
     BA_REQUIRE(same_or_disjoint(cam_in, cam_out, 6 * p->K + 1),
@@ -2230,9 +2594,51 @@ int ba_camera_step(ba_problem *p, const double *cam_in, double *cam_out, const d
     sh.counter = p->step_counter;
     sh.block_best = p->step_best;
     sh.stage = p->step_stage;
-    hipLaunchKernelGGL(k_camera_step_mb, dim3(cdiv(p->K, 256)), dim3(256), 0, (hipStream_t)stream, a, sh);
+    if (gauge) {
+        FinalizeArgs fz;
+        if (finalize) {
+            fz.partials = p->partials;
+            fz.n_partials = p->pending_partials;
+            fz.cam_sums = p->cam_sums;
+            fz.g_out = g_out;
+            if (post) {
+                fz.mailbox = p->mailbox_dev;
+                fz.seq = (double)++p->post_seq;
+            }
+            p->pending_partials = 0;
+            hipLaunchKernelGGL(k_camera_step_quad<true>, dim3(cdiv(p->K - 1, 63)), dim3(256), 0, (hipStream_t)stream, a,
+                               sh, fz);
+        } else {
+            hipLaunchKernelGGL(k_camera_step_quad<false>, dim3(cdiv(p->K - 1, 63)), dim3(256), 0, (hipStream_t)stream,
+                               a, sh, fz);
+        }
+    } else {
+        hipLaunchKernelGGL(k_camera_step_mb, dim3(cdiv(p->K, 256)), dim3(256), 0, (hipStream_t)stream, a, sh);
+    }
     BA_HIP(hipGetLastError());
     return BA_OK;
+}
+
+}  // extern "C"  (closed around the shared implementation above)
+
+extern "C" {
+
+int ba_camera_step(ba_problem *p, const double *cam_in, double *cam_out, const double *g, const double *s_in,
+                   double *s_out, const double *r_in, double *r_out, int64_t lo, int64_t hi, int rule, double lr,
+                   double gscale, double bc1, double bc2, int gauge, double *R_out, double *gauge_out, void *stream) {
+    return camera_step_impl(p, cam_in, cam_out, g, nullptr, 0, 0, s_in, s_out, r_in, r_out, lo, hi, rule, lr, gscale,
+                            bc1, bc2, gauge, R_out, gauge_out, stream);
+}
+
+int ba_camera_step_finalize(ba_problem *p, const double *cam_in, double *cam_out, double *g_out, int post,
+                            const double *s_in, double *s_out, const double *r_in, double *r_out, int64_t lo,
+                            int64_t hi, int rule, double lr, double gscale, double bc1, double bc2, double *R_out,
+                            double *gauge_out, void *stream) {
+    BA_REQUIRE(p && g_out, "ba_camera_step_finalize: null pointer");
+    BA_REQUIRE(p->pending_partials > 0,
+               "ba_camera_step_finalize: no observation pass with BA_EVAL_DEFER_FINALIZE is waiting");
+    return camera_step_impl(p, cam_in, cam_out, nullptr, g_out, 1, post, s_in, s_out, r_in, r_out, lo, hi, rule, lr,
+                            gscale, bc1, bc2, 1, R_out, gauge_out, stream);
 }
 
 int ba_fetch_double(const double *src, double *h_out, void *stream) {

@@ -261,14 +261,17 @@ class Shard:
                                     ptr(self.gauge), self.stream))
         self._table_cam = None
 
-    def eval_update(self, rule, lr, bc1, bc2, mom_x, grad_cam=True, grad_phi=True, timed=False):
+    def eval_update(self, rule, lr, bc1, bc2, mom_x, grad_cam=True, grad_phi=True, timed=False, defer_finalize=False):
         """Queues the observation pass at the current parameters WITH the update of X fused in (see
         ba_eval_update): leaves the camera-side gradient in `red`, posts the energy, and returns
         (X_new, mom_x_new) - new tensors holding the updated points BEFORE the gauge fix of this
-        step; they become current through adopt(X_new, cam_new, gauge record of camera_update)."""
+        step; they become current through adopt(X_new, cam_new, gauge record of camera_update).
+        defer_finalize (single GPU, all camera parameters free): the energy and the camera-side
+        gradient are left to the camera_update(finalize=True) that must follow."""
+        assert not (defer_finalize and self.distributed)
         flags = (_lib.EVAL_GRAD_CAM if grad_cam else 0) | (_lib.EVAL_GRAD_PHI if grad_phi else 0) | \
                 (_lib.EVAL_TIMED if timed else 0) | (_lib.EVAL_REUSE_TABLE if self._table_cam is self.cam else 0) | \
-                (0 if self.distributed else _lib.EVAL_POST)
+                (0 if self.distributed else _lib.EVAL_POST) | (_lib.EVAL_DEFER_FINALIZE if defer_finalize else 0)
         X_new = torch.empty_like(self._X_buf)
         if mom_x is not None:
             s_in, r_in = mom_x
@@ -289,7 +292,7 @@ class Shard:
             check(self.lib.ba_post_energy(self.handle, o[0], self.stream))
         return X_new, mom_x
 
-    def camera_update(self, rule, lr, bc1, bc2, cam_range, mom_cam, gauge, in_place=False):
+    def camera_update(self, rule, lr, bc1, bc2, cam_range, mom_cam, gauge, in_place=False, finalize=False):
         """Queues the camera side of one step (update rule on the free slice of [C | Theta | phi_x],
         camera half of the gauge fix, camera table of the new parameters).  Returns
         (cam_new, mom_cam_new, gauge record or None); the record (a new 16-double tensor) is what
@@ -304,6 +307,13 @@ class Shard:
         else:
             mp = (None, None, None, None)
         rec = torch.empty(16, dtype=F64, device=self.device) if gauge else None
+        if finalize:        # also finishes the pass queued with defer_finalize (and posts its energy)
+            check(self.lib.ba_camera_step_finalize(self.handle, self.cam.data_ptr(), cam_new.data_ptr(),
+                                                   self.red.data_ptr(), 1, *mp, lo, hi, rule, float(lr),
+                                                   1.0 / self.nV, float(bc1), float(bc2), self.R_gauge.data_ptr(),
+                                                   rec.data_ptr(), self.stream))
+            self._table_cam = cam_new
+            return cam_new, mom_cam, rec
         check(self.lib.ba_camera_step(self.handle, self.cam.data_ptr(), cam_new.data_ptr(), self.red.data_ptr(),
                                       *mp, lo, hi, rule, float(lr), 1.0 / self.nV, float(bc1), float(bc2),
                                       int(bool(gauge)), self.R_gauge.data_ptr(),

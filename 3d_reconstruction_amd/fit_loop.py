@@ -230,12 +230,15 @@ class SceneFit:
         rule = 2 if self.adam else 1
         timed = self.timed_every > 0 and self._passes % self.timed_every == 0
         self._passes += 1
+        # one GPU, gauge fix on: the camera step also finishes the pass (energy, camera-side gradient)
+        merge = self.gauge and not getattr(self.sh, 'distributed', False)
         X, mom_x = self.sh.eval_update(rule, self.lr, bc1, bc2, self.mom_x, grad_cam=self.masks[1],
-                                       grad_phi=self.masks[2], timed=timed)
+                                       grad_phi=merge or self.masks[2], timed=timed, defer_finalize=merge)
         self._grad_x_valid = False
         cam, mom_cam, rec = self.sh.cam, self.mom_cam, None
         if self.cam_range is not None:
-            cam, mom_cam, rec = self.sh.camera_update(rule, self.lr, bc1, bc2, self.cam_range, self.mom_cam, self.gauge)
+            cam, mom_cam, rec = self.sh.camera_update(rule, self.lr, bc1, bc2, self.cam_range, self.mom_cam, self.gauge,
+                                                      finalize=merge)
         return X, cam, mom_x, mom_cam, rec
 
     def _finish(self):

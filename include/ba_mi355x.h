@@ -47,7 +47,8 @@ enum ba_eval_flags {
     BA_EVAL_REUSE_TABLE = 1024, /* the handle's camera table already describes C, Theta, phi (left there by
                                   ba_camera_step); skip rebuilding it */
     BA_EVAL_POST = 2048,    /* also post E_sum to the handle's host mailbox (see ba_wait_energy) */
-    BA_EVAL_POINT_MAJOR = 4096 /* use the point-major tile kernel instead of the camera-run one */
+    BA_EVAL_POINT_MAJOR = 4096, /* use the point-major tile kernel instead of the camera-run one */
+    BA_EVAL_DEFER_FINALIZE = 8192 /* leave E_sum and the camera-side gradient to ba_camera_step_finalize */
 };
 
 const char *ba_last_error(void);
@@ -149,6 +150,15 @@ int ba_camera_step(ba_problem *p, const double *cam_in, double *cam_out, const d
                    double *s_out, const double *r_in, double *r_out, int64_t lo, int64_t hi, int rule,
                    double lr, double gscale, double bc1, double bc2, int gauge, double *R_out,
                    double *gauge_out, void *stream);
+/* ba_camera_step with the gauge fix that also FINISHES a pass made with BA_EVAL_DEFER_FINALIZE: sum of
+ * the per-tile partials -> energy and d E / d phi_x, camera-frame sums -> d E / d C, d E / d Theta, all
+ * written to g_out = [gC (3K) | gTheta (3K) | gphi | E_sum]; `post` also posts the energy to the
+ * mailbox (see ba_wait_energy).  One launch instead of two for a single-GPU iteration (with several
+ * GPUs the camera-block reduction sits between the two kernels). */
+int ba_camera_step_finalize(ba_problem *p, const double *cam_in, double *cam_out, double *g_out, int post,
+                            const double *s_in, double *s_out, const double *r_in, double *r_out, int64_t lo,
+                            int64_t hi, int rule, double lr, double gscale, double bc1, double bc2, double *R_out,
+                            double *gauge_out, void *stream);
 int ba_points_step(int64_t N, const double *X_in, double *X_out, const double *gX, const double *s_in,
                    double *s_out, const double *r_in, double *r_out, int rule, double lr, double gscale,
                    double bc1, double bc2, const double *gauge, void *stream);

@@ -318,7 +318,8 @@ def test_fused_update_equals_separate_steps(ba, golden):
     g = golden('f6_medium.npz')
     N, K = int(g['N']), int(g['K'])
     states = []
-    for fused in (True, False):
+    for mode in ('merged', 'fused', 'separate'):
+        fused = mode != 'separate'
         sh = ba.engine.Shard(g['obs_i'], g['obs_j'], g['obs_xy'] + 0.5, N, K, int(g['W']), int(g['H']), DEV)
         assert sh.can_fuse
         sh.set_params(g['X_0'], g['C_0'], g['Theta_0'], float(g['phi_x_0']))
@@ -329,9 +330,11 @@ def test_fused_update_equals_separate_steps(ba, golden):
         for t in range(1, 4):
             bc1, bc2 = 1 - 0.9 ** t, 1 - 0.999 ** t
             if fused:
-                X, mx = sh.eval_update(2, 1e-3, bc1, bc2, mx)
-                cam, mc, rec = sh.camera_update(2, 1e-3, bc1, bc2, (0, 6 * K + 1), mc, True)
+                merged = mode == 'merged'       # the camera step also finishes the pass
+                X, mx = sh.eval_update(2, 1e-3, bc1, bc2, mx, defer_finalize=merged)
+                cam, mc, rec = sh.camera_update(2, 1e-3, bc1, bc2, (0, 6 * K + 1), mc, True, finalize=merged)
                 E.append(sh.wait_energy())
+                assert E[-1] == sh.energy()
                 sh.adopt(X, cam, rec)
             else:
                 sh.eval()
@@ -343,9 +346,10 @@ def test_fused_update_equals_separate_steps(ba, golden):
         states.append([E] + [t.cpu().numpy() for t in (sh.X, sh.cam, mx[0], mx[1], mc[0], mc[1])])
         assert sh._X_gauge is None
         sh.close()
-    assert rel_err(np.array(states[0][0]), np.array(states[1][0])) < 1e-12
-    for a, b in zip(states[0][1:], states[1][1:]):
-        assert np.abs(a - b).max() <= 1e-11 * max(1.0, np.abs(b).max())
+    for other in states[:2]:
+        assert rel_err(np.array(other[0]), np.array(states[2][0])) < 1e-12
+        for a, b in zip(other[1:], states[2][1:]):
+            assert np.abs(a - b).max() <= 1e-11 * max(1.0, np.abs(b).max())
 
 
 def test_fit_scene_errors_match_reference_messages(ba, golden):
