@@ -31,12 +31,12 @@ def measured_traffic(points_per_gpu, cameras, track_len):
     """HBM bytes per launch of the observation-pass kernel from the committed rocprofv3 PMC passes
     (FETCH_SIZE / WRITE_SIZE, corrected as profiles/summarize_pmc.py documents); only for the
     workload those passes were taken on, else None."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic_cfg3.json')
+    path = os.path.join(ROOT, 'profiles', 'r01g_pmc_traffic_cfg3.json')
     if (points_per_gpu, cameras, track_len) != (1_000_000, 2000, 10) or not os.path.exists(path):
         return None
     with open(path) as fh:
         for kernel, row in json.load(fh).items():
-            if 'k_run_pass<ba::GradOp>' in kernel:
+            if 'k_run_pass<ba::GradOp' in kernel:
                 return row.get('hbm_bytes_per_launch')
     return None
 
@@ -128,7 +128,11 @@ def main():
 
     if rank == 0:
         N_loc, K = sc['N_local'], sc['K']
+        # gradient pass: 24 B per observation record, X in, gX out, cameras in and out
         algo_bytes = 24 * nv_local + 24 * N_loc + 24 * N_loc + 48 * K + 48 * K
+        # the launch also carries the Adam update of the points (moments in, X and moments out,
+        # no gX round trip): bytes on top of the figure above, not counted in `achieved`
+        update_bytes = (48 + 72 - 24) * N_loc if fit.fuse else 0
         avg_ms = float(np.mean(kern_ms)) if kern_ms else float('nan')
         achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
         out = {
@@ -143,12 +147,13 @@ def main():
                        'points': N_total, 'cameras': K, 'observations': nv_total,
                        'parallelism': f'point-sharded x{world}, cameras replicated',
                        'energy_first_timed': E_first, 'energy_last_timed': E_last},
-            'roofline': {'bound': 'hbm', 'kernel': 'ba::k_run_pass<ba::GradOp> (fused observation pass, gradient)',
+            'roofline': {'bound': 'hbm', 'kernel': 'ba::k_run_pass<ba::GradOp, ba::RecI16> (fused observation pass, gradient + point update)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS,
                          'traffic': measured_traffic(args.points_per_gpu, args.cameras, args.track_len),
                          'algorithmic_bytes_per_launch': algo_bytes, 'avg_kernel_ms': avg_ms,
-                         'launches_timed': len(kern_ms)},
+                         'launches_timed': len(kern_ms), 'fused_point_update_bytes_per_launch': update_bytes,
+                         'achieved_with_point_update': (algo_bytes + update_bytes) / (avg_ms * 1e-3) / 1e9},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(sc)
