@@ -222,7 +222,7 @@ class Shard:
                                self.stream))
         self._table_cam = self.cam
         if self.distributed:
-            allreduce_sum_(self.red, self.group)
+            torch.distributed.all_reduce(self.red, op=torch.distributed.ReduceOp.SUM, group=self.group)
             check(self.lib.ba_post_energy(self.handle, self._out_ptrs[0], self.stream))
 
     def wait_energy(self):
@@ -288,7 +288,7 @@ class Shard:
                                       1.0 / self.nV, float(bc1), float(bc2), *mp, X_new.data_ptr(), self.stream))
         self._table_cam = self.cam
         if self.distributed:
-            allreduce_sum_(self.red, self.group)
+            torch.distributed.all_reduce(self.red, op=torch.distributed.ReduceOp.SUM, group=self.group)
             check(self.lib.ba_post_energy(self.handle, o[0], self.stream))
         return X_new, mom_x
 

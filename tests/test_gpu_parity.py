@@ -352,6 +352,34 @@ def test_fused_update_equals_separate_steps(ba, golden):
             assert np.abs(a - b).max() <= 1e-11 * max(1.0, np.abs(b).max())
 
 
+def test_multi_gpu_code_path_on_one_rank(ba, golden):
+    """The sequence a rank runs with several GPUs (pass, k_finalize, RCCL all-reduce of the camera
+    block, energy post, camera step) on a one-rank RCCL group: same energies as the one-GPU
+    sequence, where the camera step finishes the pass itself."""
+    import torch.distributed as dist
+    g = golden('f6_medium.npz')
+    N, K = int(g['N']), int(g['K'])
+    own_group = not dist.is_initialized()
+    if own_group:
+        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29871', rank=0, world_size=1,
+                                device_id=__import__('torch').device(DEV))
+    try:
+        runs = []
+        for force in (True, False):
+            sh = ba.engine.Shard(g['obs_i'], g['obs_j'], g['obs_xy'] + 0.5, N, K, int(g['W']), int(g['H']), DEV)
+            sh.distributed = force
+            sh.set_params(g['X_0'], g['C_0'], g['Theta_0'], float(g['phi_x_0']))
+            fit = ba.SceneFit(sh, 1e-3, 60, patience=100, printer=lambda *a: None).run()
+            assert fit.fuse
+            runs.append(fit.energies())
+            sh.close()
+        assert rel_err(runs[0], runs[1]) < 1e-9
+        assert rel_err(runs[0], g['E'][:60]) < 1e-8
+    finally:
+        if own_group:
+            dist.destroy_process_group()
+
+
 def test_fit_scene_errors_match_reference_messages(ba, golden):
     g = golden('f1_tiny_masks.npz')
     args = [g['X_pix'], int(g['W']), int(g['H']), 1e-3, 5, g['X_0'], g['C_0'], g['Theta_0'], float(g['phi_x_0'])]
