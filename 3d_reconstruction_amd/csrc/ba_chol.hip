@@ -1,0 +1,409 @@
+// Dense fp64 Cholesky for the reduced camera system (no counterpart in the reference, whose optimiser
+// is first-order only, p2w:336-362).
+//
+// Storage: lower triangle, row-major, leading dimension ld (a multiple of 64); rows/columns past n
+// are the identity.  Two-level right-looking factorisation:
+//   panel  (256 columns): per 64-column block  potrf64 -> trsm -> update of the panel's remaining
+//          columns.  O(n 256^2) flops per panel, latency-bound, small next to
+//   trailing update: C -= P P^T with the whole 256-wide panel P as the inner dimension, 128 x 128
+//          tiles, operands staged through LDS in 32-column chunks, on v_mfma_f64_16x16x4_f64.
+//          With an inner dimension of 256 a tile does 32 flop per byte of C it moves (a 64-wide
+//          panel: 8 flop/B, bound by that traffic), so this kernel is bound by the matrix cores.
+// The inverse of every diagonal block is kept (trsm is a product with it, and so are the two
+// triangular solves of the right-hand side).
+//
+// Matrix-core tile v_mfma_f64_16x16x4_f64: lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15];
+// it holds D[(l >> 4) + 4 r][l & 15] in register r = 0..3.
+#include "ba_common.h"
+
+#include <string>
+
+namespace ba {
+
+constexpr int NB = 64;    // block of the panel factorisation
+constexpr int PB = 256;   // panel width = inner dimension of the trailing update
+constexpr int TS = 128;   // tile of the trailing update
+constexpr int KC = 32;    // columns of the panel staged in LDS at a time
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+static int cdiv_c(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// L_kk = chol(A_kk) in place and Linv = L_kk^-1 (64 x 64, row-major), one workgroup of four waves.
+// Factorisation: thread (row i = tid % 64, wave q = tid / 64) keeps L[i][q + 4u], u = 0..15, in
+// registers; the loop over the 64 columns is fully unrolled, column k reaches everybody through a
+// double-buffered 64-entry LDS vector (one barrier per column); what a column costs is the
+// dependent sqrt / divide, not the update.
+// Inverse: the four 16 x 16 diagonal blocks by substitution (16 lanes of each wave), then the
+// blocks below them level by level, X_ij = -X_ii (sum_m L_im X_mj), one thread per entry.
+// Entries above the diagonal are never used as inputs (they may hold anything, NaN included).
+constexpr int POTRF_LDS_DOUBLES = 2 * NB * (NB + 1) + 2 * NB + 16 * 16;
+__global__ void __launch_bounds__(256) k_potrf64(double *__restrict__ A, int64_t ld, int64_t k0, double *__restrict__ Linv,
+                                                 int *__restrict__ info) {
+    extern __shared__ double sm[];
+    double(*Ls)[NB + 1] = (double(*)[NB + 1])sm;
+    double(*Xs)[NB + 1] = (double(*)[NB + 1])(sm + NB * (NB + 1));
+    double(*raw)[NB] = (double(*)[NB])(sm + 2 * NB * (NB + 1));
+    double(*Ts)[16] = (double(*)[16])(sm + 2 * NB * (NB + 1) + 2 * NB);
+    const int tid = threadIdx.x, i = tid & 63, q = tid >> 6;
+    for (int idx = tid; idx < NB * NB; idx += 256) {
+        const int r = idx >> 6, c = idx & 63;
+        Ls[r][c] = A[(k0 + r) * ld + k0 + c];
+        Xs[r][c] = 0.0;
+    }
+    __syncthreads();
+    double reg[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) reg[u] = Ls[i][q + 4 * u];
+    int bad = 0;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int qk = k & 3, uk = k >> 2, buf = k & 1;
+        if (q == qk) raw[buf][i] = reg[uk];
+        __syncthreads();
+        const double dkk = raw[buf][k];
+        if (!(dkk > 0.0) && bad == 0) bad = k + 1;
+        const double d = sqrt(dkk);
+        const double inv = 1.0 / d;
+        const double ci = raw[buf][i] * inv;
+        if (q == qk) reg[uk] = (i == k) ? d : ci;
+#pragma unroll
+        for (int u = uk; u < 16; ++u) {
+            const int j = q + 4 * u;
+            const double cj = raw[buf][j] * inv;
+            const double v = reg[u] - ci * cj;      // L[i][j] -= L[i][k] L[j][k]
+            reg[u] = (j > k) ? v : reg[u];
+        }
+    }
+    if (bad && tid == 0) atomicCAS(info, 0, (int)(k0 + bad));
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 16; ++u) Ls[i][q + 4 * u] = (q + 4 * u <= i) ? reg[u] : 0.0;
+    __syncthreads();
+
+    // ---- inverse: diagonal 16 x 16 blocks, wave q takes block q, lane c < 16 column c
+    if ((tid & 63) < 16) {
+        const int c = tid & 63, o = 16 * q;
+        double li[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            double v = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+            for (int m = 0; m < r; ++m) v -= Ls[o + r][o + m] * li[m];
+            li[r] = v / Ls[o + r][o + r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Xs[o + r][o + c] = li[r];
+    }
+    __syncthreads();
+    // ---- blocks below the diagonal, by distance from it; thread -> entry (r, c) of the 16 x 16 block
+    const int r = tid >> 4, c = tid & 15;
+    for (int dist = 1; dist < 4; ++dist) {
+        for (int bi = dist; bi < 4; ++bi) {
+            const int bj = bi - dist;
+            double t = 0.0;
+            for (int m = 16 * bj; m < 16 * bi; ++m) t += Ls[16 * bi + r][m] * Xs[m][16 * bj + c];
+            Ts[r][c] = t;
+            __syncthreads();
+            double x = 0.0;
+#pragma unroll
+            for (int m = 0; m < 16; ++m) x -= Xs[16 * bi + r][16 * bi + m] * Ts[m][c];
+            __syncthreads();
+            Xs[16 * bi + r][16 * bj + c] = x;
+        }
+        __syncthreads();
+    }
+    for (int idx = tid; idx < NB * NB; idx += 256) {
+        const int rr = idx >> 6, cc = idx & 63;
+        if (cc <= rr) A[(k0 + rr) * ld + k0 + cc] = Ls[rr][cc];
+        Linv[idx] = Xs[rr][cc];
+    }
+}
+
+// D (64x64) += P (64 x 64 slice, row-major, leading dimension ldp) times Q^T, one wave
+__device__ __forceinline__ void mfma_tile_64(const double *__restrict__ P, int64_t ldp, const double *__restrict__ Q,
+                                             int64_t ldq, v4f64 acc[4][4]) {
+    const int lane = threadIdx.x & 63;
+    const int r16 = lane & 15, k4 = lane >> 4;
+    for (int kk = 0; kk < NB; kk += 4) {
+        double af[4], bf[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) af[m] = P[(int64_t)(16 * m + r16) * ldp + kk + k4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) bf[n] = Q[(int64_t)(16 * n + r16) * ldq + kk + k4];  // B[k][j] = Q[j][k]
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[m], bf[n], acc[m][n], 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void zero_acc(v4f64 acc[4][4]) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = (v4f64){0.0, 0.0, 0.0, 0.0};
+}
+
+// A_ik <- A_ik L_kk^-T  (= A_ik times (L^-1)^T): one wave per 64-row block below the diagonal block
+__global__ void __launch_bounds__(64) k_trsm(double *__restrict__ A, int64_t ld, int64_t k0,
+                                             const double *__restrict__ Linv) {
+    const int64_t i0 = k0 + NB + (int64_t)blockIdx.x * NB;
+    v4f64 acc[4][4];
+    zero_acc(acc);
+    double *P = A + i0 * ld + k0;
+    mfma_tile_64(P, ld, Linv, NB, acc);
+    const int lane = threadIdx.x & 63, col = lane & 15, rq = lane >> 4;
+    // every accumulator depends on all of P, so P has been read completely before the first store
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) P[(int64_t)(16 * m + rq + 4 * r) * ld + 16 * nn + col] = acc[m][nn][r];
+}
+
+// Inside a panel: A_ij -= A_ik A_jk^T for row blocks i behind block column k (all the way down) and
+// the column blocks j of the panel behind k; one wave per 64x64 block, blocks above the diagonal skipped.
+__global__ void __launch_bounds__(256) k_syrk_panel(double *__restrict__ A, int64_t ld, int64_t k0, int col_blocks,
+                                                    int64_t n_tiles) {
+    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= n_tiles) return;
+    const int64_t bi = t / col_blocks, bj = t - bi * col_blocks;
+    if (bj > bi) return;
+    const int64_t i0 = k0 + NB * (1 + bi), j0 = k0 + NB * (1 + bj);
+    v4f64 acc[4][4];
+    zero_acc(acc);
+    mfma_tile_64(A + i0 * ld + k0, ld, A + j0 * ld + k0, ld, acc);
+    const int lane = threadIdx.x & 63, col = lane & 15, rq = lane >> 4;
+    double *Cc = A + i0 * ld + j0;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double *dst = Cc + (int64_t)(16 * m + rq + 4 * r) * ld + 16 * nn + col;
+                *dst -= acc[m][nn][r];
+            }
+}
+
+// Trailing update behind a panel: C[i0:+128, j0:+128] -= P_i P_j^T with P = A[:, k0 : k0 + kw], for the
+// lower triangle of 128-tiles of the trailing matrix that starts at row / column c0.  Four waves
+// in a 2 x 2 arrangement of 64 x 64 sub-tiles; the panel rows of both operands pass through LDS in
+// chunks of KC columns (global loads of the next chunk are in flight while the matrix cores work
+// on the current one).
+__global__ void __launch_bounds__(256) k_syrk_trailing(double *__restrict__ A, int64_t ld, int64_t k0, int kw, int64_t c0) {
+    extern __shared__ double smem[];
+    double(*As)[KC + 1] = (double(*)[KC + 1])smem;
+    double(*Bs)[KC + 1] = (double(*)[KC + 1])(smem + TS * (KC + 1));
+    // tile index -> (bi, bj), bj <= bi
+    const int64_t t = blockIdx.x;
+    int64_t bi = (int64_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while (bi * (bi + 1) / 2 > t) --bi;
+    while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+    const int64_t bj = t - bi * (bi + 1) / 2;
+    const int64_t i0 = c0 + TS * bi, j0 = c0 + TS * bj;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
+    const int r16 = lane & 15, k4 = lane >> 4;
+    const bool active = !(bi == bj && wc > wr);     // the sub-tile above the diagonal is never used
+
+    // loader mapping: thread -> row (tid / 4) + 64 h, 8 consecutive columns (tid % 4) * 8
+    const int lrow = tid >> 2, lcol = (tid & 3) * 8;
+    const double *srcA[2], *srcB[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        int64_t ra = i0 + lrow + 64 * h, rb = j0 + lrow + 64 * h;
+        if (ra >= ld) ra = ld - 1;   // rows past the matrix: a valid address, results never stored
+        if (rb >= ld) rb = ld - 1;
+        srcA[h] = A + ra * ld + k0 + lcol;
+        srcB[h] = A + rb * ld + k0 + lcol;
+    }
+    double2 pa[2][4], pb[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            pa[h][q] = ((const double2 *)srcA[h])[q];
+            pb[h][q] = ((const double2 *)srcB[h])[q];
+        }
+    v4f64 acc[4][4];
+    zero_acc(acc);
+    for (int kc = 0; kc < kw; kc += KC) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                As[lrow + 64 * h][lcol + 2 * q] = pa[h][q].x;
+                As[lrow + 64 * h][lcol + 2 * q + 1] = pa[h][q].y;
+                Bs[lrow + 64 * h][lcol + 2 * q] = pb[h][q].x;
+                Bs[lrow + 64 * h][lcol + 2 * q + 1] = pb[h][q].y;
+            }
+        __syncthreads();
+        if (kc + KC < kw) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    pa[h][q] = ((const double2 *)(srcA[h] + kc + KC))[q];
+                    pb[h][q] = ((const double2 *)(srcB[h] + kc + KC))[q];
+                }
+        }
+        if (active) {
+#pragma unroll
+            for (int kk = 0; kk < KC; kk += 4) {
+                double af[4], bf[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) af[m] = As[64 * wr + 16 * m + r16][kk + k4];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) bf[n] = Bs[64 * wc + 16 * n + r16][kk + k4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[m], bf[n], acc[m][n], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    if (!active) return;
+    const int col = lane & 15, rq = lane >> 4;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = i0 + 64 * wr + 16 * m + rq + 4 * r;
+            if (row >= ld) continue;
+#pragma unroll
+            for (int nn = 0; nn < 4; ++nn) {
+                const int64_t cc = j0 + 64 * wc + 16 * nn + col;
+                if (cc < ld) A[row * ld + cc] -= acc[m][nn][r];
+            }
+        }
+}
+
+// One block step of a triangular solve with the stored inverses of the diagonal blocks.
+// forward  (L y = b):   y_k = Linv_k b_k, then b_i -= L_ik y_k for the rows i behind block k
+// backward (L^T x = y): x_k = Linv_k^T b_k, then b_i -= L_ki^T x_k for the rows i before block k
+// Every workgroup forms the 64-vector itself (b_k is not overwritten by this launch: the result
+// goes to `out`), then updates its own 256 rows.  Workgroup 0 stores the result.
+__global__ void __launch_bounds__(256) k_solve_step(const double *__restrict__ A, int64_t ld, int64_t k0,
+                                                    const double *__restrict__ Linv, double *__restrict__ b,
+                                                    double *__restrict__ out, int transpose) {
+    __shared__ double bk[NB], yk[NB], part[4][NB];
+    const int tid = threadIdx.x;
+    if (tid < NB) bk[tid] = b[k0 + tid];
+    __syncthreads();
+    {
+        // y[r] = sum_c M[r][c] bk[c], M = Linv (forward) or Linv^T (backward); 4 threads per entry
+        const int r = tid & 63, q = tid >> 6;
+        double s = 0.0;
+        for (int c = 16 * q; c < 16 * q + 16; ++c) s += (transpose ? Linv[c * NB + r] : Linv[r * NB + c]) * bk[c];
+        part[q][r] = s;
+    }
+    __syncthreads();
+    if (tid < NB) {
+        const double y = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+        yk[tid] = y;
+        if (blockIdx.x == 0) out[k0 + tid] = y;
+    }
+    __syncthreads();
+    const int64_t row = (int64_t)blockIdx.x * 256 + tid;
+    if (!transpose) {
+        const int64_t i = k0 + NB + row;
+        if (i >= ld) return;
+        const double *Ar = A + i * ld + k0;
+        double s = 0.0;
+#pragma unroll 8
+        for (int c = 0; c < NB; ++c) s += Ar[c] * yk[c];
+        b[i] -= s;
+    } else {
+        const int64_t i = row;
+        if (i >= k0) return;
+        double s = 0.0;
+#pragma unroll 8
+        for (int c = 0; c < NB; ++c) s += A[(k0 + c) * ld + i] * yk[c];
+        b[i] -= s;
+    }
+}
+
+}  // namespace ba
+
+using namespace ba;
+
+extern "C" {
+
+int ba_schur_dim(int64_t K, int64_t *n, int64_t *ld) {
+    BA_REQUIRE(K > 0 && n && ld, "ba_schur_dim: bad argument");
+    *n = 6 * K + 1;
+    *ld = ((*n + NB - 1) / NB) * NB;
+    return BA_OK;
+}
+
+int ba_cholesky_solve(int64_t n, int64_t ld, double *S, double *rhs, int *h_info, void *stream) {
+    BA_REQUIRE(S && rhs && n > 0 && ld >= n && ld % NB == 0, "ba_cholesky_solve: bad argument (ld must be a multiple of 64)");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t nb = ld / NB;
+    double *Linv = nullptr, *tmp = nullptr;   // inverse of every diagonal block; solution vector
+    int *info = nullptr;
+    BA_HIP(hipMalloc(&Linv, sizeof(double) * NB * NB * nb));
+    hipError_t e = hipMalloc(&tmp, sizeof(double) * ld);
+    if (e == hipSuccess) e = hipMalloc(&info, sizeof(int));
+    if (e == hipSuccess) e = hipMemsetAsync(info, 0, sizeof(int), st);
+    const size_t lds_trailing = sizeof(double) * 2 * TS * (KC + 1);
+    if (e == hipSuccess && lds_trailing > 64 * 1024)
+        e = hipFuncSetAttribute((const void *)k_syrk_trailing, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_trailing);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void *)k_potrf64, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(sizeof(double) * POTRF_LDS_DOUBLES));
+    if (e == hipSuccess) {
+        for (int64_t p0 = 0; p0 < ld; p0 += PB) {
+            const int64_t pw = (ld - p0 < PB) ? ld - p0 : PB;
+            for (int64_t k0 = p0; k0 < p0 + pw; k0 += NB) {
+                double *Li = Linv + (k0 / NB) * NB * NB;
+                hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(256), sizeof(double) * POTRF_LDS_DOUBLES, st, S, ld, k0, Li, info);
+                const int64_t rows_behind = (ld - k0 - NB) / NB;
+                if (rows_behind > 0) {
+                    hipLaunchKernelGGL(k_trsm, dim3((int)rows_behind), dim3(64), 0, st, S, ld, k0, Li);
+                    const int col_blocks = (int)((p0 + pw - k0 - NB) / NB);
+                    if (col_blocks > 0) {
+                        const int64_t tiles = rows_behind * col_blocks;
+                        hipLaunchKernelGGL(k_syrk_panel, dim3(cdiv_c(tiles, 4)), dim3(256), 0, st, S, ld, k0, col_blocks, tiles);
+                    }
+                }
+            }
+            const int64_t c0 = p0 + pw;
+            if (c0 < ld) {
+                const int64_t nt = cdiv_c(ld - c0, TS);
+                hipLaunchKernelGGL(k_syrk_trailing, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), lds_trailing, st, S, ld,
+                                   p0, (int)pw, c0);
+            }
+        }
+        // L y = b, then L^T x = y; the result of every block step lands in tmp
+        for (int64_t k = 0; k < nb; ++k)
+            hipLaunchKernelGGL(k_solve_step, dim3(k + 1 < nb ? cdiv_c(ld - (k + 1) * NB, 256) : 1), dim3(256), 0, st, S, ld,
+                               k * NB, Linv + k * NB * NB, rhs, tmp, 0);
+        e = hipMemcpyAsync(rhs, tmp, sizeof(double) * ld, hipMemcpyDeviceToDevice, st);
+        for (int64_t k = nb - 1; k >= 0; --k)
+            hipLaunchKernelGGL(k_solve_step, dim3(k > 0 ? cdiv_c(k * NB, 256) : 1), dim3(256), 0, st, S, ld, k * NB,
+                               Linv + k * NB * NB, rhs, tmp, 1);
+        if (e == hipSuccess) e = hipMemcpyAsync(rhs, tmp, sizeof(double) * ld, hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess) e = hipGetLastError();
+    }
+    int hinfo = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    hipFree(Linv);
+    hipFree(tmp);
+    hipFree(info);
+    BA_HIP(e);
+    if (h_info) *h_info = hinfo;
+    if (hinfo != 0) {
+        set_error("ba_cholesky_solve: matrix is not positive definite (pivot " + std::to_string(hinfo) + ")");
+        return BA_ERR_NUMERIC;
+    }
+    return BA_OK;
+}
+
+}  // extern "C"

@@ -1,7 +1,6 @@
 // Second-order extension of the engine (no counterpart in the reference, which is first-order
 // only): Gauss-Newton blocks J^T J in the same fused observation pass, the Schur complement onto
-// the cameras, a blocked dense fp64 Cholesky whose trailing update runs on the fp64 matrix cores
-// (v_mfma_f64_16x16x4_f64), triangular solves and the back-substitution for the points.
+// the cameras and the back-substitution for the points.  The dense solve is in ba_chol.hip.
 //
 // Unknown order of the reduced system: camera j owns rows 6j .. 6j+5 (C_x, C_y, C_z, theta_x,
 // theta_y, theta_z), phi_x is row 6K; n = 6K + 1, stored row-major with leading dimension
@@ -622,179 +621,6 @@ __global__ void k_unpack_solution(int64_t K, const double *__restrict__ d, doubl
     }
 }
 
-// --------------------------------------------------------------------------------------------
-// K5: blocked right-looking Cholesky, lower triangle, row-major with leading dimension ld,
-// n a multiple of NB = 64.  Per block column k:
-//   potrf : L_kk = chol(A_kk) and its inverse, one workgroup in LDS;
-//   trsm  : A_ik <- A_ik L_kk^-T for all i > k, as a product with the inverse  (matrix cores);
-//   syrk  : A_ij <- A_ij - A_ik A_jk^T for all i >= j > k                       (matrix cores).
-// The matrix-core tile is v_mfma_f64_16x16x4_f64: lane l supplies A[l & 15][l >> 4] and
-// B[l >> 4][l & 15]; it holds D[(l >> 4) + 4 r][l & 15] in register r = 0..3.
-// --------------------------------------------------------------------------------------------
-constexpr int NB = 64;
-typedef double v4f64 __attribute__((ext_vector_type(4)));
-
-__global__ void __launch_bounds__(256) k_potrf(double *__restrict__ A, int64_t ld, int64_t k0, double *__restrict__ Linv,
-                                               int *__restrict__ info) {
-    __shared__ double L[NB][NB + 1];
-    __shared__ double Li[NB][NB + 1];
-    const int tid = threadIdx.x;
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-        const int r = idx / NB, c = idx - r * NB;
-        L[r][c] = (c <= r) ? A[(k0 + r) * ld + k0 + c] : 0.0;
-    }
-    __syncthreads();
-    for (int k = 0; k < NB; ++k) {
-        const double dkk = L[k][k];
-        if (tid == 0 && !(dkk > 0.0)) atomicCAS(info, 0, (int)(k0 + k + 1));
-        const double d = sqrt(dkk);
-        __syncthreads();
-        if (tid >= k && tid < NB) L[tid][k] = (tid == k) ? d : L[tid][k] / d;
-        __syncthreads();
-        // trailing update of the lower triangle: rows i > k, columns k < j <= i
-        for (int idx = tid; idx < NB * NB; idx += 256) {
-            const int i = idx / NB, j = idx - i * NB;
-            if (j > k && i >= j) L[i][j] -= L[i][k] * L[j][k];
-        }
-        __syncthreads();
-    }
-    // inverse of L: column c of L^-1 by forward substitution, one thread per column
-    if (tid < NB) {
-        const int c = tid;
-        for (int r = 0; r < NB; ++r) {
-            double v = (r == c) ? 1.0 : 0.0;
-            for (int m = c; m < r; ++m) v -= L[r][m] * Li[m][c];
-            Li[r][c] = (r >= c) ? v / L[r][r] : 0.0;
-        }
-    }
-    __syncthreads();
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-        const int r = idx / NB, c = idx - r * NB;
-        A[(k0 + r) * ld + k0 + c] = L[r][c];
-        Linv[idx] = Li[r][c];
-    }
-}
-
-// D (64x64) = P (64x64, row-major, leading dimension ldp) times Q^T (Q 64x64 row-major, ldq), one wave
-__device__ __forceinline__ void mfma_tile_64(const double *__restrict__ P, int64_t ldp, const double *__restrict__ Q,
-                                             int64_t ldq, v4f64 acc[4][4]) {
-    const int lane = threadIdx.x & 63;
-    const int r16 = lane & 15, k4 = lane >> 4;
-    for (int kk = 0; kk < NB; kk += 4) {
-        double af[4], bf[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) af[m] = P[(int64_t)(16 * m + r16) * ldp + kk + k4];
-#pragma unroll
-        for (int n = 0; n < 4; ++n) bf[n] = Q[(int64_t)(16 * n + r16) * ldq + kk + k4];  // B[k][j] = Q[j][k]
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[m], bf[n], acc[m][n], 0, 0, 0);
-    }
-}
-
-// A_ik <- A_ik L_kk^-T  (= A_ik times (L^-1)^T): one wave per 64-row block
-__global__ void __launch_bounds__(64) k_trsm(double *__restrict__ A, int64_t ld, int64_t k0,
-                                             const double *__restrict__ Linv, int64_t n) {
-    const int64_t i0 = k0 + NB + (int64_t)blockIdx.x * NB;
-    if (i0 >= n) return;
-    v4f64 acc[4][4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int nn = 0; nn < 4; ++nn) acc[m][nn] = (v4f64){0.0, 0.0, 0.0, 0.0};
-    double *P = A + i0 * ld + k0;
-    mfma_tile_64(P, ld, Linv, NB, acc);
-    const int lane = threadIdx.x & 63, col = lane & 15, rq = lane >> 4;
-    // every accumulator depends on all of P, so P has been read completely before the first store
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int nn = 0; nn < 4; ++nn)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) P[(int64_t)(16 * m + rq + 4 * r) * ld + 16 * nn + col] = acc[m][nn][r];
-}
-
-// A_ij -= A_ik A_jk^T for the lower block triangle behind block column k; one wave per 64x64 block,
-// blocks enumerated row by row: t -> (bi, bj), bj <= bi
-__global__ void __launch_bounds__(256) k_syrk(double *__restrict__ A, int64_t ld, int64_t k0, int64_t n_blocks_behind,
-                                              int64_t n_tiles) {
-    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= n_tiles) return;
-    // invert t = bi (bi + 1) / 2 + bj
-    int64_t bi = (int64_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-    while (bi * (bi + 1) / 2 > t) --bi;
-    while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
-    const int64_t bj = t - bi * (bi + 1) / 2;
-    (void)n_blocks_behind;
-    const int64_t i0 = k0 + NB * (1 + bi), j0 = k0 + NB * (1 + bj);
-    v4f64 acc[4][4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int nn = 0; nn < 4; ++nn) acc[m][nn] = (v4f64){0.0, 0.0, 0.0, 0.0};
-    mfma_tile_64(A + i0 * ld + k0, ld, A + j0 * ld + k0, ld, acc);
-    const int lane = threadIdx.x & 63, col = lane & 15, rq = lane >> 4;
-    double *Cc = A + i0 * ld + j0;
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int nn = 0; nn < 4; ++nn)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double *dst = Cc + (int64_t)(16 * m + rq + 4 * r) * ld + 16 * nn + col;
-                *dst -= acc[m][nn][r];
-            }
-}
-
-// triangular solves with one right-hand side, block by block (NB rows at a time)
-// forward: y_k = L_kk^-1 (b_k - sum_{m<k} L_km y_m); the sums are applied eagerly after each block
-__global__ void __launch_bounds__(64) k_solve_diag(const double *__restrict__ A, int64_t ld, int64_t k0, double *__restrict__ b,
-                                                   int transpose) {
-    __shared__ double y[NB];
-    const int t = threadIdx.x;
-    y[t] = b[k0 + t];
-    __syncthreads();
-    if (!transpose) {
-        for (int r = 0; r < NB; ++r) {
-            if (t == r) y[r] /= A[(k0 + r) * ld + k0 + r];
-            __syncthreads();
-            if (t > r) y[t] -= A[(k0 + t) * ld + k0 + r] * y[r];
-            __syncthreads();
-        }
-    } else {
-        for (int r = NB - 1; r >= 0; --r) {
-            if (t == r) y[r] /= A[(k0 + r) * ld + k0 + r];
-            __syncthreads();
-            if (t < r) y[t] -= A[(k0 + r) * ld + k0 + t] * y[r];
-            __syncthreads();
-        }
-    }
-    b[k0 + t] = y[t];
-}
-
-// forward: b_i -= L_ik y_k for rows i behind block k; backward (transpose): b_i -= L_ki^T y_k for rows before
-__global__ void __launch_bounds__(256) k_solve_update(const double *__restrict__ A, int64_t ld, int64_t k0, int64_t n,
-                                                      double *__restrict__ b, int transpose) {
-    __shared__ double y[NB];
-    if (threadIdx.x < NB) y[threadIdx.x] = b[k0 + threadIdx.x];
-    __syncthreads();
-    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (!transpose) {
-        const int64_t i = k0 + NB + row;
-        if (i >= n) return;
-        double s = 0.0;
-        for (int c = 0; c < NB; ++c) s += A[i * ld + k0 + c] * y[c];
-        b[i] -= s;
-    } else {
-        const int64_t i = row;
-        if (i >= k0) return;
-        double s = 0.0;
-        for (int c = 0; c < NB; ++c) s += A[(k0 + c) * ld + i] * y[c];
-        b[i] -= s;
-    }
-}
-
 static int cdiv_i(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 }  // namespace ba
@@ -802,13 +628,6 @@ static int cdiv_i(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 using namespace ba;
 
 extern "C" {
-
-int ba_schur_dim(int64_t K, int64_t *n, int64_t *ld) {
-    BA_REQUIRE(K > 0 && n && ld, "ba_schur_dim: bad argument");
-    *n = 6 * K + 1;
-    *ld = ((*n + NB - 1) / NB) * NB;
-    return BA_OK;
-}
 
 int ba_eval_jtj(ba_problem *p, const double *X, const double *C, const double *Theta, const double *phi, int flags,
                 double *E_sum, double *gX, double *gC, double *gTheta, double *gphi, double *V, double *Xphi, double *B,
@@ -941,49 +760,6 @@ int ba_schur_build(ba_problem *p, const double *X, double lambda, const double *
         BA_HIP(hipFuncSetAttribute((const void *)k_schur_points, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_schur_points, dim3(cdiv_i(p->N, 4)), dim3(256), lds, st, a);
     BA_HIP(hipGetLastError());
-    return BA_OK;
-}
-
-int ba_cholesky_solve(int64_t n, int64_t ld, double *S, double *rhs, int *h_info, void *stream) {
-    BA_REQUIRE(S && rhs && n > 0 && ld >= n && ld % NB == 0, "ba_cholesky_solve: bad argument (ld must be a multiple of 64)");
-    hipStream_t st = (hipStream_t)stream;
-    const int64_t nb = ld / NB;
-    double *Linv = nullptr;
-    int *info = nullptr;
-    BA_HIP(hipMalloc(&Linv, sizeof(double) * NB * NB));
-    BA_HIP(hipMalloc(&info, sizeof(int)));
-    BA_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
-    for (int64_t k = 0; k < nb; ++k) {
-        const int64_t k0 = k * NB, behind = nb - k - 1;
-        hipLaunchKernelGGL(k_potrf, dim3(1), dim3(256), 0, st, S, ld, k0, Linv, info);
-        if (behind > 0) {
-            hipLaunchKernelGGL(k_trsm, dim3((int)behind), dim3(64), 0, st, S, ld, k0, Linv, ld);
-            const int64_t tiles = behind * (behind + 1) / 2;
-            hipLaunchKernelGGL(k_syrk, dim3(cdiv_i(tiles, 4)), dim3(256), 0, st, S, ld, k0, behind, tiles);
-        }
-    }
-    for (int64_t k = 0; k < nb; ++k) {  // L y = b
-        hipLaunchKernelGGL(k_solve_diag, dim3(1), dim3(64), 0, st, S, ld, k * NB, rhs, 0);
-        if (k + 1 < nb)
-            hipLaunchKernelGGL(k_solve_update, dim3(cdiv_i(ld - (k + 1) * NB, 256)), dim3(256), 0, st, S, ld, k * NB, ld,
-                               rhs, 0);
-    }
-    for (int64_t k = nb - 1; k >= 0; --k) {  // L^T x = y
-        hipLaunchKernelGGL(k_solve_diag, dim3(1), dim3(64), 0, st, S, ld, k * NB, rhs, 1);
-        if (k > 0) hipLaunchKernelGGL(k_solve_update, dim3(cdiv_i(k * NB, 256)), dim3(256), 0, st, S, ld, k * NB, ld, rhs, 1);
-    }
-    hipError_t e = hipGetLastError();
-    int hinfo = 0;
-    if (e == hipSuccess) e = hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    hipFree(Linv);
-    hipFree(info);
-    BA_HIP(e);
-    if (h_info) *h_info = hinfo;
-    if (hinfo != 0) {
-        set_error("ba_cholesky_solve: matrix is not positive definite (pivot " + std::to_string(hinfo) + ")");
-        return BA_ERR_NUMERIC;
-    }
     return BA_OK;
 }
 

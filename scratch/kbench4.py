@@ -1,6 +1,6 @@
 """Observation-pass kernel variants at cfg3: median kernel time from the library's HIP events."""
 import importlib, sys, os, numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '.'))
 ba = importlib.import_module('3d_reconstruction_amd')
 _lib = importlib.import_module('3d_reconstruction_amd._lib')
 sc = ba.scenes.orbit_scene(N=1_000_000, K=2000, track_len=10, seed=0)

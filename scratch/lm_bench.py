@@ -1,5 +1,5 @@
 import importlib, sys, os, numpy as np, torch, time
-sys.path.insert(0, '.')
+sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '.'))
 ba = importlib.import_module('3d_reconstruction_amd')
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
