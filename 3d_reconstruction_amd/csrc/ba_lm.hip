@@ -445,6 +445,165 @@ struct SchurArgs {
     int max_deg;
 };
 
+// Tile form of the Schur kernel: a workgroup owns an LDS tile (a few hundred consecutive points
+// and the ~10 cameras that see them), sums every point's contribution -Y^T V'^-1 Y to the tile's
+// (6 nc + 1)^2 corner of S in LDS (atomics from lanes that hold different entries), and only then
+// adds the lower block triangle of that corner to the global matrix: ~2.4 k global atomics per
+// tile instead of ~2 k per point.
+struct SchurTileArgs {
+    const uint32_t *opack;   // point-major: (point - tile's first point) << 16 | camera slot
+    const double2 *ouv;
+    const int64_t *row_ptr;
+    const TileMeta *meta;
+    const int32_t *cam_list;
+    int64_t K, ld;
+    int cam_cap, max_deg;
+    double lambda;
+    const double *X, *T, *scalars;
+    const double *V, *Xphi, *gX;
+    double *S, *rhs;
+};
+
+__host__ __device__ inline size_t schur_tile_lds_doubles(int cam_cap, int max_deg) {
+    const size_t m = 6 * (size_t)cam_cap;
+    return (size_t)cam_cap * CAM_ROW + 18 * (size_t)cam_cap * (cam_cap + 1) + 2 * m + 2 + (size_t)16 * max_deg * 37;
+}
+
+constexpr int SCHUR_TILE_BLOCK = 1024;   // 16 waves: what a point costs is the latency of its loads
+__global__ void __launch_bounds__(SCHUR_TILE_BLOCK) k_schur_tile(SchurTileArgs a) {
+    extern __shared__ double lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const TileMeta tm = a.meta[blockIdx.x];
+    const int nc = tm.nc, np = tm.np, p0 = tm.p0;
+    if (tm.e0 >= tm.e1) return;
+    const int m = 6 * nc;
+    double *rows = lds;                                   // cam_cap x CAM_ROW
+    double *St = rows + (size_t)a.cam_cap * CAM_ROW;      // lower block triangle: block (sr, sc <= sr) at (sr (sr + 1) / 2 + sc) * 36
+    double *sphi_t = St + 18 * (size_t)a.cam_cap * (a.cam_cap + 1);   // m
+    double *rhs_t = sphi_t + 6 * a.cam_cap;               // m
+    double *sc_t = rhs_t + 6 * a.cam_cap;                 // {phi-phi, rhs phi}
+    double *Wl = sc_t + 2 + (size_t)wid * a.max_deg * 37;
+    double *Zl = Wl + (size_t)a.max_deg * 18;
+    int *sl = (int *)(Zl + (size_t)a.max_deg * 18);
+    for (int idx = tid; idx < nc * (CAM_ROW / 2); idx += SCHUR_TILE_BLOCK) {
+        const int row = idx / (CAM_ROW / 2), piece = idx - row * (CAM_ROW / 2);
+        const int j = tm.j0 >= 0 ? tm.j0 + row : a.cam_list[tm.cb + row];
+        ((double2 *)rows)[idx] = ((const double2 *)(a.T + (int64_t)j * CAM_ROW))[piece];
+    }
+    const int n_st = 18 * nc * (nc + 1);
+    for (int idx = tid; idx < n_st; idx += SCHUR_TILE_BLOCK) St[idx] = 0.0;
+    for (int idx = tid; idx < 2 * 6 * a.cam_cap + 2; idx += SCHUR_TILE_BLOCK) sphi_t[idx] = 0.0;
+    const double f = a.scalars[SC_F], pcx = a.scalars[SC_CX], pcy = a.scalars[SC_CY];
+    __syncthreads();
+
+    for (int pt = wid; pt < np; pt += SCHUR_TILE_BLOCK / 64) {
+        const int64_t i = p0 + pt;
+        const int64_t eb = a.row_ptr[i];
+        const int deg = (int)(a.row_ptr[i + 1] - eb);
+        if (deg == 0) continue;
+        double Vi[6];
+        inv_sym3(a.V + 6 * i, a.lambda, Vi);
+        const double x[3] = {a.X[3 * i], a.X[3 * i + 1], a.X[3 * i + 2]};
+        const double wp[3] = {a.Xphi[3 * i], a.Xphi[3 * i + 1], a.Xphi[3 * i + 2]};
+        const double gx[3] = {a.gX[3 * i], a.gX[3 * i + 1], a.gX[3 * i + 2]};
+        const double zw[3] = {Vi[0] * wp[0] + Vi[1] * wp[1] + Vi[2] * wp[2], Vi[1] * wp[0] + Vi[3] * wp[1] + Vi[4] * wp[2],
+                              Vi[2] * wp[0] + Vi[4] * wp[1] + Vi[5] * wp[2]};
+        const double zg[3] = {Vi[0] * gx[0] + Vi[1] * gx[1] + Vi[2] * gx[2], Vi[1] * gx[0] + Vi[3] * gx[1] + Vi[4] * gx[2],
+                              Vi[2] * gx[0] + Vi[4] * gx[1] + Vi[5] * gx[2]};
+        for (int o = lane; o < deg; o += 64) {
+            const int64_t e = eb + o;
+            const int slot = (int)(a.opack[e] & 0xffffu);
+            const double *row = rows + slot * CAM_ROW;
+            ObsJac ob = obs_jacobian(x, (const double2 *)row, f, pcx, pcy, a.ouv[e]);
+            double Tm[6][6];
+            camera_frame_change(row, Tm);
+            double jc0[6], jc1[6];  // rows of J_cam = G T
+#pragma unroll
+            for (int al = 0; al < 6; ++al) {
+                double v0 = 0.0, v1 = 0.0;
+#pragma unroll
+                for (int mu = 0; mu < 6; ++mu) {
+                    v0 += ob.G0[mu] * Tm[mu][al];
+                    v1 += ob.G1[mu] * Tm[mu][al];
+                }
+                jc0[al] = v0;
+                jc1[al] = v1;
+            }
+#pragma unroll
+            for (int al = 0; al < 6; ++al) {
+                const double W0 = ob.jx0[0] * jc0[al] + ob.jx1[0] * jc1[al];
+                const double W1 = ob.jx0[1] * jc0[al] + ob.jx1[1] * jc1[al];
+                const double W2 = ob.jx0[2] * jc0[al] + ob.jx1[2] * jc1[al];
+                Wl[o * 18 + 0 * 6 + al] = W0;
+                Wl[o * 18 + 1 * 6 + al] = W1;
+                Wl[o * 18 + 2 * 6 + al] = W2;
+                Zl[o * 18 + 0 * 6 + al] = Vi[0] * W0 + Vi[1] * W1 + Vi[2] * W2;
+                Zl[o * 18 + 1 * 6 + al] = Vi[1] * W0 + Vi[3] * W1 + Vi[4] * W2;
+                Zl[o * 18 + 2 * 6 + al] = Vi[2] * W0 + Vi[4] * W1 + Vi[5] * W2;
+                const double sphi = W0 * zw[0] + W1 * zw[1] + W2 * zw[2];
+                const double rr = W0 * zg[0] + W1 * zg[1] + W2 * zg[2];
+                __hip_atomic_fetch_add(sphi_t + 6 * slot + al, -sphi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(rhs_t + 6 * slot + al, rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            sl[o] = slot;
+        }
+        if (lane == 0) {
+            __hip_atomic_fetch_add(sc_t + 0, -(wp[0] * zw[0] + wp[1] * zw[1] + wp[2] * zw[2]), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(sc_t + 1, wp[0] * zg[0] + wp[1] * zg[1] + wp[2] * zg[2], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        // all ordered pairs (o, o') of the point's observations with slot >= slot': the pair loop is
+        // wave-uniform, lane (al, be) < 36 owns one entry of the 6 x 6 block (no index arithmetic
+        // with divisions inside the loop)
+        if (lane < 36) {
+            const int al = lane / 6, be = lane - 6 * al;
+            for (int o = 0; o < deg; ++o) {
+                const int so = sl[o];
+                const double w0 = Wl[o * 18 + al], w1 = Wl[o * 18 + 6 + al], w2 = Wl[o * 18 + 12 + al];
+                double *dst = St + (size_t)(so * (so + 1) / 2) * 36 + lane;
+                for (int o2 = 0; o2 < deg; ++o2) {
+                    const int so2 = sl[o2];
+                    if (so < so2) continue;
+                    const double v = w0 * Zl[o2 * 18 + be] + w1 * Zl[o2 * 18 + 6 + be] + w2 * Zl[o2 * 18 + 12 + be];
+                    __hip_atomic_fetch_add(dst + 36 * so2, -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+    }
+    __syncthreads();
+    const int64_t nphi = 6 * a.K;
+    for (int idx = tid; idx < n_st; idx += SCHUR_TILE_BLOCK) {
+        const double v = St[idx];
+        if (v == 0.0) continue;
+        const int blk = idx / 36, ent = idx - 36 * blk;
+        int sr = (int)((sqrt(8.0 * (double)blk + 1.0) - 1.0) * 0.5);
+        while (sr * (sr + 1) / 2 > blk) --sr;
+        while ((sr + 1) * (sr + 2) / 2 <= blk) ++sr;
+        const int scn = blk - sr * (sr + 1) / 2;
+        const int64_t jr = tm.j0 >= 0 ? tm.j0 + sr : a.cam_list[tm.cb + sr];
+        const int64_t jc = tm.j0 >= 0 ? tm.j0 + scn : a.cam_list[tm.cb + scn];
+        __hip_atomic_fetch_add(a.S + (6 * jr + ent / 6) * a.ld + 6 * jc + ent % 6, v, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (int idx = tid; idx < m; idx += SCHUR_TILE_BLOCK) {
+        const int sr = idx / 6;
+        const int64_t jr = tm.j0 >= 0 ? tm.j0 + sr : a.cam_list[tm.cb + sr];
+        const int64_t ra = 6 * jr + (idx - 6 * sr);
+        __hip_atomic_fetch_add(a.S + nphi * a.ld + ra, sphi_t[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(a.S + ra * a.ld + nphi, sphi_t[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(a.rhs + ra, rhs_t[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid == 0) {
+        __hip_atomic_fetch_add(a.S + nphi * a.ld + nphi, sc_t[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(a.rhs + nphi, sc_t[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // One wave per point.  LDS per wave: W (deg x 18) and Z = V'^-1 W (deg x 18), camera index (deg).
 __global__ void __launch_bounds__(256) k_schur_points(SchurArgs a) {
     extern __shared__ double lds[];
@@ -732,13 +891,41 @@ int ba_schur_build(ba_problem *p, const double *X, double lambda, const double *
     int64_t n, ld;
     ba_schur_dim(p->K, &n, &ld);
     const size_t lds = (size_t)4 * p->max_degree * 37 * sizeof(double);
-    if (lds > 160 * 1024 - 256) {
+    const size_t lds_tile = p->tiled ? sizeof(double) * schur_tile_lds_doubles(p->cam_cap, p->max_degree) : ~(size_t)0;
+    const bool use_tile = p->tiled && p->tiles_worth && lds_tile <= 150 * 1024 && !getenv("BA_SCHUR_POINTS");
+    if (!use_tile && lds > 160 * 1024 - 256) {
         set_error("ba_schur_build: a point has too many observations for the Schur kernel");
         return BA_ERR_STATE;
     }
     BA_HIP(hipMemsetAsync(S, 0, sizeof(double) * ld * ld, st));
     hipLaunchKernelGGL(k_schur_init, dim3(cdiv_i(p->K, 256)), dim3(256), 0, st, p->K, n, ld, lambda, B, bphi, hphi, gC,
                        gTheta, gphi, S, rhs);
+    if (use_tile) {
+        SchurTileArgs ta;
+        ta.opack = p->opack;
+        ta.ouv = p->ouv;
+        ta.row_ptr = p->row_ptr;
+        ta.meta = (const TileMeta *)p->tile_meta;
+        ta.cam_list = p->cam_list;
+        ta.K = p->K;
+        ta.ld = ld;
+        ta.cam_cap = p->cam_cap;
+        ta.max_deg = p->max_degree;
+        ta.lambda = lambda;
+        ta.X = X;
+        ta.T = p->cam_table;
+        ta.scalars = p->scalars;
+        ta.V = V;
+        ta.Xphi = Xphi;
+        ta.gX = gX;
+        ta.S = S;
+        ta.rhs = rhs;
+        if (lds_tile > 64 * 1024)
+            BA_HIP(hipFuncSetAttribute((const void *)k_schur_tile, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tile));
+        hipLaunchKernelGGL(k_schur_tile, dim3(p->n_tiles), dim3(SCHUR_TILE_BLOCK), lds_tile, st, ta);
+        BA_HIP(hipGetLastError());
+        return BA_OK;
+    }
     SchurArgs a;
     a.oj = p->oj;
     a.ouv = p->ouv;

@@ -14,10 +14,16 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 
-def _scene(ba, N=300, K=80, seed=4):
+def _scene(ba, N=300, K=80, seed=4, tile_obs=None):
+    import os
     sc = ba.scenes.orbit_scene(N=N, K=K, track_len=8, seed=seed)
     assert sc['i'].size > 4 * N
-    sh = ba.engine.Shard(sc['i'], sc['j'], sc['uv'], sc['N_local'], K, sc['W'], sc['H'], DEV)
+    if tile_obs:
+        os.environ['BA_TILE_OBS'] = str(tile_obs)
+    try:
+        sh = ba.engine.Shard(sc['i'], sc['j'], sc['uv'], sc['N_local'], K, sc['W'], sc['H'], DEV)
+    finally:
+        os.environ.pop('BA_TILE_OBS', None)
     sh.set_params(sc['X_0'], sc['C_0'], sc['Theta_0'], sc['phi_x_0'])
     r, J = orc.dense_jacobian(sc['X_0'], sc['C_0'], sc['Theta_0'], sc['phi_x_0'], sc['W'], sc['H'], sc['i'],
                               sc['j'], sc['uv'])
@@ -98,6 +104,37 @@ def test_lm_step_matches_dense_solve(ba):
     dcam = sh.dcam.cpu().numpy()
     assert rel_err(dcam, d[3 * N:]) < 1e-7
     assert rel_err(dX, d[:3 * N]) < 1e-7
+    sh.close()
+
+
+def test_schur_tile_kernel_matches_point_kernel_and_dense(ba):
+    """Few cameras per tile: the Schur complement is summed per tile in LDS.  Same S and rhs as the
+    one-wave-per-point kernel, same step as the dense normal equations."""
+    import os
+    sc, sh, r, J = _scene(ba, N=800, K=60, seed=12, tile_obs=256)
+    N, K = sc['N_local'], sc['K']
+    lam = 1e-2
+    sh.eval_jtj()
+    assert sh.lm_step(lam) == 0
+    d_tile, dX_tile = sh.dcam.clone(), sh.dX.clone()
+    lib, p = sh.lib, ba.engine.ptr
+    def build():
+        ba.engine.check(lib.ba_schur_build(sh.handle, p(sh.X), lam, p(sh.V), p(sh.Xphi), p(sh.gX), p(sh.B), p(sh.bphi),
+                                           p(sh.hphi), p(sh.gC), p(sh.gTheta), p(sh.gphi), p(sh.S), p(sh.rhs), None))
+        n = sh.n_red
+        return torch.tril(sh.S[:n, :n]).cpu().numpy(), sh.rhs[:n].cpu().numpy()
+    S_tile, rhs_tile = build()
+    os.environ['BA_SCHUR_POINTS'] = '1'
+    try:
+        S_pts, rhs_pts = build()
+    finally:
+        os.environ.pop('BA_SCHUR_POINTS', None)
+    assert np.abs(S_tile - S_pts).max() <= 1e-11 * np.abs(S_pts).max()
+    assert np.abs(rhs_tile - rhs_pts).max() <= 1e-11 * np.abs(rhs_pts).max()
+    H, g = J.T @ J, J.T @ r
+    d = np.linalg.solve(H + lam * np.diag(np.diag(H)), -g)
+    assert rel_err(d_tile.cpu().numpy(), d[3 * N:]) < 1e-7
+    assert rel_err(sh.points_to_caller(dX_tile).cpu().numpy().ravel(), d[:3 * N]) < 1e-7
     sh.close()
 
 
