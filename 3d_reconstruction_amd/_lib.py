@@ -38,7 +38,7 @@ SIGNATURES = {
     'ba_eval': (_int, [_p, _p, _p, _p, _p, _int, _p, _p, _p, _p, _p, _p]),
     'ba_eval_jtj': (_int, [_p, _p, _p, _p, _p, _int] + [_p] * 11),
     'ba_schur_dim': (_int, [_i64, C.POINTER(_i64), C.POINTER(_i64)]),
-    'ba_schur_build': (_int, [_p, _p, _dbl] + [_p] * 12),
+    'ba_schur_build': (_int, [_p, _p, _dbl] + [_p] * 9 + [_int] + [_p] * 3),
     'ba_cholesky_solve': (_int, [_i64, _i64, _p, _p, C.POINTER(_int), _p]),
     'ba_backsubstitute': (_int, [_p, _p, _dbl, _p, _p, _p, _p, _p, _p, _p]),
     'ba_can_fuse_update': (_int, [_p]),

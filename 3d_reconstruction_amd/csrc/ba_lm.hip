@@ -883,7 +883,7 @@ static int ensure_row_ptr(ba_problem *p) {
 
 int ba_schur_build(ba_problem *p, const double *X, double lambda, const double *V, const double *Xphi, const double *gX,
                    const double *B, const double *bphi, const double *hphi, const double *gC, const double *gTheta,
-                   const double *gphi, double *S, double *rhs, void *stream) {
+                   const double *gphi, int with_camera_blocks, double *S, double *rhs, void *stream) {
     BA_REQUIRE(p && X && V && Xphi && gX && B && bphi && hphi && gC && gTheta && gphi && S && rhs,
                "ba_schur_build: null pointer");
     if (int rc = ensure_row_ptr(p)) return rc;
@@ -898,8 +898,11 @@ int ba_schur_build(ba_problem *p, const double *X, double lambda, const double *
         return BA_ERR_STATE;
     }
     BA_HIP(hipMemsetAsync(S, 0, sizeof(double) * ld * ld, st));
-    hipLaunchKernelGGL(k_schur_init, dim3(cdiv_i(p->K, 256)), dim3(256), 0, st, p->K, n, ld, lambda, B, bphi, hphi, gC,
-                       gTheta, gphi, S, rhs);
+    if (with_camera_blocks)
+        hipLaunchKernelGGL(k_schur_init, dim3(cdiv_i(p->K, 256)), dim3(256), 0, st, p->K, n, ld, lambda, B, bphi, hphi,
+                           gC, gTheta, gphi, S, rhs);
+    else
+        BA_HIP(hipMemsetAsync(rhs, 0, sizeof(double) * ld, st));
     if (use_tile) {
         SchurTileArgs ta;
         ta.opack = p->opack;

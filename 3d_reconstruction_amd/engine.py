@@ -96,6 +96,9 @@ class Shard:
         self.stream = stream_ptr()
         self.distributed = torch.distributed.is_available() and torch.distributed.is_initialized() and \
             torch.distributed.get_world_size(group) > 1
+        # RCCL sums device tensors in place; with a gloo group (rehearsals of the multi-rank path on
+        # one GPU) the buffers are staged through the host explicitly
+        self._stage_reduce = self.distributed and torch.distributed.get_backend(group) == 'gloo'
         self._out_ptrs = [t.data_ptr() for t in (self.E_sum, self.gX, self.gC, self.gTheta, self.gphi)]
         self._E_host = C.c_double(0.0)
 
@@ -125,6 +128,22 @@ class Shard:
     def can_fuse(self):
         """The observation pass can apply the point update itself (eval_update)."""
         return bool(self.lib.ba_can_fuse_update(self.handle))
+
+    def all_ranks_agree(self, flag):
+        """True if `flag` is true on every rank of the group."""
+        t = torch.tensor([1.0 if flag else 0.0], dtype=F64)
+        if torch.distributed.get_backend(self.group) != 'gloo':
+            t = t.to(self.device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN, group=self.group)
+        return bool(t.item() > 0.5)
+
+    def _sum_over_ranks(self, t):
+        if self._stage_reduce:
+            host = t.cpu()
+            torch.distributed.all_reduce(host, op=torch.distributed.ReduceOp.SUM, group=self.group)
+            t.copy_(host)
+        else:
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM, group=self.group)
 
     # views of the current camera buffer
     @property
@@ -222,7 +241,7 @@ class Shard:
                                self.stream))
         self._table_cam = self.cam
         if self.distributed:
-            torch.distributed.all_reduce(self.red, op=torch.distributed.ReduceOp.SUM, group=self.group)
+            self._sum_over_ranks(self.red)
             check(self.lib.ba_post_energy(self.handle, self._out_ptrs[0], self.stream))
 
     def wait_energy(self):
@@ -288,7 +307,7 @@ class Shard:
                                       1.0 / self.nV, float(bc1), float(bc2), *mp, X_new.data_ptr(), self.stream))
         self._table_cam = self.cam
         if self.distributed:
-            torch.distributed.all_reduce(self.red, op=torch.distributed.ReduceOp.SUM, group=self.group)
+            self._sum_over_ranks(self.red)
             check(self.lib.ba_post_energy(self.handle, o[0], self.stream))
         return X_new, mom_x
 
@@ -355,37 +374,54 @@ class Shard:
             check(self.lib.ba_schur_dim(self.K, C.byref(n), C.byref(ld)))
             self.n_red, self.ld_red = int(n.value), int(ld.value)
             self.V, self.Xphi = z(self.N, 6), z(self.N, 3)
-            self.B, self.bphi, self.hphi = z(self.K, 21), z(self.K, 6), z(1)
+            # camera-side blocks in one buffer (one cross-GPU sum): [B (21K) | bphi (6K) | hphi]
+            self.jred = z(27 * self.K + 1)
+            self.B = self.jred[:21 * self.K].view(self.K, 21)
+            self.bphi = self.jred[21 * self.K:27 * self.K].view(self.K, 6)
+            self.hphi = self.jred[27 * self.K:]
             self.S, self.rhs = z(self.ld_red, self.ld_red), z(self.ld_red)
             self.dX, self.dcam = z(self.N, 3), z(6 * self.K + 1)
 
     def eval_jtj(self, timed=False, point_major=False):
-        """Fused pass that also leaves the Gauss-Newton blocks V, Xphi, B, bphi, hphi."""
+        """Fused pass that also leaves the Gauss-Newton blocks V, Xphi (this shard's points) and
+        B, bphi, hphi (summed over the GPUs together with the gradient block)."""
         self._lm_buffers()
         flags = (_lib.EVAL_TIMED if timed else 0) | (_lib.EVAL_REUSE_TABLE if self.table_valid else 0) | \
                 (_lib.EVAL_POINT_MAJOR if point_major else 0)
-        with torch.cuda.device(self.device):
-            check(self.lib.ba_eval_jtj(self.handle, ptr(self.X), ptr(self.C), ptr(self.Theta), ptr(self.phi), flags,
-                                       ptr(self.E_sum), ptr(self.gX), ptr(self.gC), ptr(self.gTheta), ptr(self.gphi),
-                                       ptr(self.V), ptr(self.Xphi), ptr(self.B), ptr(self.bphi), ptr(self.hphi),
-                                       stream_ptr()))
+        X = self.X
+        c = self.cam.data_ptr()
+        K24 = 24 * self.K
+        check(self.lib.ba_eval_jtj(self.handle, X.data_ptr(), c, c + K24, c + 2 * K24, flags, *self._out_ptrs,
+                                   ptr(self.V), ptr(self.Xphi), ptr(self.B), ptr(self.bphi), ptr(self.hphi),
+                                   self.stream))
         self._table_cam = self.cam
+        if self.distributed:
+            self._sum_over_ranks(self.red)
+            self._sum_over_ranks(self.jred)
 
     def lm_step(self, lam):
         """Solve the damped normal equations (J^T J + lam diag) d = -J^T r by Schur complement and
-        dense Cholesky; leaves dX and dcam = [dC | dTheta | dphi].  Returns the pivot info (0 = ok)."""
+        dense Cholesky; leaves dX and dcam = [dC | dTheta | dphi].  Returns the pivot info (0 = ok).
+        With several GPUs every rank adds its points' part of S and rhs, the sums go over the
+        ranks, and every rank factorises the (identical) reduced system itself."""
         info = C.c_int(0)
-        with torch.cuda.device(self.device):
-            check(self.lib.ba_schur_build(self.handle, ptr(self.X), float(lam), ptr(self.V), ptr(self.Xphi),
-                                          ptr(self.gX), ptr(self.B), ptr(self.bphi), ptr(self.hphi), ptr(self.gC),
-                                          ptr(self.gTheta), ptr(self.gphi), ptr(self.S), ptr(self.rhs), stream_ptr()))
-            status = self.lib.ba_cholesky_solve(self.n_red, self.ld_red, ptr(self.S), ptr(self.rhs), C.byref(info),
-                                                stream_ptr())
-            if status == -4:
-                return int(info.value)
-            check(status)
-            check(self.lib.ba_backsubstitute(self.handle, ptr(self.X), float(lam), ptr(self.V), ptr(self.Xphi),
-                                             ptr(self.gX), ptr(self.rhs), ptr(self.dcam), ptr(self.dX), stream_ptr()))
+        X = self.X
+        first = 1
+        if self.distributed:
+            first = 1 if torch.distributed.get_rank(self.group) == 0 else 0
+        check(self.lib.ba_schur_build(self.handle, X.data_ptr(), float(lam), ptr(self.V), ptr(self.Xphi),
+                                      ptr(self.gX), ptr(self.B), ptr(self.bphi), ptr(self.hphi), ptr(self.gC),
+                                      ptr(self.gTheta), ptr(self.gphi), first, ptr(self.S), ptr(self.rhs), self.stream))
+        if self.distributed:
+            self._sum_over_ranks(self.S)
+            self._sum_over_ranks(self.rhs)
+        status = self.lib.ba_cholesky_solve(self.n_red, self.ld_red, ptr(self.S), ptr(self.rhs), C.byref(info),
+                                            self.stream)
+        if status == -4:
+            return int(info.value)
+        check(status)
+        check(self.lib.ba_backsubstitute(self.handle, X.data_ptr(), float(lam), ptr(self.V), ptr(self.Xphi),
+                                         ptr(self.gX), ptr(self.rhs), ptr(self.dcam), ptr(self.dX), self.stream))
         return 0
 
 

@@ -54,6 +54,9 @@ class SceneFit:
         # let the observation pass apply the X update (only as a queued step: the update is then
         # part of the pass that produces the energy)
         self.fuse = bool(fuse) and self.speculate and bool(X_mask) and bool(getattr(shard, 'can_fuse', False))
+        if getattr(shard, 'distributed', False):
+            # every rank must walk the same sequence of collectives: fuse only if all of them can
+            self.fuse = bool(shard.all_ranks_agree(self.fuse))
         self._grad_x_valid = False         # gX holds the gradient at the current parameters
         self.dropped = 0                   # queued updates the schedule overruled
         self.timed_every = 0        # record HIP events around the observation-pass kernel of every n-th pass

@@ -11,7 +11,12 @@ reached through the same entry point, `fit_scene(..., optimizer='LM')`, and retu
 
 The gauge freedom (7 degrees) is handled the same way the reference's loop does it: the trial point
 is mapped back to the gauge "camera 0 at the origin, longest baseline 1" (the energy is invariant),
-and the damping keeps the normal equations positive definite."""
+and the damping keeps the normal equations positive definite.
+
+Several GPUs: points are sharded like in the first-order path; the camera-side blocks, the
+Schur complement and its right-hand side are summed over the ranks (engine.Shard.eval_jtj,
+lm_step), every rank solves the reduced system itself, and the loop below runs identically on all
+ranks (the energy it branches on is the cross-GPU sum)."""
 from __future__ import annotations
 
 import numpy as np

@@ -201,8 +201,6 @@ def fit_scene_sparse(i, j, uv, N, K, W, H, lr, max_iters, X_0, C_0, Theta_0, phi
         shard.set_params(X_0, C_0, Theta_0, phi_x_0)
     try:
         if optimizer == 'LM':
-            if world > 1:
-                raise ValueError("optimizer='LM' runs on one GPU")
             fit = LMFit(shard, max_iters, lam=lr, stop_value=stop_value, stop_diff=stop_diff, print_step=print_step)
             fit.ret_all_iters = False
         else:

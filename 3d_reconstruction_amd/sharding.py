@@ -58,6 +58,8 @@ def allreduce_sum_(t, group=None):
 def all_gather_rows(x_local, point_bounds, group=None):
     """Concatenate the per-rank row blocks of a (n_local, 3) tensor into the full (N, 3) tensor
     on every rank."""
+    if x_local.is_cuda and torch.distributed.get_backend(group) == 'gloo':   # stage through the host
+        return all_gather_rows(x_local.cpu(), point_bounds, group).to(x_local.device)
     world = len(point_bounds) - 1
     sizes = [point_bounds[r + 1] - point_bounds[r] for r in range(world)]
     width = x_local.shape[1]

@@ -173,7 +173,10 @@ int ba_points_step(int64_t N, const double *X_in, double *X_out, const double *g
  * ba_schur_build: S (ld x ld, row-major, lower triangle valid) and rhs (ld) of
  *   (D' - Y^T V'^-1 Y) d = -g_cam + Y^T V'^-1 g_X, primes = diagonal scaled by (1 + lambda);
  *   unknown order: camera j at 6j..6j+5 (C then Theta), phi_x at 6K.  Uses the camera table left by
- *   the last ba_eval_jtj.
+ *   the last ba_eval_jtj.  with_camera_blocks = 0 leaves out D', -g_cam and the identity padding
+ *   and gives only this shard's sum over its points: with several GPUs one rank passes 1, the
+ *   others 0, and S, rhs are summed over the ranks (B, bphi, hphi, g_cam already being the
+ *   cross-GPU sums).
  * ba_cholesky_solve: blocked Cholesky of S in place (trailing update on the fp64 matrix cores) and
  *   solution of S d = rhs in place; *h_info = 0 or 1 + index of the first non-positive pivot.
  * ba_backsubstitute: dX[N][3] = V'^-1 (-g_X - W d_cam - Xphi d_phi); dcam_packed (optional, 6K+1)
@@ -184,8 +187,8 @@ int ba_eval_jtj(ba_problem *p, const double *X, const double *C, const double *T
 int ba_schur_dim(int64_t K, int64_t *n, int64_t *ld);
 int ba_schur_build(ba_problem *p, const double *X, double lambda, const double *V, const double *Xphi,
                    const double *gX, const double *B, const double *bphi, const double *hphi,
-                   const double *gC, const double *gTheta, const double *gphi, double *S, double *rhs,
-                   void *stream);
+                   const double *gC, const double *gTheta, const double *gphi, int with_camera_blocks,
+                   double *S, double *rhs, void *stream);
 int ba_cholesky_solve(int64_t n, int64_t ld, double *S, double *rhs, int *h_info, void *stream);
 int ba_backsubstitute(ba_problem *p, const double *X, double lambda, const double *V, const double *Xphi,
                       const double *gX, const double *d, double *dcam_packed, double *dX, void *stream);

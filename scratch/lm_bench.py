@@ -25,7 +25,7 @@ _lib = ba.engine._lib
 p = _lib.ptr
 lam = 1e-3
 def schur():
-    _lib.check(sh.lib.ba_schur_build(sh.handle, p(sh.X), lam, p(sh.V), p(sh.Xphi), p(sh.gX), p(sh.B), p(sh.bphi), p(sh.hphi), p(sh.gC), p(sh.gTheta), p(sh.gphi), p(sh.S), p(sh.rhs), _lib.stream_ptr()))
+    _lib.check(sh.lib.ba_schur_build(sh.handle, p(sh.X), lam, p(sh.V), p(sh.Xphi), p(sh.gX), p(sh.B), p(sh.bphi), p(sh.hphi), p(sh.gC), p(sh.gTheta), p(sh.gphi), 1, p(sh.S), p(sh.rhs), _lib.stream_ptr()))
 t_s = timeit(schur, 3)
 print(f'schur build: {t_s:.2f} ms', flush=True)
 n, ld = sh.n_red, sh.ld_red

@@ -120,7 +120,7 @@ def test_schur_tile_kernel_matches_point_kernel_and_dense(ba):
     lib, p = sh.lib, ba.engine.ptr
     def build():
         ba.engine.check(lib.ba_schur_build(sh.handle, p(sh.X), lam, p(sh.V), p(sh.Xphi), p(sh.gX), p(sh.B), p(sh.bphi),
-                                           p(sh.hphi), p(sh.gC), p(sh.gTheta), p(sh.gphi), p(sh.S), p(sh.rhs), None))
+                                           p(sh.hphi), p(sh.gC), p(sh.gTheta), p(sh.gphi), 1, p(sh.S), p(sh.rhs), None))
         n = sh.n_red
         return torch.tril(sh.S[:n, :n]).cpu().numpy(), sh.rhs[:n].cpu().numpy()
     S_tile, rhs_tile = build()
