@@ -1966,8 +1966,7 @@ static int build_runs(ba_problem *p) {
         int rep = 2;
         if (const char *env = getenv(env_name)) rep = atoi(env);
         if (rep < 1) rep = 1;
-        while (rep > 1 && sizeof(double) * ((size_t)p->cam_cap * (ROW_LDS + ncv * rep) +
-                                             (size_t)(3 + npv) * 8 * p->run_pt_stride) > limit)
+        while (rep > 1 && sizeof(double) * run_pass_lds_doubles(ncv, npv, p->cam_cap, p->run_pt_stride, rep) > limit)
             rep >>= 1;
         return rep;
     };

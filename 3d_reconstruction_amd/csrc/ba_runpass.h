@@ -24,8 +24,15 @@
 // points: the point atomics never collide, and two copies of the camera accumulators (selected by
 // the round's parity, stored in the record) keep the flush collision-free as well.
 //
-// Point data in LDS is indexed through pt_swz(): point p lives at (p mod 8) * S + p / 8 with
-// S = 2 * odd, which maps those 16 points to 16 different bank pairs.
+// Point data in LDS: one record per point, [x (3) | per-point sums (NPV) | pad to an odd number of
+// doubles], at record index pt_swz(p) = (p mod 8) * S + p / 8 with S = 2 * odd, which maps those 16
+// points to 16 different bank pairs (an odd record length keeps that property).  Every field of a
+// point is then a constant offset from one address register.
+//
+// Latencies: the LDS returns results in order, so a read issued behind the 3 / 12 atomics of the
+// previous observation waits for them; the point of observation k + 1 is therefore fetched before
+// the arithmetic of observation k starts, and the records of the thread's next run are requested
+// as soon as those of the current run have been decoded.
 #pragma once
 
 #include "ba_device.h"
@@ -97,10 +104,16 @@ __device__ __forceinline__ RecI16::raw_t RecI16::load(const RunArgs &a, int64_t 
 
 __device__ __forceinline__ int pt_swz(int p, int S) { return (p & 7) * S + (p >> 3); }
 
+// doubles of a point's LDS record: x (3), the per-point sums, padded to an odd count
+__host__ __device__ constexpr int pt_record_doubles(int npv) { return (3 + npv) | 1; }
+
 // LDS doubles a workgroup of the pass needs
+__host__ __device__ inline size_t run_pass_lds_doubles(int ncv, int npv, int cam_cap, int pt_stride, int rep) {
+    return (size_t)cam_cap * ROW_LDS + (size_t)cam_cap * ncv * rep + (size_t)pt_record_doubles(npv) * 8 * pt_stride;
+}
 template <class Op>
 __host__ __device__ inline size_t run_pass_lds_doubles(int cam_cap, int pt_stride, int rep) {
-    return (size_t)cam_cap * ROW_LDS + (size_t)cam_cap * Op::NCV * rep + (size_t)(3 + Op::NPV) * 8 * pt_stride;
+    return run_pass_lds_doubles(Op::NCV, Op::NPV, cam_cap, pt_stride, rep);
 }
 
 // Op supplies:  Op(scalars), WAVES_PER_EU (register budget), NCV, NPV, NPART, NOUT, out_width(o), out_offset(o) (slices of the per-point sums),
@@ -130,11 +143,11 @@ __global__ void __launch_bounds__(TILE_BLOCK, Op::WAVES_PER_EU) k_run_pass(RunAr
         for (int k = 0; k < RUN_LEN; ++k) rec[k] = Rec::load(a, base + (int64_t)k * nruns);
     }
 
-    const int rep = a.cam_rep, S = a.pt_stride, PS = 8 * S;
+    constexpr int PREC = pt_record_doubles(NPV);                // doubles of a point's LDS record
+    const int rep = a.cam_rep, S = a.pt_stride;
     double *rows = lds;                                         // cam_cap x ROW_LDS
     double *cacc = rows + (size_t)a.cam_cap * ROW_LDS;          // rep x NCV x nc (component-major)
-    double *xs = cacc + (size_t)a.cam_cap * NCV * rep;          // 3 x PS (component-major, swizzled)
-    double *pacc = xs + 3 * (size_t)PS;                         // NPV x PS
+    double *pts = cacc + (size_t)a.cam_cap * NCV * rep;         // 8 S records of PREC doubles: x (3), sums (NPV)
 
     for (int idx = tid; idx < nc * (ROW_LDS / 2); idx += TILE_BLOCK) {
         const int row = idx / (ROW_LDS / 2), piece = idx - row * (ROW_LDS / 2);
@@ -142,24 +155,29 @@ __global__ void __launch_bounds__(TILE_BLOCK, Op::WAVES_PER_EU) k_run_pass(RunAr
         ((double2 *)rows)[idx] = ((const double2 *)(a.T + (int64_t)j * CAM_ROW))[piece];
     }
     for (int idx = tid; idx < NCV * nc * rep; idx += TILE_BLOCK) cacc[idx] = 0.0;
-    if (a.X_gauge) {
+    {
         const double *G = a.X_gauge;
-        const double c0 = G[9], c1 = G[10], c2 = G[11], factor = G[12];
+        double g[13] = {1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0};
+        if (G) {
+#pragma unroll
+            for (int k = 0; k < 13; ++k) g[k] = G[k];
+        }
         for (int pt = tid; pt < np; pt += TILE_BLOCK) {
             const double *x = a.X + 3 * (int64_t)(p0 + pt);
-            const double d0 = x[0] - c0, d1 = x[1] - c1, d2 = x[2] - c2;
-            const int sw = pt_swz(pt, S);
+            double *rec_pt = pts + pt_swz(pt, S) * PREC;
+            if (G) {
+                const double d0 = x[0] - g[9], d1 = x[1] - g[10], d2 = x[2] - g[11];
 #pragma unroll
-            for (int comp = 0; comp < 3; ++comp)
-                xs[comp * PS + sw] = (d0 * G[comp] + d1 * G[3 + comp] + d2 * G[6 + comp]) * factor;
-        }
-    } else {
-        for (int idx = tid; idx < 3 * np; idx += TILE_BLOCK) {
-            const int pt = idx / 3, comp = idx - 3 * pt;
-            xs[comp * PS + pt_swz(pt, S)] = a.X[3 * (int64_t)p0 + idx];
+                for (int comp = 0; comp < 3; ++comp)
+                    rec_pt[comp] = (d0 * g[comp] + d1 * g[3 + comp] + d2 * g[6 + comp]) * g[12];
+            } else {
+#pragma unroll
+                for (int comp = 0; comp < 3; ++comp) rec_pt[comp] = x[comp];
+            }
+#pragma unroll
+            for (int v = 0; v < NPV; ++v) rec_pt[3 + v] = 0.0;
         }
     }
-    for (int idx = tid; idx < NPV * PS; idx += TILE_BLOCK) pacc[idx] = 0.0;
     const Op op(a.scalars);
     __syncthreads();
 
@@ -168,11 +186,8 @@ __global__ void __launch_bounds__(TILE_BLOCK, Op::WAVES_PER_EU) k_run_pass(RunAr
     for (int k = 0; k < NPART; ++k) part[k] = 0.0;
 
     for (int r = tid; r < nruns; r += TILE_BLOCK) {
-        if (r != tid) {
-            const int64_t base = rb * RUN_LEN + r;
-#pragma unroll
-            for (int k = 0; k < RUN_LEN; ++k) rec[k] = Rec::load(a, base + (int64_t)k * nruns);
-        }
+        const bool more = r + TILE_BLOCK < nruns;
+        const int64_t base_next = rb * RUN_LEN + (more ? r + TILE_BLOCK : r);
         const int slot = (int)(Rec::pack(rec[0]) & (RUN_MAX_CAMS - 1));   // one camera per run
         const int round = (int)(Rec::pack(rec[0]) >> RUN_SLOT_BITS) & 15;
         double2 rw[6];
@@ -184,15 +199,28 @@ __global__ void __launch_bounds__(TILE_BLOCK, Op::WAVES_PER_EU) k_run_pass(RunAr
         double cv[NCV];
 #pragma unroll
         for (int k = 0; k < NCV; ++k) cv[k] = 0.0;
+        double *pt_next = pts + pt_swz((int)(Rec::pack(rec[0]) >> 16), S) * PREC;
+        double xn[3] = {pt_next[0], pt_next[1], pt_next[2]};
 #pragma unroll
         for (int k = 0; k < RUN_LEN; ++k) {
-            const int sw = pt_swz((int)(Rec::pack(rec[k]) >> 16), S);
-            const double x[3] = {xs[sw], xs[PS + sw], xs[2 * PS + sw]};
+            double *pt_cur = pt_next;
+            const double x[3] = {xn[0], xn[1], xn[2]};
+            const bool valid = Rec::valid(rec[k]);
+            const double2 uv = Rec::uv(rec[k]);
+            if (k + 1 < RUN_LEN) {      // the next observation's point, ahead of this observation's atomics
+                pt_next = pts + pt_swz((int)(Rec::pack(rec[k + 1]) >> 16), S) * PREC;
+                xn[0] = pt_next[0];
+                xn[1] = pt_next[1];
+                xn[2] = pt_next[2];
+            }
+            // this slot of the thread's next run (of this run again after the last one: no branch)
+            rec[k] = Rec::load(a, base_next + (int64_t)k * nruns);
             double pv[NPV];
-            op.obs(Rec::valid(rec[k]), x, rw, Rec::uv(rec[k]), cv, pv, part);
+            op.obs(valid, x, rw, uv, cv, pv, part);
 #pragma unroll
             for (int v = 0; v < NPV; ++v)
-                __hip_atomic_fetch_add(pacc + v * PS + sw, pv[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(pt_cur + 3 + v, pv[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __builtin_amdgcn_sched_barrier(0);     // keep the eight bodies apart: their live ranges add up otherwise
         }
         double *acc = cacc + (size_t)(round & (rep - 1)) * NCV * nc + slot;
 #pragma unroll
@@ -217,9 +245,9 @@ __global__ void __launch_bounds__(TILE_BLOCK, Op::WAVES_PER_EU) k_run_pass(RunAr
             const int comp = (int)(gi - 3 * gpt), pt = (int)(gpt - p0);
             double x, g = 0.0;
             if (pt >= 0 && pt < np) {
-                const int sw = comp * PS + pt_swz(pt, S);
-                x = xs[sw];
-                g = pacc[sw];     // the gradient is the first slice of the per-point sums
+                const double *rec_pt = pts + pt_swz(pt, S) * PREC;
+                x = rec_pt[comp];
+                g = rec_pt[3 + comp];     // the gradient is the first slice of the per-point sums
             } else if (a.X_gauge) {   // a point nobody observes: only the stored value changes frame
                 const double *G = a.X_gauge, *xp = a.X + 3 * gpt;
                 x = ((xp[0] - G[9]) * G[comp] + (xp[1] - G[10]) * G[3 + comp] + (xp[2] - G[11]) * G[6 + comp]) * G[12];
@@ -245,7 +273,7 @@ __global__ void __launch_bounds__(TILE_BLOCK, Op::WAVES_PER_EU) k_run_pass(RunAr
         const int w = Op::out_width(o), off = Op::out_offset(o);
         for (int idx = w * lo + tid; idx < w * hi; idx += TILE_BLOCK) {
             const int pt = idx >= 0 ? idx / w : -1, k = idx - w * pt;
-            dst[(int64_t)w * p0 + idx] = (idx >= 0 && pt < np) ? pacc[(off + k) * PS + pt_swz(pt, S)] : 0.0;
+            dst[(int64_t)w * p0 + idx] = (idx >= 0 && pt < np) ? pts[pt_swz(pt, S) * PREC + 3 + off + k] : 0.0;
         }
     }
     for (int idx = tid; idx < NCV * nc; idx += TILE_BLOCK) {

@@ -1,0 +1,41 @@
+"""Observation-pass kernels at cfg3: gradient pass (stand-alone and with the fused point update inside a
+fit loop) and J^T J pass; median kernel time from the library's HIP events."""
+import importlib, sys, os, numpy as np, torch
+sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '.'))
+ba = importlib.import_module('3d_reconstruction_amd')
+sc = ba.scenes.orbit_scene(N=1_000_000, K=2000, track_len=10, seed=0)
+N, K = sc['N_local'], sc['K']
+nv = sc['i'].size
+algo_g = 24 * nv + 48 * N + 96 * K
+algo_j = 24 * nv + 24 * N + 24 * N + 48 * N + 24 * N + 96 * K + 216 * K
+what = sys.argv[1] if len(sys.argv) > 1 else 'gfj'
+sh = ba.engine.Shard(sc['i'], sc['j'], sc['uv'], N, K, sc['W'], sc['H'], 'cuda:0')
+sh.set_params(sc['X_0'], sc['C_0'], sc['Theta_0'], sc['phi_x_0'])
+sh.gauge_fix()
+def report(tag, ms, algo, extra=''):
+    m = float(np.median(ms))
+    print(f'{tag:34s} median {m*1e3:7.1f} us  min {min(ms)*1e3:7.1f}  {algo/m/1e6:8.1f} GB/s  frac {algo/m/1e6/8000:.3f} {extra}', flush=True)
+if 'g' in what:
+    for _ in range(23):
+        sh.eval(timed=True)
+    torch.cuda.synchronize()
+    report('gradient pass (stand-alone)', sh.eval_kernel_ms()[3:], algo_g, f'E={sh.energy():.12f} gC={float(sh.gC.abs().sum()):.12e} gX={float(sh.gX.abs().sum()):.12e}')
+if 'j' in what:
+    for _ in range(13):
+        sh.eval_jtj(timed=True)
+    torch.cuda.synchronize()
+    report('J^T J pass', sh.eval_kernel_ms()[3:], algo_j, f'E={sh.energy():.12f} B={float(sh.B.sum()):.12e} V={float(sh.V.sum()):.12e} Xphi={float(sh.Xphi.sum()):.12e}')
+if 'f' in what:
+    fit = ba.SceneFit(sh, lr=1e-3, max_iters=200, patience=1000, print_step=10 ** 9, printer=lambda *a: None)
+    fit.timed_every = 2
+    for _ in range(20):
+        fit.step()
+    sh.eval_kernel_ms()
+    torch.cuda.synchronize()
+    import time
+    t0 = time.perf_counter()
+    for _ in range(100):
+        fit.step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    report('gradient pass + fused point update', sh.eval_kernel_ms(), algo_g, f'iteration {dt/100*1e6:.1f} us  E[119]={fit.E[119]:.12f}')
