@@ -20,6 +20,7 @@ EVAL_REUSE_TABLE = 1024
 EVAL_POST = 2048
 EVAL_POINT_MAJOR = 4096
 EVAL_DEFER_FINALIZE = 8192
+EVAL_DENSE_BLOCKS = 16384
 
 _p = C.c_void_p
 _i64 = C.c_int64
@@ -36,7 +37,7 @@ SIGNATURES = {
     'ba_problem_create': (_int, [_i64, _i64, _i64, _p, _p, _p, _dbl, _dbl, _int, C.POINTER(_p)]),
     'ba_problem_destroy': (_int, [_p]),
     'ba_eval': (_int, [_p, _p, _p, _p, _p, _int, _p, _p, _p, _p, _p, _p]),
-    'ba_eval_jtj': (_int, [_p, _p, _p, _p, _p, _int] + [_p] * 11),
+    'ba_eval_jtj': (_int, [_p, _p, _p, _p, _p, _int] + [_p] * 10),
     'ba_schur_dim': (_int, [_i64, C.POINTER(_i64), C.POINTER(_i64)]),
     'ba_schur_build': (_int, [_p, _p, _dbl] + [_p] * 9 + [_int] + [_p] * 3),
     'ba_cholesky_solve': (_int, [_i64, _i64, _p, _p, C.POINTER(_int), _p]),

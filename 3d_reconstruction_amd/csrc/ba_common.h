@@ -80,6 +80,14 @@ struct ba_problem {
     int64_t total_runs = 0;
     int run_pt_stride = 0;            // LDS point capacity / 8
     int run_rep_grad = 1, run_rep_jtj = 1;   // copies of the camera accumulators per pass
+    // dense block layout of the tiles (see ba_blockpass.h); null when its padding would cost too much
+    uint32_t *brec = nullptr;         // total_units x 512 compact records
+    double2 *buv = nullptr;           // ... or pixel centres as doubles
+    int64_t *blk_ptr = nullptr;       // n_tiles + 1
+    int64_t total_units = 0;
+    double blk_fill = 0.0;            // observations / record slots
+    int blk_pt_stride = 0;            // LDS point capacity / 8
+    int blk_waves = 0;                // waves per workgroup of the block pass
     // scratch owned by the handle (device)
     double *cam_table = nullptr;  // K x CAM_ROW
     double *cam_sums = nullptr;   // 6 x K camera-frame sums (SoA: component-major), zero between passes

@@ -16,10 +16,12 @@
 //  at p2w:678-692 are never formed.)  All sums are un-normalised; the caller applies 1/|V|.
 #include "ba_common.h"
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include "ba_device.h"
 #include "ba_runpass.h"
+#include "ba_blockpass.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -740,9 +742,13 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_tile_fill(const int32_t *__restr
 
 // ---- gradient pass on camera runs (see ba_runpass.h) --------------------------------------------
 struct GradOp {
-    static constexpr int NCV = 6, NPV = 3, NPART = 2, NOUT = 1, WAVES_PER_EU = 4;
+    static constexpr int NCV = 6, NPV = 3, NPART = 2, NOUT = 1, WAVES_PER_EU = 4, WAVES_PER_EU_COMPACT = 4;
     __host__ __device__ static constexpr int out_width(int) { return 3; }
     __host__ __device__ static constexpr int out_offset(int) { return 0; }
+    __host__ __device__ static constexpr bool cv_used(int) { return true; }
+    static constexpr int NCV_LDS = 6;
+    __host__ __device__ static constexpr int cv_lds(int k) { return k; }
+    __host__ __device__ static constexpr int cv_from_lds(int c) { return c; }
     double f, pcx, pcy;
     __device__ explicit GradOp(const double *scalars) : f(scalars[SC_F]), pcx(scalars[SC_CX]), pcy(scalars[SC_CY]) {}
     // cv: camera-frame force (3) and torque (3); pv: world-frame dE/dX_i part; part: r.r, m.r
@@ -875,6 +881,46 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_run_fill(const uint32_t *__restr
                 rpack[idx] = word;
                 ruv[idx] = make_double2(__longlong_as_double(0x7ff8000000000000ll), 0.0);
             }
+        }
+    }
+}
+
+// Dense block layout (see ba_blockpass.h), pass 1: units per tile = chunks of 128 points x batches of 4 cameras.
+__global__ void k_block_count(const TileMeta *__restrict__ meta, int nt, int64_t *__restrict__ counts) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt) return;
+    const TileMeta tm = meta[t];
+    counts[t] = tm.e0 < tm.e1 ? (int64_t)((tm.np + BLK_PTS - 1) / BLK_PTS) * ((tm.nc + BLK_CAMS - 1) / BLK_CAMS) : 0;
+}
+
+// every record slot starts as a zero-weight record
+__global__ void k_block_clear(int64_t n, uint32_t *__restrict__ brec, double2 *__restrict__ buv) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    if (brec) brec[e] = 0x8000u;
+    else buv[e] = make_double2(__longlong_as_double(0x7ff8000000000000ll), 0.0);
+}
+
+// Pass 2: every observation of the tile goes to the slot its point and camera name.
+__global__ void __launch_bounds__(TILE_BLOCK) k_block_fill(const uint32_t *__restrict__ opack,
+                                                           const double2 *__restrict__ ouv,
+                                                           const TileMeta *__restrict__ meta,
+                                                           const int64_t *__restrict__ blk_ptr,
+                                                           uint32_t *__restrict__ brec, double2 *__restrict__ buv) {
+    const TileMeta tm = meta[blockIdx.x];
+    const int nchunk = (tm.np + BLK_PTS - 1) / BLK_PTS;
+    const int64_t ub = blk_ptr[blockIdx.x];
+    for (int e = tm.e0 + threadIdx.x; e < tm.e1; e += TILE_BLOCK) {
+        const uint32_t pk = opack[e];
+        const int pt = (int)(pk >> 16), slot = (int)(pk & 0xffffu);
+        const int64_t unit = ub + (int64_t)(slot / BLK_CAMS) * nchunk + pt / BLK_PTS;
+        const int64_t idx = (unit * 8 + (pt & 7)) * 64 + (slot % BLK_CAMS) * 16 + ((pt >> 3) & 15);
+        const double2 uv = ouv[e];
+        if (brec) {
+            const int px = (int)(uv.x - 0.5), py = (int)(uv.y - 0.5);
+            brec[idx] = ((uint32_t)px & 0xffffu) | ((uint32_t)py << 16);
+        } else {
+            buv[idx] = uv;
         }
     }
 }
@@ -1962,20 +2008,62 @@ static int build_runs(ba_problem *p) {
     while ((p->run_pt_stride & 3) != 2) ++p->run_pt_stride;   // 2 * odd, see pt_swz
     // copies of the camera accumulators: as many as keep the workgroup near a quarter of the LDS budget
     const size_t budget = 64 * 1024;
-    auto pick_rep = [&](int ncv, int npv, size_t limit, const char *env_name) {
+    auto pick_rep = [&](int ncv, int npv, int cam_cap, size_t limit, const char *env_name) {
         int rep = 2;
         if (const char *env = getenv(env_name)) rep = atoi(env);
         if (rep < 1) rep = 1;
-        while (rep > 1 && sizeof(double) * run_pass_lds_doubles(ncv, npv, p->cam_cap, p->run_pt_stride, rep) > limit)
+        while (rep > 1 && sizeof(double) * run_pass_lds_doubles(ncv, npv, cam_cap, p->run_pt_stride, rep) > limit)
             rep >>= 1;
         return rep;
     };
-    p->run_rep_grad = pick_rep(6, 3, budget / 2, "BA_CAM_REP");
-    p->run_rep_jtj = pick_rep(33, 12, 78 * 1024, "BA_CAM_REP_JTJ");   // two workgroups per CU
+    p->run_rep_grad = pick_rep(6, 3, p->cam_cap, budget / 2, "BA_CAM_REP");
+    p->run_rep_jtj = pick_rep(31, 9, p->cam_cap, 78 * 1024, "BA_CAM_REP_JTJ");   // two workgroups per CU at least
     if (getenv("BA_VERBOSE"))
         fprintf(stderr, "[ba] runs: records=%s total=%lld (%.3f x nV/8) pt_stride=%d rep_grad=%d rep_jtj=%d\n",
                 p->compact ? "i16" : "f64", (long long)p->total_runs, (double)p->total_runs * RUN_LEN / (double)p->nV, p->run_pt_stride,
                 p->run_rep_grad, p->run_rep_jtj);
+    return BA_OK;
+}
+
+// Lays the tiles out as dense blocks as well (see ba_blockpass.h) when that costs little padding.
+static int build_blocks(ba_problem *p) {
+    const int nt = p->n_tiles;
+    BA_HIP(hipMalloc(&p->blk_ptr, sizeof(int64_t) * (nt + 1)));
+    hipLaunchKernelGGL(k_block_count, dim3(cdiv(nt, 256)), dim3(256), 0, 0, (const TileMeta *)p->tile_meta, nt, p->blk_ptr);
+    const int n_scan_tiles = cdiv(nt, SCAN_TILE);
+    int64_t *tile_sums = nullptr;
+    BA_HIP(hipMalloc(&tile_sums, sizeof(int64_t) * (n_scan_tiles + 1)));
+    hipLaunchKernelGGL(k_scan_tiles, dim3(n_scan_tiles), dim3(1024), 0, 0, p->blk_ptr, (int64_t)nt, p->blk_ptr, tile_sums);
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(1), dim3(1024), 0, 0, tile_sums, n_scan_tiles);
+    hipLaunchKernelGGL(k_scan_add, dim3(cdiv(nt, 256)), dim3(256), 0, 0, p->blk_ptr, (int64_t)nt, tile_sums, n_scan_tiles);
+    hipError_t e = hipMemcpy(&p->total_units, p->blk_ptr + nt, sizeof(int64_t), hipMemcpyDeviceToHost);
+    hipFree(tile_sums);
+    BA_HIP(e);
+    const double fill = p->total_units > 0 ? (double)p->nV / ((double)p->total_units * BLK_UNIT) : 0.0;
+    double min_fill = 0.6;      // below this the padding costs more than the cheaper reductions save
+    if (const char *env = getenv("BA_BLOCK_MIN_FILL")) min_fill = atof(env);
+    p->blk_fill = fill;
+    if (fill < min_fill) {
+        hipFree(p->blk_ptr);
+        p->blk_ptr = nullptr;
+        p->total_units = 0;
+        return BA_OK;
+    }
+    const int64_t n_rec = p->total_units * BLK_UNIT;
+    if (p->compact) BA_HIP(hipMalloc(&p->brec, sizeof(uint32_t) * n_rec));
+    else BA_HIP(hipMalloc(&p->buv, sizeof(double2) * n_rec));
+    hipLaunchKernelGGL(k_block_clear, dim3(cdiv(n_rec, 256)), dim3(256), 0, 0, n_rec, p->brec, p->buv);
+    hipLaunchKernelGGL(k_block_fill, dim3(nt), dim3(TILE_BLOCK), 0, 0, p->opack, p->ouv, (const TileMeta *)p->tile_meta,
+                       p->blk_ptr, p->brec, p->buv);
+    BA_HIP(hipGetLastError());
+    // LDS point capacity 8 S: S = 4 mod 8 (see ba_blockpass.h), at least 16 slots per chunk of the largest tile
+    p->blk_pt_stride = 16 * ((p->pt_cap + BLK_PTS - 1) / BLK_PTS);
+    while ((p->blk_pt_stride & 7) != 4) ++p->blk_pt_stride;
+    const int nb_max = (p->cam_cap + BLK_CAMS - 1) / BLK_CAMS;
+    p->blk_waves = nb_max < 4 ? nb_max : 4;
+    if (getenv("BA_VERBOSE"))
+        fprintf(stderr, "[ba] blocks: records=%s units=%lld fill=%.3f pt_stride=%d waves=%d\n", p->compact ? "i16" : "f64",
+                (long long)p->total_units, fill, p->blk_pt_stride, p->blk_waves);
     return BA_OK;
 }
 
@@ -1987,7 +2075,7 @@ static int build_tiles(ba_problem *p) {
     const int64_t K = p->K, nV = p->nV;
     const int n_words = (int)((K + 31) >> 5);
     const size_t lds_budget = 64 * 1024;
-    int tobs = 3968;   // two camera runs per thread of the run pass ((2 * 256 - cameras of a tile) * 8)
+    int tobs = 3840;   // two camera runs per thread of the run pass (at most (2 * 256 - cameras of a tile) * 8 observations)
     if (const char *env = getenv("BA_TILE_OBS")) tobs = atoi(env);
     if (tobs < 64 || (size_t)n_words * 8 > lds_budget) return BA_OK;
     int *maxima = p->flag;  // 2 ints of the handle's flag buffer
@@ -2053,6 +2141,7 @@ static int build_tiles(ba_problem *p) {
     }
     if (p->tiles_worth) {
         if (int rc = build_runs(p)) return rc;
+        if (int rc = build_blocks(p)) return rc;
     }
     if (getenv("BA_VERBOSE"))
         fprintf(stderr, "[ba] tiles: tiled=%d worth=%d n_tiles=%d target_obs=%d cam_cap=%d pt_cap=%d rep=%d lds=%zu B cams/tile=%.1f\n",
@@ -2130,6 +2219,9 @@ int ba_problem_destroy(ba_problem *p) {
     hipFree(p->rrec);
     hipFree(p->ruv);
     hipFree(p->run_ptr);
+    hipFree(p->brec);
+    hipFree(p->buv);
+    hipFree(p->blk_ptr);
     hipFree(p->cam_table);
     hipFree(p->cam_sums);
     hipFree(p->partials);

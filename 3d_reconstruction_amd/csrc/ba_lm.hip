@@ -15,6 +15,7 @@
 // rotated once per camera afterwards.
 #include "ba_device.h"
 #include "ba_runpass.h"
+#include "ba_blockpass.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -24,7 +25,7 @@
 namespace ba {
 
 constexpr int CAMV = 33;  // per camera: force (3), torque (3), B' upper triangle (21), b' (6)
-constexpr int PTV = 12;   // per point: gradient (3), V upper triangle (6), point x phi (3)
+constexpr int PTV = 9;    // per point: gradient (3), V upper triangle (6)
 
 struct JtjArgs {
     const uint32_t *opack;
@@ -38,7 +39,6 @@ struct JtjArgs {
     const double *scalars;
     double *gX;        // N x 3
     double *V;         // N x 6
-    double *Xphi;      // N x 3
     double *cam_sums;  // CAMV x K, component-major (pre-zeroed)
     double *partials;  // per tile {sum r^2, sum m.r, sum m.m}
 };
@@ -51,8 +51,20 @@ struct ObsJac {
     double G0[6], G1[6];    // rows of the camera-frame camera Jacobian
 };
 
+// 1 / x without the range scaling and fix-up of the IEEE division sequence (x is a depth along the
+// optical axis: far from the ends of the exponent range): hardware estimate and two Newton steps,
+// relative error of a few 1e-16
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+// valid = false (a zero-weight record, any point / camera pair): every Jacobian entry and m come out
+// as zero (they carry the factor 1 / q2, which is replaced by 0)
 __device__ __forceinline__ ObsJac obs_jacobian(const double *x, const double2 *rw, double f, double pcx, double pcy,
-                                               double2 uv) {
+                                               double2 uv, bool valid = true) {
     const double2 t0 = rw[0], t1 = rw[1], t2 = rw[2], t3 = rw[3], t4 = rw[4], t5 = rw[5];
     const double R00 = t0.x, R01 = t0.y, R02 = t1.x, R10 = t1.y, R11 = t2.x, R12 = t2.y, R20 = t3.x, R21 = t3.y,
                  R22 = t4.x;
@@ -61,7 +73,7 @@ __device__ __forceinline__ ObsJac obs_jacobian(const double *x, const double2 *r
     o.q0 = R00 * d0 + R10 * d1 + R20 * d2;
     o.q1 = R01 * d0 + R11 * d1 + R21 * d2;
     o.q2 = R02 * d0 + R12 * d1 + R22 * d2;
-    const double inv = 1.0 / o.q2;
+    const double inv = valid ? fast_rcp(o.q2) : 0.0;
     o.m0 = o.q0 * inv;
     o.m1 = o.q1 * inv;
     o.r0 = f * o.m0 + pcx - uv.x;
@@ -117,7 +129,7 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_jtj_tiled(JtjArgs a) {
     for (int idx = tid; idx < CAMV * nc; idx += TILE_BLOCK) cacc[idx] = 0.0;
     for (int idx = tid; idx < 3 * np; idx += TILE_BLOCK) xs[idx] = a.X[3 * (int64_t)p0 + idx];
     for (int idx = tid; idx < PTV * np; idx += TILE_BLOCK) pacc[idx] = 0.0;
-    const double f = a.scalars[SC_F], pcx = a.scalars[SC_CX], pcy = a.scalars[SC_CY], dphi = a.scalars[SC_DPHI];
+    const double f = a.scalars[SC_F], pcx = a.scalars[SC_CX], pcy = a.scalars[SC_CY];
     __syncthreads();
 
     double esum = 0.0, psum = 0.0, hsum = 0.0;
@@ -154,7 +166,7 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_jtj_tiled(JtjArgs a) {
                 __hip_atomic_fetch_add(acc + k * nc, cv[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
 
-        // point side: 12 values, segmented scan inside 16-lane rows, run tails add to LDS
+        // point side: 9 values, segmented scan inside 16-lane rows, run tails add to LDS
         double pv[PTV];
 #pragma unroll
         for (int k = 0; k < 3; ++k) pv[k] = o.jx0[k] * r0 + o.jx1[k] * r1;
@@ -164,8 +176,6 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_jtj_tiled(JtjArgs a) {
         pv[6] = vm * (o.jx0[1] * o.jx0[1] + o.jx1[1] * o.jx1[1]);
         pv[7] = vm * (o.jx0[1] * o.jx0[2] + o.jx1[1] * o.jx1[2]);
         pv[8] = vm * (o.jx0[2] * o.jx0[2] + o.jx1[2] * o.jx1[2]);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) pv[9 + k] = vm * dphi * (o.jx0[k] * o.m0 + o.jx1[k] * o.m1);
 
         const int lane16 = lane & 15;
         const int ip = row_shr<1>(li);
@@ -211,7 +221,6 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_jtj_tiled(JtjArgs a) {
         const int pt = idx >= 0 ? idx / 3 : -1, k = idx - 3 * pt;
         const bool in = idx >= 0 && pt < np;
         a.gX[3 * (int64_t)p0 + idx] = in ? pacc[PTV * pt + k] : 0.0;
-        a.Xphi[3 * (int64_t)p0 + idx] = in ? pacc[PTV * pt + 9 + k] : 0.0;
     }
     for (int idx = 6 * lo + tid; idx < 6 * hi; idx += TILE_BLOCK) {
         const int pt = idx >= 0 ? idx / 6 : -1, k = idx - 6 * pt;
@@ -228,54 +237,59 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_jtj_tiled(JtjArgs a) {
 // The same pass on camera runs (see ba_runpass.h): 33 camera sums in registers over a run, 12 point
 // sums as conflict-free LDS atomics.
 struct JtjOp {
-    static constexpr int NCV = CAMV, NPV = PTV, NPART = 3, NOUT = 3, WAVES_PER_EU = 2;
-    // per-point sums: gradient (3) -> gX, V upper triangle (6) -> V, point x phi (3) -> Xphi
+    // register budget: three waves per SIMD with the 8-byte records, two with the long ones
+    static constexpr int NCV = CAMV, NPV = PTV, NPART = 3, NOUT = 2, WAVES_PER_EU = 2, WAVES_PER_EU_COMPACT = 3;
+    // per-point sums: gradient (3) -> gX, V upper triangle (6) -> V
     __host__ __device__ static constexpr int out_width(int o) { return o == 1 ? 6 : 3; }
-    __host__ __device__ static constexpr int out_offset(int o) { return o == 0 ? 0 : (o == 1 ? 3 : 9); }
-    double f, pcx, pcy, dphi;
-    __device__ explicit JtjOp(const double *scalars)
-        : f(scalars[SC_F]), pcx(scalars[SC_CX]), pcy(scalars[SC_CY]), dphi(scalars[SC_DPHI]) {}
+    __host__ __device__ static constexpr int out_offset(int o) { return o == 0 ? 0 : 3; }
+    // camera sums 7 (block entry (0,1): zero) and 12 (entry (1,1): equal to (0,0)) are not accumulated
+    __host__ __device__ static constexpr bool cv_used(int k) { return k != 7 && k != 12; }
+    static constexpr int NCV_LDS = CAMV - 2;
+    __host__ __device__ static constexpr int cv_lds(int k) { return k < 7 ? k : (k < 12 ? k - 1 : k - 2); }
+    __host__ __device__ static constexpr int cv_from_lds(int c) { return c < 7 ? c : (c < 11 ? c + 1 : c + 2); }
+    double f, pcx, pcy;
+    __device__ explicit JtjOp(const double *scalars) : f(scalars[SC_F]), pcx(scalars[SC_CX]), pcy(scalars[SC_CY]) {}
+    // Sums of products are written as chains of fused multiply-adds into the accumulator (two
+    // instructions per two-term product instead of multiply, multiply-add, add).
     __device__ __forceinline__ void obs(bool valid, const double (&x)[3], const double2 (&rw)[6], double2 uv,
                                         double (&cv)[CAMV], double (&pv)[PTV], double (&part)[3]) const {
-        // a zero-weight record acts through f = 0: every Jacobian entry carries the factor f / q2
-        const ObsJac o = obs_jacobian(x, rw, valid ? f : 0.0, pcx, pcy, uv);
+        const ObsJac o = obs_jacobian(x, rw, f, pcx, pcy, uv, valid);
         const double r0 = valid ? o.r0 : 0.0, r1 = valid ? o.r1 : 0.0;
-        part[0] += r0 * r0 + r1 * r1;
-        part[1] += o.m0 * r0 + o.m1 * r1;
-        part[2] += valid ? o.m0 * o.m0 + o.m1 * o.m1 : 0.0;
+        part[0] = fma(r0, r0, fma(r1, r1, part[0]));
+        part[1] = fma(o.m0, r0, fma(o.m1, r1, part[1]));
+        part[2] = fma(o.m0, o.m0, fma(o.m1, o.m1, part[2]));      // m = 0 for a zero-weight record
         // G0[1] = G1[0] = 0 and G0[0] = G1[1] = -fi: the products with them are written out
         const double fi = o.fi;
-        cv[0] += fi * r0;
-        cv[1] += fi * r1;
+        cv[0] = fma(fi, r0, cv[0]);
+        cv[1] = fma(fi, r1, cv[1]);
 #pragma unroll
-        for (int k = 2; k < 6; ++k) cv[k] -= o.G0[k] * r0 + o.G1[k] * r1;
-        const double fi2 = fi * fi;
-        cv[6] += fi2;                               // (0,0)
-        // (0,1) stays zero
+        for (int k = 2; k < 6; ++k) cv[k] = fma(-o.G0[k], r0, fma(-o.G1[k], r1, cv[k]));
+        cv[6] = fma(fi, fi, cv[6]);                 // (0,0); (1,1) is the same sum and (0,1) is zero:
+                                                    // cv[7] and cv[12] stay unused, k_jtj_finalize fills them in
 #pragma unroll
-        for (int q = 2; q < 6; ++q) cv[6 + q] -= fi * o.G0[q];    // (0,q)
-        cv[12] += fi2;                              // (1,1)
+        for (int q = 2; q < 6; ++q) cv[6 + q] = fma(-fi, o.G0[q], cv[6 + q]);    // (0,q)
 #pragma unroll
-        for (int q = 2; q < 6; ++q) cv[11 + q] -= fi * o.G1[q];   // (1,q)
+        for (int q = 2; q < 6; ++q) cv[11 + q] = fma(-fi, o.G1[q], cv[11 + q]);  // (1,q)
         int idx = 17;
 #pragma unroll
         for (int p = 2; p < 6; ++p)
 #pragma unroll
-            for (int q = p; q < 6; ++q) cv[idx++] += o.G0[p] * o.G0[q] + o.G1[p] * o.G1[q];
-        cv[27] -= fi * o.m0;
-        cv[28] -= fi * o.m1;
+            for (int q = p; q < 6; ++q) {
+                cv[idx] = fma(o.G0[p], o.G0[q], fma(o.G1[p], o.G1[q], cv[idx]));
+                ++idx;
+            }
+        cv[27] = fma(-fi, o.m0, cv[27]);
+        cv[28] = fma(-fi, o.m1, cv[28]);
 #pragma unroll
-        for (int k = 2; k < 6; ++k) cv[27 + k] += o.G0[k] * o.m0 + o.G1[k] * o.m1;
+        for (int k = 2; k < 6; ++k) cv[27 + k] = fma(o.G0[k], o.m0, fma(o.G1[k], o.m1, cv[27 + k]));
 #pragma unroll
-        for (int k = 0; k < 3; ++k) pv[k] = o.jx0[k] * r0 + o.jx1[k] * r1;
-        pv[3] = o.jx0[0] * o.jx0[0] + o.jx1[0] * o.jx1[0];
-        pv[4] = o.jx0[0] * o.jx0[1] + o.jx1[0] * o.jx1[1];
-        pv[5] = o.jx0[0] * o.jx0[2] + o.jx1[0] * o.jx1[2];
-        pv[6] = o.jx0[1] * o.jx0[1] + o.jx1[1] * o.jx1[1];
-        pv[7] = o.jx0[1] * o.jx0[2] + o.jx1[1] * o.jx1[2];
-        pv[8] = o.jx0[2] * o.jx0[2] + o.jx1[2] * o.jx1[2];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) pv[9 + k] = dphi * (o.jx0[k] * o.m0 + o.jx1[k] * o.m1);
+        for (int k = 0; k < 3; ++k) pv[k] = fma(o.jx0[k], r0, o.jx1[k] * r1);
+        pv[3] = fma(o.jx0[0], o.jx0[0], o.jx1[0] * o.jx1[0]);
+        pv[4] = fma(o.jx0[0], o.jx0[1], o.jx1[0] * o.jx1[1]);
+        pv[5] = fma(o.jx0[0], o.jx0[2], o.jx1[0] * o.jx1[2]);
+        pv[6] = fma(o.jx0[1], o.jx0[1], o.jx1[1] * o.jx1[1]);
+        pv[7] = fma(o.jx0[1], o.jx0[2], o.jx1[1] * o.jx1[2]);
+        pv[8] = fma(o.jx0[2], o.jx0[2], o.jx1[2] * o.jx1[2]);
     }
 };
 
@@ -335,6 +349,7 @@ __global__ void __launch_bounds__(256) k_jtj_finalize(int64_t K, int n_partials,
     double c[CAMV];
 #pragma unroll
     for (int k = 0; k < CAMV; ++k) c[k] = cam_sums[(int64_t)k * K + j];
+    c[12] = c[6];       // entry (1,1) of the camera-frame block equals entry (0,0) (see JtjOp::cv_used)
     // gradient: sum J_cam^T r = T^T sum G^T r = -T^T (force, torque)
 #pragma unroll
     for (int al = 0; al < 6; ++al) {
@@ -440,7 +455,8 @@ struct SchurArgs {
     int64_t N, K, ld;
     double lambda;
     const double *X, *T, *scalars;
-    const double *V, *Xphi, *gX;
+    const double *V, *gX;
+    double *Xphi;            // N x 3, written: point x phi column
     double *S, *rhs;
     int max_deg;
 };
@@ -460,7 +476,8 @@ struct SchurTileArgs {
     int cam_cap, max_deg;
     double lambda;
     const double *X, *T, *scalars;
-    const double *V, *Xphi, *gX;
+    const double *V, *gX;
+    double *Xphi;            // N x 3, written: point x phi column
     double *S, *rhs;
 };
 
@@ -493,18 +510,32 @@ __global__ void __launch_bounds__(SCHUR_TILE_BLOCK) k_schur_tile(SchurTileArgs a
     const int n_st = 18 * nc * (nc + 1);
     for (int idx = tid; idx < n_st; idx += SCHUR_TILE_BLOCK) St[idx] = 0.0;
     for (int idx = tid; idx < 2 * 6 * a.cam_cap + 2; idx += SCHUR_TILE_BLOCK) sphi_t[idx] = 0.0;
-    const double f = a.scalars[SC_F], pcx = a.scalars[SC_CX], pcy = a.scalars[SC_CY];
+    const double f = a.scalars[SC_F], pcx = a.scalars[SC_CX], pcy = a.scalars[SC_CY], dphi = a.scalars[SC_DPHI];
     __syncthreads();
 
     for (int pt = wid; pt < np; pt += SCHUR_TILE_BLOCK / 64) {
         const int64_t i = p0 + pt;
         const int64_t eb = a.row_ptr[i];
         const int deg = (int)(a.row_ptr[i + 1] - eb);
-        if (deg == 0) continue;
+        if (deg == 0) {
+            if (lane < 3) a.Xphi[3 * i + lane] = 0.0;
+            continue;
+        }
         double Vi[6];
         inv_sym3(a.V + 6 * i, a.lambda, Vi);
         const double x[3] = {a.X[3 * i], a.X[3 * i + 1], a.X[3 * i + 2]};
-        const double wp[3] = {a.Xphi[3 * i], a.Xphi[3 * i + 1], a.Xphi[3 * i + 2]};
+        // point x phi column w = dphi sum_obs J_X^T m (not kept by the J^T J pass: summed here, stored for the back-substitution)
+        double wp[3] = {0.0, 0.0, 0.0};
+        for (int o = lane; o < deg; o += 64) {
+            const int64_t e = eb + o;
+            const int slot = (int)(a.opack[e] & 0xffffu);
+            const ObsJac ob = obs_jacobian(x, (const double2 *)(rows + slot * CAM_ROW), f, pcx, pcy, a.ouv[e]);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) wp[k] += ob.jx0[k] * ob.m0 + ob.jx1[k] * ob.m1;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) wp[k] = dphi * wave_sum(wp[k]);
+        if (lane < 3) a.Xphi[3 * i + lane] = lane == 0 ? wp[0] : (lane == 1 ? wp[1] : wp[2]);
         const double gx[3] = {a.gX[3 * i], a.gX[3 * i + 1], a.gX[3 * i + 2]};
         const double zw[3] = {Vi[0] * wp[0] + Vi[1] * wp[1] + Vi[2] * wp[2], Vi[1] * wp[0] + Vi[3] * wp[1] + Vi[4] * wp[2],
                               Vi[2] * wp[0] + Vi[4] * wp[1] + Vi[5] * wp[2]};
@@ -612,15 +643,28 @@ __global__ void __launch_bounds__(256) k_schur_points(SchurArgs a) {
     if (i >= a.N) return;
     const int64_t e0 = a.row_ptr[i], e1 = a.row_ptr[i + 1];
     const int deg = (int)(e1 - e0);
-    if (deg == 0) return;
+    if (deg == 0) {
+        if (lane < 3) a.Xphi[3 * i + lane] = 0.0;
+        return;
+    }
     double *Wl = lds + (size_t)wid * a.max_deg * 37;
     double *Zl = Wl + (size_t)a.max_deg * 18;
     int *jl = (int *)(Zl + (size_t)a.max_deg * 18);
-    const double f = a.scalars[SC_F], pcx = a.scalars[SC_CX], pcy = a.scalars[SC_CY];
+    const double f = a.scalars[SC_F], pcx = a.scalars[SC_CX], pcy = a.scalars[SC_CY], dphi = a.scalars[SC_DPHI];
     double Vi[6];
     inv_sym3(a.V + 6 * i, a.lambda, Vi);
     const double x[3] = {a.X[3 * i], a.X[3 * i + 1], a.X[3 * i + 2]};
-    const double wp[3] = {a.Xphi[3 * i], a.Xphi[3 * i + 1], a.Xphi[3 * i + 2]};
+    // point x phi column w = dphi sum_obs J_X^T m (summed here, stored for the back-substitution)
+    double wp[3] = {0.0, 0.0, 0.0};
+    for (int o = lane; o < deg; o += 64) {
+        const int64_t e = e0 + o;
+        const ObsJac ob = obs_jacobian(x, (const double2 *)(a.T + (int64_t)a.oj[e] * CAM_ROW), f, pcx, pcy, a.ouv[e]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) wp[k] += ob.jx0[k] * ob.m0 + ob.jx1[k] * ob.m1;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) wp[k] = dphi * wave_sum(wp[k]);
+    if (lane < 3) a.Xphi[3 * i + lane] = lane == 0 ? wp[0] : (lane == 1 ? wp[1] : wp[2]);
     const double gx[3] = {a.gX[3 * i], a.gX[3 * i + 1], a.gX[3 * i + 2]};
     // V'^-1 wphi and V'^-1 gX
     const double zw[3] = {Vi[0] * wp[0] + Vi[1] * wp[1] + Vi[2] * wp[2], Vi[1] * wp[0] + Vi[3] * wp[1] + Vi[4] * wp[2],
@@ -789,10 +833,10 @@ using namespace ba;
 extern "C" {
 
 int ba_eval_jtj(ba_problem *p, const double *X, const double *C, const double *Theta, const double *phi, int flags,
-                double *E_sum, double *gX, double *gC, double *gTheta, double *gphi, double *V, double *Xphi, double *B,
+                double *E_sum, double *gX, double *gC, double *gTheta, double *gphi, double *V, double *B,
                 double *bphi, double *hphi, void *stream) {
     BA_REQUIRE(p && X && C && Theta && phi, "ba_eval_jtj: null pointer");
-    BA_REQUIRE(E_sum && gX && gC && gTheta && gphi && V && Xphi && B && bphi && hphi, "ba_eval_jtj: null output");
+    BA_REQUIRE(E_sum && gX && gC && gTheta && gphi && V && B && bphi && hphi, "ba_eval_jtj: null output");
     if (!p->tiled) {
         set_error("ba_eval_jtj: the scene has no LDS tiles (camera lists too long for a workgroup)");
         return BA_ERR_STATE;
@@ -800,9 +844,12 @@ int ba_eval_jtj(ba_problem *p, const double *X, const double *C, const double *T
     hipStream_t st = (hipStream_t)stream;
     const int64_t K = p->K;
     const size_t lds_runs = sizeof(double) * run_pass_lds_doubles<JtjOp>(p->cam_cap, p->run_pt_stride, p->run_rep_jtj);
-    const bool use_runs = p->run_ptr && !(flags & BA_EVAL_POINT_MAJOR) && lds_runs <= 160 * 1024 - 256;
-    const size_t lds = use_runs ? lds_runs
-                                : sizeof(double) * ((size_t)(ROW_LDS + CAMV) * p->cam_cap + (size_t)(3 + PTV) * p->pt_cap);
+    const size_t lds_blocks = sizeof(double) * block_pass_lds_doubles(PTV, p->cam_cap, p->blk_pt_stride);
+    const bool use_blocks = p->blk_ptr && (flags & BA_EVAL_DENSE_BLOCKS) && !(flags & BA_EVAL_POINT_MAJOR) && lds_blocks <= 160 * 1024 - 256;
+    const bool use_runs = !use_blocks && p->run_ptr && !(flags & BA_EVAL_POINT_MAJOR) && lds_runs <= 160 * 1024 - 256;
+    const size_t lds = use_blocks ? lds_blocks
+                       : use_runs ? lds_runs
+                                  : sizeof(double) * ((size_t)(ROW_LDS + CAMV) * p->cam_cap + (size_t)(3 + PTV) * p->pt_cap);
     if (lds > 160 * 1024 - 256) {
         set_error("ba_eval_jtj: tile accumulators exceed the LDS of a workgroup");
         return BA_ERR_STATE;
@@ -825,7 +872,6 @@ int ba_eval_jtj(ba_problem *p, const double *X, const double *C, const double *T
     a.scalars = p->scalars;
     a.gX = gX;
     a.V = V;
-    a.Xphi = Xphi;
     a.cam_sums = p->cam_sums_jtj;
     a.partials = p->partials_jtj;
     RunArgs ra;
@@ -844,15 +890,35 @@ int ba_eval_jtj(ba_problem *p, const double *X, const double *C, const double *T
     ra.scalars = p->scalars;
     ra.out[0] = gX;
     ra.out[1] = V;
-    ra.out[2] = Xphi;
     ra.cam_sums = p->cam_sums_jtj;
     ra.partials = p->partials_jtj;
-    const void *fn = !use_runs ? (const void *)k_jtj_tiled
+    BlockArgs bk;
+    bk.brec = p->brec;
+    bk.buv = p->buv;
+    bk.blk_ptr = p->blk_ptr;
+    bk.meta = a.meta;
+    bk.cam_list = p->cam_list;
+    bk.K = (int)K;
+    bk.cam_cap = p->cam_cap;
+    bk.pt_stride = p->blk_pt_stride;
+    bk.X = X;
+    bk.T = p->cam_table;
+    bk.scalars = p->scalars;
+    bk.out[0] = gX;
+    bk.out[1] = V;
+    bk.cam_sums = p->cam_sums_jtj;
+    bk.partials = p->partials_jtj;
+    const void *fn = use_blocks ? (p->compact ? (const void *)k_block_pass<JtjOp, BlkRecI16> : (const void *)k_block_pass<JtjOp, BlkRecF64>)
+                     : !use_runs ? (const void *)k_jtj_tiled
                      : p->compact ? (const void *)k_run_pass<JtjOp, RecI16> : (const void *)k_run_pass<JtjOp, RecF64>;
     if (lds > 64 * 1024) BA_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const bool timed = (flags & BA_EVAL_TIMED) != 0 && p->ev_count < TIMING_RING;
     if (timed) BA_HIP(hipEventRecord(p->ev_begin[p->ev_count], st));
-    if (use_runs && p->compact)
+    if (use_blocks && p->compact)
+        hipLaunchKernelGGL((k_block_pass<JtjOp, BlkRecI16>), dim3(p->n_tiles), dim3(64 * p->blk_waves), lds, st, bk);
+    else if (use_blocks)
+        hipLaunchKernelGGL((k_block_pass<JtjOp, BlkRecF64>), dim3(p->n_tiles), dim3(64 * p->blk_waves), lds, st, bk);
+    else if (use_runs && p->compact)
         hipLaunchKernelGGL((k_run_pass<JtjOp, RecI16>), dim3(p->n_tiles), dim3(TILE_BLOCK), lds, st, ra);
     else if (use_runs)
         hipLaunchKernelGGL((k_run_pass<JtjOp, RecF64>), dim3(p->n_tiles), dim3(TILE_BLOCK), lds, st, ra);
@@ -881,7 +947,7 @@ static int ensure_row_ptr(ba_problem *p) {
     return BA_OK;
 }
 
-int ba_schur_build(ba_problem *p, const double *X, double lambda, const double *V, const double *Xphi, const double *gX,
+int ba_schur_build(ba_problem *p, const double *X, double lambda, const double *V, double *Xphi, const double *gX,
                    const double *B, const double *bphi, const double *hphi, const double *gC, const double *gTheta,
                    const double *gphi, int with_camera_blocks, double *S, double *rhs, void *stream) {
     BA_REQUIRE(p && X && V && Xphi && gX && B && bphi && hphi && gC && gTheta && gphi && S && rhs,

@@ -26,10 +26,10 @@
 //
 // Point data in LDS: one record per point, [x (3) | per-point sums (NPV) | pad to an odd number of
 // doubles], at record index pt_swz(p) = (p mod 8) * S + p / 8 with S = 2 * odd, which maps those 16
-// points to 16 different bank pairs (an odd record length keeps that property).  Every field of a
-// point is then a constant offset from one address register.
+// points to 16 different bank pairs (an odd record length keeps that property; an odd S measured
+// slower).  Every field of a point is then a constant offset from one address register.
 //
-// Latencies: the LDS returns results in order, so a read issued behind the 3 / 12 atomics of the
+// Latencies: the LDS returns results in order, so a read issued behind the 3 / 9 atomics of the
 // previous observation waits for them; the point of observation k + 1 is therefore fetched before
 // the arithmetic of observation k starts, and the records of the thread's next run are requested
 // as soon as those of the current run have been decoded.
@@ -113,14 +113,19 @@ __host__ __device__ inline size_t run_pass_lds_doubles(int ncv, int npv, int cam
 }
 template <class Op>
 __host__ __device__ inline size_t run_pass_lds_doubles(int cam_cap, int pt_stride, int rep) {
-    return run_pass_lds_doubles(Op::NCV, Op::NPV, cam_cap, pt_stride, rep);
+    return run_pass_lds_doubles(Op::NCV_LDS, Op::NPV, cam_cap, pt_stride, rep);
 }
 
-// Op supplies:  Op(scalars), WAVES_PER_EU (register budget), NCV, NPV, NPART, NOUT, out_width(o), out_offset(o) (slices of the per-point sums),
+// Op supplies:  Op(scalars), WAVES_PER_EU / WAVES_PER_EU_COMPACT (register budget with long / 8-byte records),
+//   cv_used(k) (false: camera sum k is never accumulated and is not flushed), NCV_LDS (number of used sums),
+//   cv_lds(k) / cv_from_lds(c) (position of sum k among the used ones and back; the LDS accumulators hold only
+//   those: with 160 KB of LDS per CU in granules of 1280 bytes, three workgroups fit if each stays within 53 760
+//   bytes, and the J^T J pass at ~380 points and up to 20 cameras per tile is within a few hundred bytes of that), NCV, NPV, NPART, NOUT, out_width(o), out_offset(o) (slices of the per-point sums),
 //   obs(valid, x[3], rw[6], uv, cv[NCV] (+=), pv[NPV] (=), part[NPART] (+=)); everything it adds is zero when !valid
 template <class Op, class Rec>
-__global__ void __launch_bounds__(TILE_BLOCK, Op::WAVES_PER_EU) k_run_pass(RunArgs a) {
-    constexpr int NCV = Op::NCV, NPV = Op::NPV, NPART = Op::NPART;
+__global__ void __launch_bounds__(TILE_BLOCK, sizeof(typename Rec::raw_t) <= 8 ? Op::WAVES_PER_EU_COMPACT : Op::WAVES_PER_EU)
+    k_run_pass(RunArgs a) {
+    constexpr int NCV = Op::NCV, NCVL = Op::NCV_LDS, NPV = Op::NPV, NPART = Op::NPART;
     extern __shared__ double lds[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int t = blockIdx.x;
@@ -146,15 +151,15 @@ __global__ void __launch_bounds__(TILE_BLOCK, Op::WAVES_PER_EU) k_run_pass(RunAr
     constexpr int PREC = pt_record_doubles(NPV);                // doubles of a point's LDS record
     const int rep = a.cam_rep, S = a.pt_stride;
     double *rows = lds;                                         // cam_cap x ROW_LDS
-    double *cacc = rows + (size_t)a.cam_cap * ROW_LDS;          // rep x NCV x nc (component-major)
-    double *pts = cacc + (size_t)a.cam_cap * NCV * rep;         // 8 S records of PREC doubles: x (3), sums (NPV)
+    double *cacc = rows + (size_t)a.cam_cap * ROW_LDS;          // rep x NCVL x nc (component-major, used sums only)
+    double *pts = cacc + (size_t)a.cam_cap * NCVL * rep;         // 8 S records of PREC doubles: x (3), sums (NPV)
 
     for (int idx = tid; idx < nc * (ROW_LDS / 2); idx += TILE_BLOCK) {
         const int row = idx / (ROW_LDS / 2), piece = idx - row * (ROW_LDS / 2);
         const int j = tm.j0 >= 0 ? tm.j0 + row : a.cam_list[cb + row];
         ((double2 *)rows)[idx] = ((const double2 *)(a.T + (int64_t)j * CAM_ROW))[piece];
     }
-    for (int idx = tid; idx < NCV * nc * rep; idx += TILE_BLOCK) cacc[idx] = 0.0;
+    for (int idx = tid; idx < NCVL * nc * rep; idx += TILE_BLOCK) cacc[idx] = 0.0;
     {
         const double *G = a.X_gauge;
         double g[13] = {1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0};
@@ -222,10 +227,11 @@ __global__ void __launch_bounds__(TILE_BLOCK, Op::WAVES_PER_EU) k_run_pass(RunAr
                 __hip_atomic_fetch_add(pt_cur + 3 + v, pv[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __builtin_amdgcn_sched_barrier(0);     // keep the eight bodies apart: their live ranges add up otherwise
         }
-        double *acc = cacc + (size_t)(round & (rep - 1)) * NCV * nc + slot;
+        double *acc = cacc + (size_t)(round & (rep - 1)) * NCVL * nc + slot;
 #pragma unroll
         for (int k = 0; k < NCV; ++k)
-            __hip_atomic_fetch_add(acc + k * nc, cv[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (Op::cv_used(k))
+                __hip_atomic_fetch_add(acc + Op::cv_lds(k) * nc, cv[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 
 #pragma unroll
@@ -276,11 +282,12 @@ __global__ void __launch_bounds__(TILE_BLOCK, Op::WAVES_PER_EU) k_run_pass(RunAr
             dst[(int64_t)w * p0 + idx] = (idx >= 0 && pt < np) ? pts[pt_swz(pt, S) * PREC + 3 + off + k] : 0.0;
         }
     }
-    for (int idx = tid; idx < NCV * nc; idx += TILE_BLOCK) {
-        const int comp = idx / nc, slot = idx - comp * nc;
+    for (int idx = tid; idx < NCVL * nc; idx += TILE_BLOCK) {
+        const int cl = idx / nc, slot = idx - cl * nc;
+        const int comp = Op::cv_from_lds(cl);
         const int j = tm.j0 >= 0 ? tm.j0 + slot : a.cam_list[cb + slot];
         double v = cacc[idx];
-        for (int r = 1; r < rep; ++r) v += cacc[idx + (size_t)r * NCV * nc];
+        for (int r = 1; r < rep; ++r) v += cacc[idx + (size_t)r * NCVL * nc];
         __hip_atomic_fetch_add(a.cam_sums + (int64_t)comp * a.K + j, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }

@@ -382,18 +382,17 @@ class Shard:
             self.S, self.rhs = z(self.ld_red, self.ld_red), z(self.ld_red)
             self.dX, self.dcam = z(self.N, 3), z(6 * self.K + 1)
 
-    def eval_jtj(self, timed=False, point_major=False):
-        """Fused pass that also leaves the Gauss-Newton blocks V, Xphi (this shard's points) and
+    def eval_jtj(self, timed=False, point_major=False, dense_blocks=False):
+        """Fused pass that also leaves the Gauss-Newton blocks V (this shard's points) and
         B, bphi, hphi (summed over the GPUs together with the gradient block)."""
         self._lm_buffers()
         flags = (_lib.EVAL_TIMED if timed else 0) | (_lib.EVAL_REUSE_TABLE if self.table_valid else 0) | \
-                (_lib.EVAL_POINT_MAJOR if point_major else 0)
+                (_lib.EVAL_POINT_MAJOR if point_major else 0) | (_lib.EVAL_DENSE_BLOCKS if dense_blocks else 0)
         X = self.X
         c = self.cam.data_ptr()
         K24 = 24 * self.K
         check(self.lib.ba_eval_jtj(self.handle, X.data_ptr(), c, c + K24, c + 2 * K24, flags, *self._out_ptrs,
-                                   ptr(self.V), ptr(self.Xphi), ptr(self.B), ptr(self.bphi), ptr(self.hphi),
-                                   self.stream))
+                                   ptr(self.V), ptr(self.B), ptr(self.bphi), ptr(self.hphi), self.stream))
         self._table_cam = self.cam
         if self.distributed:
             self._sum_over_ranks(self.red)

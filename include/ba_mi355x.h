@@ -48,7 +48,8 @@ enum ba_eval_flags {
                                   ba_camera_step); skip rebuilding it */
     BA_EVAL_POST = 2048,    /* also post E_sum to the handle's host mailbox (see ba_wait_energy) */
     BA_EVAL_POINT_MAJOR = 4096, /* use the point-major tile kernel instead of the camera-run one */
-    BA_EVAL_DEFER_FINALIZE = 8192 /* leave E_sum and the camera-side gradient to ba_camera_step_finalize */
+    BA_EVAL_DEFER_FINALIZE = 8192, /* leave E_sum and the camera-side gradient to ba_camera_step_finalize */
+    BA_EVAL_DENSE_BLOCKS = 16384 /* ba_eval_jtj: use the dense block layout (if the scene has one) instead of camera runs */
 };
 
 const char *ba_last_error(void);
@@ -167,13 +168,16 @@ int ba_points_step(int64_t N, const double *X_in, double *X_out, const double *g
  * Gauss-Newton / Levenberg-Marquardt on the same energy.  All quantities un-normalised (J^T J, J^T r).
  * ba_eval_jtj: the fused pass of ba_eval plus the blocks of J^T J:
  *   V[N][6]    upper triangle (xx,xy,xz,yy,yz,zz) of sum J_X^T J_X per point
- *   Xphi[N][3] point x phi_x column,  B[K][21] upper triangle (row-major) of the 6x6 block over
- *   (C, Theta) per camera,  bphi[K][6] camera x phi_x column,  hphi[1].
+ *   B[K][21]   upper triangle (row-major) of the 6x6 block over (C, Theta) per camera,
+ *   bphi[K][6] camera x phi_x column,  hphi[1].
+ *   The cross blocks (point x camera, point x phi_x) are not stored: ba_schur_build and
+ *   ba_backsubstitute form them from the observations.
  * ba_schur_dim: n = 6K+1 unknowns of the reduced camera system, ld = n rounded up to 64.
  * ba_schur_build: S (ld x ld, row-major, lower triangle valid) and rhs (ld) of
  *   (D' - Y^T V'^-1 Y) d = -g_cam + Y^T V'^-1 g_X, primes = diagonal scaled by (1 + lambda);
  *   unknown order: camera j at 6j..6j+5 (C then Theta), phi_x at 6K.  Uses the camera table left by
- *   the last ba_eval_jtj.  with_camera_blocks = 0 leaves out D', -g_cam and the identity padding
+ *   the last ba_eval_jtj.  Also WRITES Xphi[N][3], the point x phi_x column of J^T J, for
+ *   ba_backsubstitute.  with_camera_blocks = 0 leaves out D', -g_cam and the identity padding
  *   and gives only this shard's sum over its points: with several GPUs one rank passes 1, the
  *   others 0, and S, rhs are summed over the ranks (B, bphi, hphi, g_cam already being the
  *   cross-GPU sums).
@@ -183,9 +187,9 @@ int ba_points_step(int64_t N, const double *X_in, double *X_out, const double *g
  *   receives d reordered to [dC (3K) | dTheta (3K) | dphi]. */
 int ba_eval_jtj(ba_problem *p, const double *X, const double *C, const double *Theta, const double *phi,
                 int flags, double *E_sum, double *gX, double *gC, double *gTheta, double *gphi,
-                double *V, double *Xphi, double *B, double *bphi, double *hphi, void *stream);
+                double *V, double *B, double *bphi, double *hphi, void *stream);
 int ba_schur_dim(int64_t K, int64_t *n, int64_t *ld);
-int ba_schur_build(ba_problem *p, const double *X, double lambda, const double *V, const double *Xphi,
+int ba_schur_build(ba_problem *p, const double *X, double lambda, const double *V, double *Xphi,
                    const double *gX, const double *B, const double *bphi, const double *hphi,
                    const double *gC, const double *gTheta, const double *gphi, int with_camera_blocks,
                    double *S, double *rhs, void *stream);

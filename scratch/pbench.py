@@ -7,7 +7,7 @@ sc = ba.scenes.orbit_scene(N=1_000_000, K=2000, track_len=10, seed=0)
 N, K = sc['N_local'], sc['K']
 nv = sc['i'].size
 algo_g = 24 * nv + 48 * N + 96 * K
-algo_j = 24 * nv + 24 * N + 24 * N + 48 * N + 24 * N + 96 * K + 216 * K
+algo_j = 24 * nv + 24 * N + 24 * N + 48 * N + 96 * K + 216 * K
 what = sys.argv[1] if len(sys.argv) > 1 else 'gfj'
 sh = ba.engine.Shard(sc['i'], sc['j'], sc['uv'], N, K, sc['W'], sc['H'], 'cuda:0')
 sh.set_params(sc['X_0'], sc['C_0'], sc['Theta_0'], sc['phi_x_0'])
@@ -21,10 +21,11 @@ if 'g' in what:
     torch.cuda.synchronize()
     report('gradient pass (stand-alone)', sh.eval_kernel_ms()[3:], algo_g, f'E={sh.energy():.12f} gC={float(sh.gC.abs().sum()):.12e} gX={float(sh.gX.abs().sum()):.12e}')
 if 'j' in what:
-    for _ in range(13):
-        sh.eval_jtj(timed=True)
-    torch.cuda.synchronize()
-    report('J^T J pass', sh.eval_kernel_ms()[3:], algo_j, f'E={sh.energy():.12f} B={float(sh.B.sum()):.12e} V={float(sh.V.sum()):.12e} Xphi={float(sh.Xphi.sum()):.12e}')
+    for tag, kw in (('J^T J pass (dense blocks)', dict(dense_blocks=True)), ('J^T J pass (camera runs)', {})):
+        for _ in range(13):
+            sh.eval_jtj(timed=True, **kw)
+        torch.cuda.synchronize()
+        report(tag, sh.eval_kernel_ms()[3:], algo_j, f'E={sh.energy():.12f} B={float(sh.B.sum()):.12e} V={float(sh.V.sum()):.12e}')
 if 'f' in what:
     fit = ba.SceneFit(sh, lr=1e-3, max_iters=200, patience=1000, print_step=10 ** 9, printer=lambda *a: None)
     fit.timed_every = 2

@@ -14,27 +14,39 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 
-def _scene(ba, N=300, K=80, seed=4, tile_obs=None):
+def _scene(ba, N=300, K=80, seed=4, tile_obs=None, env=None):
     import os
     sc = ba.scenes.orbit_scene(N=N, K=K, track_len=8, seed=seed)
     assert sc['i'].size > 4 * N
+    env = dict(env or {})
     if tile_obs:
-        os.environ['BA_TILE_OBS'] = str(tile_obs)
+        env['BA_TILE_OBS'] = str(tile_obs)
+    os.environ.update(env)
     try:
         sh = ba.engine.Shard(sc['i'], sc['j'], sc['uv'], sc['N_local'], K, sc['W'], sc['H'], DEV)
     finally:
-        os.environ.pop('BA_TILE_OBS', None)
+        for k in env:
+            os.environ.pop(k, None)
     sh.set_params(sc['X_0'], sc['C_0'], sc['Theta_0'], sc['phi_x_0'])
     r, J = orc.dense_jacobian(sc['X_0'], sc['C_0'], sc['Theta_0'], sc['phi_x_0'], sc['W'], sc['H'], sc['i'],
                               sc['j'], sc['uv'])
     return sc, sh, r, J
 
 
-@pytest.mark.parametrize('point_major', [False, True], ids=['camera-runs', 'point-major-tiles'])
-def test_jtj_blocks_match_dense_normal_equations(ba, point_major):
-    sc, sh, r, J = _scene(ba)
+# every layout of the J^T J pass; the dense block layout is forced (BA_BLOCK_MIN_FILL=0) because the
+# small test scenes fill their blocks poorly, once per record format and once with several tiles and
+# camera batches per tile
+@pytest.mark.parametrize('layout,env,tile_obs', [
+    ('blocks', {'BA_BLOCK_MIN_FILL': '0'}, None),
+    ('blocks', {'BA_BLOCK_MIN_FILL': '0', 'BA_RECORDS': 'f64'}, None),
+    ('blocks', {'BA_BLOCK_MIN_FILL': '0'}, 256),
+    ('runs', {}, None),
+    ('point-major', {}, None),
+], ids=['dense-blocks', 'dense-blocks-f64-records', 'dense-blocks-small-tiles', 'camera-runs', 'point-major-tiles'])
+def test_jtj_blocks_match_dense_normal_equations(ba, layout, env, tile_obs):
+    sc, sh, r, J = _scene(ba, env=env, tile_obs=tile_obs)
     N, K = sc['N_local'], sc['K']
-    sh.eval_jtj(point_major=point_major)
+    sh.eval_jtj(point_major=layout == 'point-major', dense_blocks=layout == 'blocks')
     H, g = J.T @ J, J.T @ r
     back = lambda t: sh.points_to_caller(t).cpu().numpy()
     assert abs(float(sh.E_sum.item()) - r @ r) / (r @ r) < 1e-12
@@ -46,6 +58,8 @@ def test_jtj_blocks_match_dense_normal_equations(ba, point_major):
     iu = np.triu_indices(3)
     V_ref = np.array([H[3 * i:3 * i + 3, 3 * i:3 * i + 3][iu] for i in range(N)])
     assert rel_err(V, V_ref) < 1e-10
+    # the point x phi column is formed by the Schur build (the pass does not store cross blocks)
+    sh.lm_step(1e-3)
     assert rel_err(back(sh.Xphi), H[:3 * N, -1].reshape(N, 3)) < 1e-10
     iu6 = np.triu_indices(6)
     B_ref = np.zeros((K, 21))
