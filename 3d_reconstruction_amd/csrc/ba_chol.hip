@@ -2,13 +2,19 @@
 // is first-order only, p2w:336-362).
 //
 // Storage: lower triangle, row-major, leading dimension ld (a multiple of 64); rows/columns past n
-// are the identity.  Two-level right-looking factorisation:
+// are the identity.  Three-level right-looking factorisation:
 //   panel  (256 columns): per 64-column block  potrf64 -> trsm -> update of the panel's remaining
-//          columns.  O(n 256^2) flops per panel, latency-bound, small next to
-//   trailing update: C -= P P^T with the whole 256-wide panel P as the inner dimension, 128 x 128
-//          tiles, operands staged through LDS in 32-column chunks, on v_mfma_f64_16x16x4_f64.
-//          With an inner dimension of 256 a tile does 32 flop per byte of C it moves (a 64-wide
-//          panel: 8 flop/B, bound by that traffic), so this kernel is bound by the matrix cores.
+//          columns (v_mfma_f64_16x16x4_f64, operands from global memory).  O(n 256^2) flops per
+//          panel, latency-bound, small next to the updates below.
+//   outer panel (1024 columns = 4 panels): after each panel only the remaining columns of the outer
+//          panel are updated with it; everything behind the outer panel is updated once, with all
+//          1024 columns as the inner dimension.  What this buys is traffic: an update reads and
+//          writes every entry of C it touches once, i.e. 16 bytes per 2 x (inner dimension) flops;
+//          with 256 columns that is 1 byte per 32 flop, 1.9 TB/s at the rate the matrix cores reach
+//          and not overlapped with them (measured: the read-modify-write of C took a quarter of
+//          the kernel's time), with 1024 columns a quarter of that.
+//   update kernel: C -= P P^T on 128 x 128 tiles, operands staged through LDS in 16-column chunks,
+//          on v_mfma_f64_4x4x4_4b_f64.
 // The inverse of every diagonal block is kept (trsm is a product with it, and so are the two
 // triangular solves of the right-hand side).
 //
@@ -16,14 +22,17 @@
 // it holds D[(l >> 4) + 4 r][l & 15] in register r = 0..3.
 #include "ba_common.h"
 
+#include <stdlib.h>
 #include <string>
 
 namespace ba {
 
 constexpr int NB = 64;    // block of the panel factorisation
-constexpr int PB = 256;   // panel width = inner dimension of the trailing update
+constexpr int PB = 256;   // panel width
+constexpr int OB = 1024;  // outer panel = inner dimension of the update of everything behind it
 constexpr int TS = 128;   // tile of the trailing update
-constexpr int KC = 32;    // columns of the panel staged in LDS at a time
+constexpr int KC = 16;    // columns of the panel staged in LDS at a time
+constexpr int LDT = TS + 4;    // row pitch of the staged (column-major) panel chunks in LDS
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 static int cdiv_c(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
@@ -189,98 +198,145 @@ __global__ void __launch_bounds__(256) k_syrk_panel(double *__restrict__ A, int6
             }
 }
 
-// Trailing update behind a panel: C[i0:+128, j0:+128] -= P_i P_j^T with P = A[:, k0 : k0 + kw], for the
-// lower triangle of 128-tiles of the trailing matrix that starts at row / column c0.  Four waves
-// in a 2 x 2 arrangement of 64 x 64 sub-tiles; the panel rows of both operands pass through LDS in
-// chunks of KC columns (global loads of the next chunk are in flight while the matrix cores work
-// on the current one).
-__global__ void __launch_bounds__(256) k_syrk_trailing(double *__restrict__ A, int64_t ld, int64_t k0, int kw, int64_t c0) {
+// Update behind a panel: C[i0:+128, j0:+128] -= P_i P_j^T with P = A[:, k0 : k0 + kw], for the 128-tiles of
+// the region that starts at row / column c0 and is nct tile columns wide (lower triangle of its first
+// nct tile rows, whole rows below).  Four waves in a 2 x 2 arrangement of 64 x 64 sub-tiles.
+//
+// Matrix-core instruction: v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 products per
+// instruction), measured at 70 TFLOP/s on MI355X against 36 TFLOP/s for v_mfma_f64_16x16x4_f64.
+// Lane layout (found by probing the instruction): block b = (lane >> 2) & 3; lane supplies
+// A_b[lane & 3][lane >> 4] and B_b[lane >> 4][lane & 3] and holds D_b[lane >> 4][lane & 3].
+// A wave's 64 x 64 sub-tile is 16 x 16 blocks of 4 x 4.  Per 4 columns of the panel it reads 16
+// A registers (register I: rows 4 I + (lane & 3) of the row operand, the same for every b) and 4
+// B registers (register c: rows 16 c + (lane & 15) of the column operand, i.e. the four block
+// columns 4 c + b), and issues 64 instructions, instruction (I, c) updating the blocks (I, 4 c + b),
+// b = 0..3; its 64 results are 4 rows of 16 consecutive columns of C (128-byte segments).
+//
+// The panel rows of both operands pass through LDS in chunks of KC columns, stored column-major
+// ([column][row], row pitch 132 = 4 mod 32 doubles: the 16 addresses of an A register read fall on 16
+// different bank pairs, and the transposing stores of the loader - 8 columns x 8 rows per wave
+// instruction - on 32 bank pairs twice); global loads of the next chunk are in flight while the
+// matrix cores work on the current one.  Loads are whole 128-byte rows per 8 lanes: a mapping with one
+// row per lane makes every load instruction touch 64 cache lines and leaves the kernel bound by the
+// address pipeline of the vector memory unit.
+__global__ void __launch_bounds__(256, 2) k_syrk_trailing(double *__restrict__ A, int64_t ld, int64_t k0, int kw, int64_t c0,
+                                                          int64_t nct) {
     extern __shared__ double smem[];
-    double(*As)[KC + 1] = (double(*)[KC + 1])smem;
-    double(*Bs)[KC + 1] = (double(*)[KC + 1])(smem + TS * (KC + 1));
-    // tile index -> (bi, bj), bj <= bi
-    const int64_t t = blockIdx.x;
-    int64_t bi = (int64_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-    while (bi * (bi + 1) / 2 > t) --bi;
-    while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
-    const int64_t bj = t - bi * (bi + 1) / 2;
+    double(*As)[LDT] = (double(*)[LDT])smem;
+    double(*Bs)[LDT] = (double(*)[LDT])(smem + KC * LDT);
+    // tile index -> (bi, bj), bj <= bi and bj < nct: the lower triangle of the first nct tile columns, then the rows
+    // below it, nct tiles each.  (Grouping the tiles of an 8 x 8 super-tile on one XCD, to share panel rows through
+    // its L2, was measured: no gain - the panel is served from the infinity cache either way.)
+    const int64_t t = blockIdx.x, tri = nct * (nct + 1) / 2;
+    int64_t bi, bj;
+    if (t < tri) {
+        bi = (int64_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while (bi * (bi + 1) / 2 > t) --bi;
+        while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+        bj = t - bi * (bi + 1) / 2;
+    } else {
+        bi = nct + (t - tri) / nct;
+        bj = (t - tri) % nct;
+    }
     const int64_t i0 = c0 + TS * bi, j0 = c0 + TS * bj;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
-    const int r16 = lane & 15, k4 = lane >> 4;
+    const int r16 = lane & 15, k4 = lane >> 4, j4 = lane & 3;
     const bool active = !(bi == bj && wc > wr);     // the sub-tile above the diagonal is never used
 
-    // loader mapping: thread -> row (tid / 4) + 64 h, 8 consecutive columns (tid % 4) * 8
-    const int lrow = tid >> 2, lcol = (tid & 3) * 8;
-    const double *srcA[2], *srcB[2];
+    // loader mapping: 8 consecutive lanes read the 128 bytes (KC columns) of one row, a wave 8 whole rows per
+    // instruction; thread -> columns 2 (tid % 8), +1 of rows tid / 8 + 32 q, q = 0..3, of both operands
+    const int lcol = 2 * (tid & 7), lrow = tid >> 3;
+    const double2 *srcA[4], *srcB[4];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        int64_t ra = i0 + lrow + 64 * h, rb = j0 + lrow + 64 * h;
+    for (int q = 0; q < 4; ++q) {
+        int64_t ra = i0 + lrow + 32 * q, rb = j0 + lrow + 32 * q;
         if (ra >= ld) ra = ld - 1;   // rows past the matrix: a valid address, results never stored
         if (rb >= ld) rb = ld - 1;
-        srcA[h] = A + ra * ld + k0 + lcol;
-        srcB[h] = A + rb * ld + k0 + lcol;
+        srcA[q] = (const double2 *)(A + ra * ld + k0 + lcol);
+        srcB[q] = (const double2 *)(A + rb * ld + k0 + lcol);
     }
-    double2 pa[2][4], pb[2][4];
+    double2 pa[4], pb[4];
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int q = 0; q < 4; ++q) {
+        pa[q] = srcA[q][0];
+        pb[q] = srcB[q][0];
+    }
+    double acc[16][4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            pa[h][q] = ((const double2 *)srcA[h])[q];
-            pb[h][q] = ((const double2 *)srcB[h])[q];
-        }
-    v4f64 acc[4][4];
-    zero_acc(acc);
+    for (int I = 0; I < 16; ++I)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[I][c] = 0.0;
     for (int kc = 0; kc < kw; kc += KC) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                As[lrow + 64 * h][lcol + 2 * q] = pa[h][q].x;
-                As[lrow + 64 * h][lcol + 2 * q + 1] = pa[h][q].y;
-                Bs[lrow + 64 * h][lcol + 2 * q] = pb[h][q].x;
-                Bs[lrow + 64 * h][lcol + 2 * q + 1] = pb[h][q].y;
-            }
+        for (int q = 0; q < 4; ++q) {
+            As[lcol][lrow + 32 * q] = pa[q].x;
+            As[lcol + 1][lrow + 32 * q] = pa[q].y;
+            Bs[lcol][lrow + 32 * q] = pb[q].x;
+            Bs[lcol + 1][lrow + 32 * q] = pb[q].y;
+        }
         __syncthreads();
         if (kc + KC < kw) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    pa[h][q] = ((const double2 *)(srcA[h] + kc + KC))[q];
-                    pb[h][q] = ((const double2 *)(srcB[h] + kc + KC))[q];
-                }
+            for (int q = 0; q < 4; ++q) {
+                pa[q] = srcA[q][(kc + KC) / 2];
+                pb[q] = srcB[q][(kc + KC) / 2];
+            }
         }
         if (active) {
+            // Software pipeline over the KC / 4 slabs of the chunk: the fragments of slab s + 1 are read from LDS
+            // while the matrix cores work on slab s, in two halves so that no extra A registers are needed (the
+            // A registers of block rows 0..7 are refilled during the instructions of block rows 8..15 and
+            // vice versa); only the first slab of a chunk waits for its reads.
+            double af[16], bf[2][4];
+            auto load_b = [&](int kk, int buf) {
 #pragma unroll
-            for (int kk = 0; kk < KC; kk += 4) {
-                double af[4], bf[4];
+                for (int c = 0; c < 4; ++c) bf[buf][c] = Bs[kk + k4][64 * wc + 16 * c + r16];
+            };
+            auto load_a = [&](int kk, int half) {
 #pragma unroll
-                for (int m = 0; m < 4; ++m) af[m] = As[64 * wr + 16 * m + r16][kk + k4];
+                for (int I = 8 * half; I < 8 * half + 8; ++I) af[I] = As[kk + k4][64 * wr + 4 * I + j4];
+            };
+            auto mma = [&](int half, int buf) {
 #pragma unroll
-                for (int n = 0; n < 4; ++n) bf[n] = Bs[64 * wc + 16 * n + r16][kk + k4];
+                for (int I = 8 * half; I < 8 * half + 8; ++I)
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
+                    for (int c = 0; c < 4; ++c)
+                        acc[I][c] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[I], bf[buf][c], acc[I][c], 0, 0, 0);
+            };
+            load_b(0, 0);
+            load_a(0, 0);
+            load_a(0, 1);
 #pragma unroll
-                    for (int n = 0; n < 4; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[m], bf[n], acc[m][n], 0, 0, 0);
+            for (int sl = 0; sl < KC / 4; ++sl) {
+                const int buf = sl & 1;
+                const bool more = sl + 1 < KC / 4;
+                __builtin_amdgcn_sched_barrier(0);
+                mma(0, buf);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) {
+                    load_b(4 * sl + 4, buf ^ 1);
+                    load_a(4 * sl + 4, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mma(1, buf);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) load_a(4 * sl + 4, 1);
             }
         }
         __syncthreads();
     }
     if (!active) return;
-    const int col = lane & 15, rq = lane >> 4;
+    // block (I, 4 c + b), b = (lane >> 2) & 3, entry [lane >> 4][lane & 3]: row 4 I + (lane >> 4), column 16 c + (lane & 15)
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int I = 0; I < 16; ++I) {
+        const int64_t row = i0 + 64 * wr + 4 * I + k4;
+        if (row >= ld) continue;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int64_t row = i0 + 64 * wr + 16 * m + rq + 4 * r;
-            if (row >= ld) continue;
-#pragma unroll
-            for (int nn = 0; nn < 4; ++nn) {
-                const int64_t cc = j0 + 64 * wc + 16 * nn + col;
-                if (cc < ld) A[row * ld + cc] -= acc[m][nn][r];
-            }
+        for (int c = 0; c < 4; ++c) {
+            const int64_t cc = j0 + 64 * wc + 16 * c + r16;
+            if (cc < ld) A[row * ld + cc] -= acc[I][c];
         }
+    }
 }
 
 // One block step of a triangular solve with the stored inverses of the diagonal blocks.
@@ -351,34 +407,45 @@ int ba_cholesky_solve(int64_t n, int64_t ld, double *S, double *rhs, int *h_info
     hipError_t e = hipMalloc(&tmp, sizeof(double) * ld);
     if (e == hipSuccess) e = hipMalloc(&info, sizeof(int));
     if (e == hipSuccess) e = hipMemsetAsync(info, 0, sizeof(int), st);
-    const size_t lds_trailing = sizeof(double) * 2 * TS * (KC + 1);
+    const size_t lds_trailing = sizeof(double) * 2 * KC * LDT;
     if (e == hipSuccess && lds_trailing > 64 * 1024)
         e = hipFuncSetAttribute((const void *)k_syrk_trailing, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_trailing);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void *)k_potrf64, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(sizeof(double) * POTRF_LDS_DOUBLES));
     if (e == hipSuccess) {
-        for (int64_t p0 = 0; p0 < ld; p0 += PB) {
-            const int64_t pw = (ld - p0 < PB) ? ld - p0 : PB;
-            for (int64_t k0 = p0; k0 < p0 + pw; k0 += NB) {
-                double *Li = Linv + (k0 / NB) * NB * NB;
-                hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(256), sizeof(double) * POTRF_LDS_DOUBLES, st, S, ld, k0, Li, info);
-                const int64_t rows_behind = (ld - k0 - NB) / NB;
-                if (rows_behind > 0) {
-                    hipLaunchKernelGGL(k_trsm, dim3((int)rows_behind), dim3(64), 0, st, S, ld, k0, Li);
-                    const int col_blocks = (int)((p0 + pw - k0 - NB) / NB);
-                    if (col_blocks > 0) {
-                        const int64_t tiles = rows_behind * col_blocks;
-                        hipLaunchKernelGGL(k_syrk_panel, dim3(cdiv_c(tiles, 4)), dim3(256), 0, st, S, ld, k0, col_blocks, tiles);
+        // tiles of the region C[c0.., c0 .. c_end): lower triangle of the first tile columns, whole rows below
+        auto trailing = [&](int64_t k_first, int64_t kw, int64_t c0, int64_t c_end) {
+            if (c0 >= ld || c_end <= c0) return;
+            const int64_t nt = cdiv_c(ld - c0, TS);
+            int64_t nct = cdiv_c(c_end - c0, TS);
+            if (nct > nt) nct = nt;
+            const int64_t tiles = nct * (nct + 1) / 2 + (nt - nct) * nct;
+            hipLaunchKernelGGL(k_syrk_trailing, dim3((unsigned)tiles), dim3(256), lds_trailing, st, S, ld, k_first, (int)kw, c0,
+                               nct);
+        };
+        for (int64_t o0 = 0; o0 < ld; o0 += OB) {
+            const int64_t o_end = (ld - o0 < OB) ? ld : o0 + OB;
+            for (int64_t p0 = o0; p0 < o_end; p0 += PB) {
+                const int64_t pw = (o_end - p0 < PB) ? o_end - p0 : PB;
+                for (int64_t k0 = p0; k0 < p0 + pw; k0 += NB) {
+                    double *Li = Linv + (k0 / NB) * NB * NB;
+                    hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(256), sizeof(double) * POTRF_LDS_DOUBLES, st, S, ld, k0, Li, info);
+                    const int64_t rows_behind = (ld - k0 - NB) / NB;
+                    if (rows_behind > 0) {
+                        hipLaunchKernelGGL(k_trsm, dim3((int)rows_behind), dim3(64), 0, st, S, ld, k0, Li);
+                        const int col_blocks = (int)((p0 + pw - k0 - NB) / NB);
+                        if (col_blocks > 0) {
+                            const int64_t tiles = rows_behind * col_blocks;
+                            hipLaunchKernelGGL(k_syrk_panel, dim3(cdiv_c(tiles, 4)), dim3(256), 0, st, S, ld, k0, col_blocks, tiles);
+                        }
                     }
                 }
+                // inside the outer panel: only its remaining columns see this 256-wide panel now
+                trailing(p0, pw, p0 + pw, o_end);
             }
-            const int64_t c0 = p0 + pw;
-            if (c0 < ld) {
-                const int64_t nt = cdiv_c(ld - c0, TS);
-                hipLaunchKernelGGL(k_syrk_trailing, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), lds_trailing, st, S, ld,
-                                   p0, (int)pw, c0);
-            }
+            // behind the outer panel: one update with all its columns as the inner dimension
+            trailing(o0, o_end - o0, o_end, ld);
         }
         // L y = b, then L^T x = y; the result of every block step lands in tmp
         for (int64_t k = 0; k < nb; ++k)

@@ -14,6 +14,16 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// 1 / x without the range scaling and fix-up of the IEEE division sequence (x is a depth along the
+// optical axis: far from the ends of the exponent range): hardware estimate and two Newton steps,
+// relative error of a few 1e-16
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
 // value of the lane N positions lower in the same 16-lane row (0.0 / 0 where there is none)
 template <int N>
 __device__ __forceinline__ int row_shr(int v) {

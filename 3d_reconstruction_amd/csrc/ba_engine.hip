@@ -760,7 +760,7 @@ struct GradOp {
         const double q0 = R00 * d0 + R10 * d1 + R20 * d2;
         const double q1 = R01 * d0 + R11 * d1 + R21 * d2;
         const double q2 = R02 * d0 + R12 * d1 + R22 * d2;
-        const double inv = 1.0 / q2;
+        const double inv = fast_rcp(q2);
         const double m0 = q0 * inv, m1 = q1 * inv;
         const double r0 = valid ? f * m0 + pcx - uv.x : 0.0;
         const double r1 = valid ? f * m1 + pcy - uv.y : 0.0;

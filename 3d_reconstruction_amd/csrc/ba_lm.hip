@@ -51,16 +51,6 @@ struct ObsJac {
     double G0[6], G1[6];    // rows of the camera-frame camera Jacobian
 };
 
-// 1 / x without the range scaling and fix-up of the IEEE division sequence (x is a depth along the
-// optical axis: far from the ends of the exponent range): hardware estimate and two Newton steps,
-// relative error of a few 1e-16
-__device__ __forceinline__ double fast_rcp(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    r = fma(fma(-x, r, 1.0), r, r);
-    r = fma(fma(-x, r, 1.0), r, r);
-    return r;
-}
-
 // valid = false (a zero-weight record, any point / camera pair): every Jacobian entry and m come out
 // as zero (they carry the factor 1 / q2, which is replaced by 0)
 __device__ __forceinline__ ObsJac obs_jacobian(const double *x, const double2 *rw, double f, double pcx, double pcy,
