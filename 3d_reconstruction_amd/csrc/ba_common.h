@@ -90,8 +90,11 @@ struct ba_problem {
     int blk_waves = 0;                // waves per workgroup of the block pass
     // scratch owned by the handle (device)
     double *cam_table = nullptr;  // K x CAM_ROW
+    double *sum_block = nullptr;  // owned: [cam_sums | partials]
     double *cam_sums = nullptr;   // 6 x K camera-frame sums (SoA: component-major), zero between passes
-    double *partials = nullptr;   // grid*EVAL_WAVES x 2 per-wave partial sums
+    double *partials = nullptr;   // 2 per wave / tile, directly behind cam_sums
+    int64_t partials_cap = 0;     // partial-sum pairs this problem may write
+    int64_t ext_partials_cap = 0; // > 0: cam_sums / partials live in a caller's buffer (ba_set_sum_buffer) with this many pairs
     double *scalars = nullptr;    // SC_COUNT
     int *flag = nullptr;          // 4 ints: validation flags, tile maxima
     int *step_counter = nullptr;  // arrival counter of the multi-workgroup camera step (kept at 0)

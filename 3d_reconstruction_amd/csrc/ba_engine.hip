@@ -1557,8 +1557,10 @@ __global__ void __launch_bounds__(256) k_camera_step_mb(CameraStep a, CameraStep
 // separate k_finalize launch, and leaves the camera-frame sums at zero.
 // --------------------------------------------------------------------------------------------
 struct FinalizeArgs {
-    const double *partials = nullptr;   // 2 per tile
-    int n_partials = 0;
+    double *partials = nullptr;         // 2 per tile
+    int n_partials = 0;                 // entries to add up
+    int n_own = 0;                      // entries the pass of this GPU writes; the others (sums from other GPUs in a
+                                        // shared sum buffer) are cleared once they have been added
     double *cam_sums = nullptr;         // 6 x K
     double *g_out = nullptr;            // [gC (3K) | gTheta (3K) | gphi | E_sum]
     volatile double *mailbox = nullptr;
@@ -1601,6 +1603,7 @@ __global__ void __launch_bounds__(256) k_camera_step_quad(CameraStep a, CameraSt
             const double2 v = pp[t];
             e += v.x;
             ps += v.y;
+            if (t >= fz.n_own) ((double2 *)fz.partials)[t] = make_double2(0.0, 0.0);
         }
         e = wave_sum(e);
         ps = wave_sum(ps);
@@ -2223,8 +2226,7 @@ int ba_problem_destroy(ba_problem *p) {
     hipFree(p->buv);
     hipFree(p->blk_ptr);
     hipFree(p->cam_table);
-    hipFree(p->cam_sums);
-    hipFree(p->partials);
+    hipFree(p->sum_block);
     hipFree(p->scalars);
     hipFree(p->step_counter);
     hipFree(p->step_best);
@@ -2326,8 +2328,17 @@ int ba_problem_create(int64_t N, int64_t K, int64_t nV, const int32_t *i, const 
     if (int rc_tiles = build_tiles(p)) return fail(rc_tiles);
 
     BA_TRY(hipMalloc(&p->cam_table, sizeof(double) * K * CAM_ROW));
-    BA_TRY(hipMalloc(&p->cam_sums, sizeof(double) * K * 6));
-    BA_TRY(hipMemset(p->cam_sums, 0, sizeof(double) * K * 6));   // kept at zero between passes by k_finalize
+    {
+        // camera-frame sums (kept at zero between passes by the finalisation) and per-tile partial sums in one
+        // block, so that several GPUs can add both up with one collective
+        size_t n_part = (size_t)p->grid * EVAL_WAVES;
+        if ((size_t)p->n_tiles > n_part) n_part = p->n_tiles;
+        p->partials_cap = (int64_t)n_part;
+        BA_TRY(hipMalloc(&p->sum_block, sizeof(double) * (K * 6 + 2 * n_part)));
+        BA_TRY(hipMemset(p->sum_block, 0, sizeof(double) * (K * 6 + 2 * n_part)));
+        p->cam_sums = p->sum_block;
+        p->partials = p->sum_block + K * 6;
+    }
     {
         void *host = nullptr, *dev = nullptr;
         BA_TRY(hipHostMalloc(&host, 64, hipHostMallocMapped | hipHostMallocCoherent));
@@ -2335,11 +2346,6 @@ int ba_problem_create(int64_t N, int64_t K, int64_t nV, const int32_t *i, const 
         p->mailbox_host = (double *)host;
         BA_TRY(hipHostGetDevicePointer(&dev, host, 0));
         p->mailbox_dev = (double *)dev;
-    }
-    {
-        size_t n_part = (size_t)p->grid * EVAL_WAVES;
-        if ((size_t)p->n_tiles > n_part) n_part = p->n_tiles;
-        BA_TRY(hipMalloc(&p->partials, sizeof(double) * 2 * n_part));
     }
     BA_TRY(hipMalloc(&p->scalars, sizeof(double) * SC_COUNT));
     BA_TRY(hipMalloc(&p->step_counter, 16));
@@ -2689,7 +2695,8 @@ static int camera_step_impl(ba_problem *p, const double *cam_in, double *cam_out
         FinalizeArgs fz;
         if (finalize) {
             fz.partials = p->partials;
-            fz.n_partials = p->pending_partials;
+            fz.n_own = p->pending_partials;
+            fz.n_partials = p->ext_partials_cap > 0 ? (int)p->ext_partials_cap : p->pending_partials;
             fz.cam_sums = p->cam_sums;
             fz.g_out = g_out;
             if (post) {
@@ -2730,6 +2737,22 @@ int ba_camera_step_finalize(ba_problem *p, const double *cam_in, double *cam_out
                "ba_camera_step_finalize: no observation pass with BA_EVAL_DEFER_FINALIZE is waiting");
     return camera_step_impl(p, cam_in, cam_out, nullptr, g_out, 1, post, s_in, s_out, r_in, r_out, lo, hi, rule, lr,
                             gscale, bc1, bc2, 1, R_out, gauge_out, stream);
+}
+
+int ba_sum_buffer_size(ba_problem *p, int64_t *n_partials) {
+    BA_REQUIRE(p && n_partials, "ba_sum_buffer_size: null pointer");
+    *n_partials = p->partials_cap;
+    return BA_OK;
+}
+
+int ba_set_sum_buffer(ba_problem *p, double *buf, int64_t n_partials) {
+    BA_REQUIRE(p && buf, "ba_set_sum_buffer: null pointer");
+    BA_REQUIRE(n_partials >= p->partials_cap, "ba_set_sum_buffer: room for fewer partial sums than this problem writes");
+    BA_REQUIRE(p->pending_partials == 0, "ba_set_sum_buffer: an observation pass is waiting for its finalisation");
+    p->cam_sums = buf;
+    p->partials = buf + p->K * 6;
+    p->ext_partials_cap = n_partials;
+    return BA_OK;
 }
 
 int ba_fetch_double(const double *src, double *h_out, void *stream) {

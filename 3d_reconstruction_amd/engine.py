@@ -101,6 +101,10 @@ class Shard:
         self._stage_reduce = self.distributed and torch.distributed.get_backend(group) == 'gloo'
         self._out_ptrs = [t.data_ptr() for t in (self.E_sum, self.gX, self.gC, self.gTheta, self.gphi)]
         self._E_host = C.c_double(0.0)
+        # Several GPUs: the sums a deferred pass leaves for the camera step (camera-frame sums, per-tile partial
+        # sums) live in one tensor of this class, summed over the ranks with one collective.
+        # (created by the first deferred pass: a collective, every rank gets there in the same iteration)
+        self.raw = None
 
     @property
     def X(self):
@@ -128,6 +132,19 @@ class Shard:
     def can_fuse(self):
         """The observation pass can apply the point update itself (eval_update)."""
         return bool(self.lib.ba_can_fuse_update(self.handle))
+
+    def _shared_sum_buffer(self):
+        if self.raw is None:
+            cap = C.c_int64(0)
+            check(self.lib.ba_sum_buffer_size(self.handle, C.byref(cap)))
+            t = torch.tensor([float(cap.value)], dtype=F64)
+            if torch.distributed.get_backend(self.group) != 'gloo':
+                t = t.to(self.device)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=self.group)
+            cap = int(t.item())
+            self.raw = torch.zeros(6 * self.K + 2 * cap, dtype=F64, device=self.device)
+            check(self.lib.ba_set_sum_buffer(self.handle, self.raw.data_ptr(), cap))
+        return self.raw
 
     def all_ranks_agree(self, flag):
         """True if `flag` is true on every rank of the group."""
@@ -285,12 +302,14 @@ class Shard:
         ba_eval_update): leaves the camera-side gradient in `red`, posts the energy, and returns
         (X_new, mom_x_new) - new tensors holding the updated points BEFORE the gauge fix of this
         step; they become current through adopt(X_new, cam_new, gauge record of camera_update).
-        defer_finalize (single GPU, all camera parameters free): the energy and the camera-side
-        gradient are left to the camera_update(finalize=True) that must follow."""
-        assert not (defer_finalize and self.distributed)
+        defer_finalize (all camera parameters free): the energy and the camera-side gradient are left
+        to the camera_update(finalize=True) that must follow; with several GPUs the raw sums of the
+        pass are added up over the ranks in between (one collective)."""
         flags = (_lib.EVAL_GRAD_CAM if grad_cam else 0) | (_lib.EVAL_GRAD_PHI if grad_phi else 0) | \
                 (_lib.EVAL_TIMED if timed else 0) | (_lib.EVAL_REUSE_TABLE if self._table_cam is self.cam else 0) | \
                 (0 if self.distributed else _lib.EVAL_POST) | (_lib.EVAL_DEFER_FINALIZE if defer_finalize else 0)
+        if self.distributed and defer_finalize:
+            self._shared_sum_buffer()
         X_new = torch.empty_like(self._X_buf)
         if mom_x is not None:
             s_in, r_in = mom_x
@@ -306,7 +325,9 @@ class Shard:
                                       c + 2 * K24, flags, o[0], None, o[2], o[3], o[4], rule, float(lr),
                                       1.0 / self.nV, float(bc1), float(bc2), *mp, X_new.data_ptr(), self.stream))
         self._table_cam = self.cam
-        if self.distributed:
+        if self.distributed and defer_finalize:
+            self._sum_over_ranks(self.raw)
+        elif self.distributed:
             self._sum_over_ranks(self.red)
             check(self.lib.ba_post_energy(self.handle, o[0], self.stream))
         return X_new, mom_x

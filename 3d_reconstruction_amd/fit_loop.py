@@ -233,8 +233,9 @@ class SceneFit:
         rule = 2 if self.adam else 1
         timed = self.timed_every > 0 and self._passes % self.timed_every == 0
         self._passes += 1
-        # one GPU, gauge fix on: the camera step also finishes the pass (energy, camera-side gradient)
-        merge = self.gauge and not getattr(self.sh, 'distributed', False)
+        # gauge fix on: the camera step also finishes the pass (energy, camera-side gradient); with several
+        # GPUs the raw sums of the pass are added up over the ranks between the two launches
+        merge = self.gauge
         X, mom_x = self.sh.eval_update(rule, self.lr, bc1, bc2, self.mom_x, grad_cam=self.masks[1],
                                        grad_phi=merge or self.masks[2], timed=timed, defer_finalize=merge)
         self._grad_x_valid = False

@@ -160,6 +160,14 @@ int ba_camera_step_finalize(ba_problem *p, const double *cam_in, double *cam_out
                             const double *s_in, double *s_out, const double *r_in, double *r_out, int64_t lo,
                             int64_t hi, int rule, double lr, double gscale, double bc1, double bc2, double *R_out,
                             double *gauge_out, void *stream);
+
+/* Several GPUs, no counterpart in the reference (single process): the sums a pass with BA_EVAL_DEFER_FINALIZE
+ * leaves for ba_camera_step_finalize - camera-frame sums (6K doubles) followed by pairs of per-tile partial
+ * sums - can live in a caller's device buffer of 6K + 2 * n_partials doubles, zeroed once, so that ONE
+ * all-reduce of that buffer between the pass and ba_camera_step_finalize adds up the GPUs' shares
+ * (n_partials: the largest ba_sum_buffer_size over the GPUs).  The buffer stays the caller's. */
+int ba_sum_buffer_size(ba_problem *p, int64_t *n_partials);
+int ba_set_sum_buffer(ba_problem *p, double *buf, int64_t n_partials);
 int ba_points_step(int64_t N, const double *X_in, double *X_out, const double *gX, const double *s_in,
                    double *s_out, const double *r_in, double *r_out, int rule, double lr, double gscale,
                    double bc1, double bc2, const double *gauge, void *stream);

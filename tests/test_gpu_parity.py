@@ -353,9 +353,9 @@ def test_fused_update_equals_separate_steps(ba, golden):
 
 
 def test_multi_gpu_code_path_on_one_rank(ba, golden):
-    """The sequence a rank runs with several GPUs (pass, k_finalize, RCCL all-reduce of the camera
-    block, energy post, camera step) on a one-rank RCCL group: same energies as the one-GPU
-    sequence, where the camera step finishes the pass itself."""
+    """The sequence a rank runs with several GPUs (pass into the shared sum buffer, RCCL all-reduce
+    of it, camera step that finishes the pass) on a one-rank RCCL group: same energies as the
+    one-GPU sequence without the buffer and the collective."""
     import torch.distributed as dist
     g = golden('f6_medium.npz')
     N, K = int(g['N']), int(g['K'])
