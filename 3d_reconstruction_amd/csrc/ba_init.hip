@@ -1,0 +1,449 @@
+// Linear steps on either side of the bundle adjustment, on the visible pairs only:
+//   ba_triangulate  - every point from the cameras that see it      (get_X_from_C_Theta, p2w:1655-1721)
+//   ba_resect       - every camera from the points it sees (DLT)     (get_C_Theta_from_X, p2w:1724-1808)
+// Both stream the observation list once; the per-point 4x4 / per-camera 12x12 Gram matrices live
+// in registers / LDS, the small dense solves are done in place (3x3 inverse; cyclic Jacobi).
+//
+// Rank tests: the reference applies numpy.linalg.matrix_rank to the row matrices themselves
+// (tolerance: largest singular value x rows x eps).  Here only the Gram matrices exist, whose
+// eigenvalues (squared singular values) carry an absolute error of a few eps x the largest one,
+// so the test is  lambda_k > lambda_1 max((rows eps)^2, 1e-14)  (resection: eigenvalues from the
+// Jacobi iteration; triangulation: pivots of a Cholesky factorisation with diagonal pivoting, which
+// follow the eigenvalues within small factors):  the same verdict unless the k-th singular value
+// is below about 1e-7 of the largest, where the solution has no correct digit anyway.
+#include "ba_device.h"
+
+#include <math.h>
+
+namespace ba {
+
+constexpr double RANK_FLOOR = 1e-14;
+
+struct Intrinsics {
+    double f, px, py;      // K matrix (p2w:1684-1695)
+    double scale, sx, sy;  // pixel centre -> (centre - (sx, sy)) * scale  (p2w:1682, 1688)
+};
+
+static Intrinsics make_intrinsics(double phi_x, double W, double H, int normalize) {
+    Intrinsics k;
+    if (!normalize) {
+        k.f = W / 2.0 / tan(phi_x / 2.0);
+        k.px = W / 2.0;
+        k.py = H / 2.0;
+        k.scale = 1.0;
+        k.sx = k.sy = 0.0;
+    } else {
+        const double m = W > H ? W : H;
+        k.f = W / m / 2.0 / tan(phi_x / 2.0);
+        k.px = k.py = 0.0;
+        k.scale = 1.0 / m;
+        k.sx = 0.5 * W;
+        k.sy = 0.5 * H;
+    }
+    return k;
+}
+
+// P = K [R^T | -R^T C] per camera, 12 doubles row-major (p2w:1697-1700)
+__global__ void k_projection_matrices(int64_t K, const double *__restrict__ C, const double *__restrict__ Theta,
+                                      Intrinsics in, double *__restrict__ P) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= K) return;
+    double R[9], cz, sz;
+    rotation_yxz(Theta[3 * j], Theta[3 * j + 1], Theta[3 * j + 2], R, &cz, &sz);
+    const double c0 = C[3 * j], c1 = C[3 * j + 1], c2 = C[3 * j + 2];
+    double RT[3][4];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        RT[r][0] = R[r];          // row r of R^T = column r of R
+        RT[r][1] = R[3 + r];
+        RT[r][2] = R[6 + r];
+        RT[r][3] = -(R[r] * c0 + R[3 + r] * c1 + R[6 + r] * c2);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        P[12 * j + q] = in.f * RT[0][q] + in.px * RT[2][q];
+        P[12 * j + 4 + q] = in.f * RT[1][q] + in.py * RT[2][q];
+        P[12 * j + 8 + q] = RT[2][q];
+    }
+}
+
+// First three pivots of the Cholesky factorisation with diagonal pivoting of a symmetric positive
+// semi-definite 4 x 4 matrix (fully unrolled, no indexed registers).  The pivots follow the eigenvalues
+// within small factors, which is all the rank test needs: rank >= 3  <=>  d3 > threshold x d1.
+__device__ __forceinline__ void pivots_4x4(double (&A)[4][4], double &d1, double &d3) {
+    double piv[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int p = k;
+        double best = A[k][k];
+#pragma unroll
+        for (int q = k + 1; q < 4; ++q)
+            if (A[q][q] > best) {
+                best = A[q][q];
+                p = q;
+            }
+#pragma unroll
+        for (int q = k + 1; q < 4; ++q)
+            if (q == p) {      // symmetric swap of rows / columns k and q
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double t = A[k][r];
+                    A[k][r] = A[q][r];
+                    A[q][r] = t;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double t = A[r][k];
+                    A[r][k] = A[r][q];
+                    A[r][q] = t;
+                }
+            }
+        piv[k] = A[k][k];
+        const double inv = A[k][k] > 0.0 ? 1.0 / A[k][k] : 0.0;
+#pragma unroll
+        for (int r = k + 1; r < 4; ++r)
+#pragma unroll
+            for (int c = k + 1; c < 4; ++c) A[r][c] -= A[r][k] * A[c][k] * inv;
+    }
+    d1 = piv[0];
+    d3 = piv[2];
+}
+
+// One thread per point.  The observations of the workgroup's 256 consecutive points are one contiguous range
+// of the list: it is copied to LDS with coalesced loads first (a thread walking its own points' records in
+// global memory makes every load instruction touch 64 cache lines), as long as it fits TRI_STAGE records.
+constexpr int TRI_STAGE = 3072;
+__global__ void __launch_bounds__(256) k_triangulate(int64_t N, const int64_t *__restrict__ row_ptr,
+                                                     const int32_t *__restrict__ oj, const double2 *__restrict__ uv,
+                                                     const double *__restrict__ P, Intrinsics in, double rank_thr,
+                                                     double *__restrict__ X) {
+    __shared__ double2 s_uv[TRI_STAGE];
+    __shared__ int32_t s_j[TRI_STAGE];
+    const int64_t i_first = (int64_t)blockIdx.x * 256;
+    const int64_t i_last = i_first + 256 < N ? i_first + 256 : N;
+    const int64_t b0 = row_ptr[i_first], b1 = row_ptr[i_last];
+    const bool staged = b1 - b0 <= TRI_STAGE;
+    if (staged) {
+        for (int64_t e = b0 + threadIdx.x; e < b1; e += 256) {
+            s_uv[e - b0] = uv[e];
+            s_j[e - b0] = oj[e];
+        }
+    }
+    __syncthreads();
+    const int64_t i = i_first + threadIdx.x;
+    if (i >= N) return;
+    const double nan = __builtin_nan("");
+    const int64_t e0 = row_ptr[i], e1 = row_ptr[i + 1];
+    double x0 = nan, x1 = nan, x2 = nan;
+    if (e1 - e0 >= 2) {                                           // p2w:1671
+        double M[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};           // upper triangle of [A b]^T [A b], row-major
+        for (int64_t e = e0; e < e1; ++e) {
+            const double2 *Pv = (const double2 *)(P + 12 * (int64_t)(staged ? s_j[e - b0] : oj[e]));
+            double Pj[12];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const double2 t = Pv[q];
+                Pj[2 * q] = t.x;
+                Pj[2 * q + 1] = t.y;
+            }
+            const double2 c = staged ? s_uv[e - b0] : uv[e];
+            const double u = (c.x - in.sx) * in.scale, v = (c.y - in.sy) * in.scale;
+            double a[4], b[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                a[q] = u * Pj[8 + q] - Pj[q];                     // p2w:1703
+                b[q] = v * Pj[8 + q] - Pj[4 + q];                 // p2w:1704
+            }
+            int idx = 0;
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int q = p; q < 4; ++q) M[idx++] += a[p] * a[q] + b[p] * b[q];
+        }
+        double A[4][4];
+        {
+            int idx = 0;
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int q = p; q < 4; ++q) {
+                    A[p][q] = M[idx];
+                    A[q][p] = M[idx];
+                    ++idx;
+                }
+        }
+        double d1, d3;
+        pivots_4x4(A, d1, d3);
+        if (d3 > d1 * rank_thr && d1 > 0.0) {                     // rank >= 3, p2w:1707
+            // X = -(A3^T A3)^-1 A3^T b  (p2w:1716-1719): G = M[0,1,2; 4,5; 7], h = M[3], M[6], M[8]
+            const double g00 = M[0], g01 = M[1], g02 = M[2], g11 = M[4], g12 = M[5], g22 = M[7];
+            const double h0 = M[3], h1 = M[6], h2 = M[8];
+            const double c00 = g11 * g22 - g12 * g12, c01 = g02 * g12 - g01 * g22, c02 = g01 * g12 - g02 * g11;
+            const double det = g00 * c00 + g01 * c01 + g02 * c02;
+            const double c11 = g00 * g22 - g02 * g02, c12 = g01 * g02 - g00 * g12, c22 = g00 * g11 - g01 * g01;
+            const double id = 1.0 / det;
+            x0 = -(c00 * h0 + c01 * h1 + c02 * h2) * id;
+            x1 = -(c01 * h0 + c11 * h1 + c12 * h2) * id;
+            x2 = -(c02 * h0 + c12 * h1 + c22 * h2) * id;
+        }
+    }
+    X[3 * i] = x0;
+    X[3 * i + 1] = x1;
+    X[3 * i + 2] = x2;
+}
+
+// ---------------------------------------------------------------------------------------------
+// resection: one wave per camera
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void inv3(const double (&m)[3][3], double (&o)[3][3]) {
+    const double c00 = m[1][1] * m[2][2] - m[1][2] * m[2][1], c01 = m[1][2] * m[2][0] - m[1][0] * m[2][2],
+                 c02 = m[1][0] * m[2][1] - m[1][1] * m[2][0];
+    const double id = 1.0 / (m[0][0] * c00 + m[0][1] * c01 + m[0][2] * c02);
+    o[0][0] = c00 * id;
+    o[1][0] = c01 * id;
+    o[2][0] = c02 * id;
+    o[0][1] = (m[0][2] * m[2][1] - m[0][1] * m[2][2]) * id;
+    o[1][1] = (m[0][0] * m[2][2] - m[0][2] * m[2][0]) * id;
+    o[2][1] = (m[0][1] * m[2][0] - m[0][0] * m[2][1]) * id;
+    o[0][2] = (m[0][1] * m[1][2] - m[0][2] * m[1][1]) * id;
+    o[1][2] = (m[0][2] * m[1][0] - m[0][0] * m[1][2]) * id;
+    o[2][2] = (m[0][0] * m[1][1] - m[0][1] * m[1][0]) * id;
+}
+
+struct ResectArgs {
+    int64_t K;
+    const int64_t *col_ptr;   // K + 1: observation range of every camera in the camera-sorted list
+    const int32_t *oi;        // point of every observation, camera-sorted
+    const double2 *uv;        // pixel centre, camera-sorted
+    const double *X;          // N x 3
+    Intrinsics in;
+    double rank_thr;
+    int min_points;
+    double *C, *Theta;        // K x 3 each
+};
+
+__global__ void __launch_bounds__(64) k_resect(ResectArgs a) {
+    __shared__ double G[12][13];   // Gram matrix A^T A, overwritten by the Jacobi iteration
+    __shared__ double V[12][13];   // accumulated rotations: eigenvectors in the columns
+    __shared__ double cs[2];
+    const int64_t j = blockIdx.x;
+    const int lane = threadIdx.x;
+    const double nan = __builtin_nan("");
+    const int64_t e0 = a.col_ptr[j], e1 = a.col_ptr[j + 1];
+    if (e1 - e0 < a.min_points) {                                  // p2w:1739
+        if (lane < 3) {
+            a.C[3 * j + lane] = nan;
+            a.Theta[3 * j + lane] = nan;
+        }
+        return;
+    }
+    // A^T A = [[S, 0, -Su], [0, S, -Sv], [-Su, -Sv, Sw]] with S = sum Xh Xh^T, Su = sum u Xh Xh^T, Sv = sum v Xh Xh^T,
+    // Sw = sum (u^2 + v^2) Xh Xh^T over the camera's observations (rows p2w:1767-1770); 4 x 10 sums per lane
+    double acc[4][10];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int k = 0; k < 10; ++k) acc[b][k] = 0.0;
+    for (int64_t e = e0 + lane; e < e1; e += 64) {
+        const int64_t i = a.oi[e];
+        const double xh[4] = {a.X[3 * i], a.X[3 * i + 1], a.X[3 * i + 2], 1.0};
+        if (xh[0] != xh[0] || xh[1] != xh[1] || xh[2] != xh[2]) continue;      // rows with NaN are zeroed (p2w:1771-1772)
+        const double2 c = a.uv[e];
+        const double u = (c.x - a.in.sx) * a.in.scale, v = (c.y - a.in.sy) * a.in.scale;
+        const double w = u * u + v * v;
+        int idx = 0;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int q = p; q < 4; ++q) {
+                const double s = xh[p] * xh[q];
+                acc[0][idx] += s;
+                acc[1][idx] += u * s;
+                acc[2][idx] += v * s;
+                acc[3][idx] += w * s;
+                ++idx;
+            }
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int k = 0; k < 10; ++k) acc[b][k] = wave_sum(acc[b][k]);
+    if (lane == 0) {
+        int idx = 0;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int q = p; q < 4; ++q) {
+                const double s = acc[0][idx], su = acc[1][idx], sv = acc[2][idx], sw = acc[3][idx];
+                ++idx;
+                for (int t = 0; t < 2; ++t) {      // both (p, q) and (q, p)
+                    const int r = t ? q : p, c = t ? p : q;
+                    G[r][c] = s;
+                    G[4 + r][4 + c] = s;
+                    G[8 + r][8 + c] = sw;
+                    G[r][4 + c] = 0.0;
+                    G[4 + r][c] = 0.0;
+                    G[r][8 + c] = -su;
+                    G[8 + c][r] = -su;
+                    G[4 + r][8 + c] = -sv;
+                    G[8 + c][4 + r] = -sv;
+                }
+            }
+    }
+    if (lane < 12)
+        for (int k = 0; k < 12; ++k) V[lane][k] = lane == k ? 1.0 : 0.0;
+    __syncthreads();
+
+    // cyclic Jacobi, lane k < 12 owns row / column k of the updates; rotation angle computed by every lane
+    // (a rotation is skipped when |g_pq| <= 1e-16 sqrt(g_pp g_qq), the criterion that keeps the relative accuracy
+    // of the small eigenpairs; every lane reads the same values, so the control flow is uniform)
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        bool rotated = false;
+        for (int p = 0; p < 11; ++p)
+            for (int q = p + 1; q < 12; ++q) {
+                const double apq = G[p][q], app = G[p][p], aqq = G[q][q];
+                if (apq * apq <= 1e-32 * fabs(app * aqq)) continue;
+                rotated = true;
+                const double theta = (aqq - app) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                __syncthreads();
+                if (lane < 12) {
+                    const double akp = G[lane][p], akq = G[lane][q];
+                    G[lane][p] = c * akp - s * akq;
+                    G[lane][q] = s * akp + c * akq;
+                    const double vkp = V[lane][p], vkq = V[lane][q];
+                    V[lane][p] = c * vkp - s * vkq;
+                    V[lane][q] = s * vkp + c * vkq;
+                }
+                __syncthreads();
+                if (lane < 12) {
+                    const double apk = G[p][lane], aqk = G[q][lane];
+                    G[p][lane] = c * apk - s * aqk;
+                    G[q][lane] = s * apk + c * aqk;
+                }
+                __syncthreads();
+            }
+        if (!rotated) break;
+    }
+    __syncthreads();
+    if (lane != 0) return;
+    double lmax = 0.0, lmin = G[0][0];
+    int kmin = 0;
+    for (int k = 0; k < 12; ++k) {
+        const double l = G[k][k];
+        lmax = fmax(lmax, l);
+        if (l < lmin) {
+            lmin = l;
+            kmin = k;
+        }
+    }
+    int rank = 0;
+    for (int k = 0; k < 12; ++k) rank += G[k][k] > lmax * a.rank_thr ? 1 : 0;
+    if (rank < 11 || !(lmax > 0.0)) {                              // p2w:1774
+        for (int k = 0; k < 3; ++k) {
+            a.C[3 * j + k] = nan;
+            a.Theta[3 * j + k] = nan;
+        }
+        return;
+    }
+    // P (3 x 4) = eigenvector of the smallest eigenvalue (p2w:1786-1792); RT_scaled = K^-1 P (p2w:1794)
+    double Pm[3][4];
+    for (int r = 0; r < 3; ++r)
+        for (int q = 0; q < 4; ++q) Pm[r][q] = V[4 * r + q][kmin];
+    const double fi = 1.0 / a.in.f;
+    double M[3][3], T[3];
+    for (int q = 0; q < 3; ++q) {
+        M[0][q] = fi * (Pm[0][q] - a.in.px * Pm[2][q]);
+        M[1][q] = fi * (Pm[1][q] - a.in.py * Pm[2][q]);
+        M[2][q] = Pm[2][q];
+    }
+    T[0] = fi * (Pm[0][3] - a.in.px * Pm[2][3]);
+    T[1] = fi * (Pm[1][3] - a.in.py * Pm[2][3]);
+    T[2] = Pm[2][3];
+    // orthogonal polar factor Q = U V^T of M (orthogonolize_matrix, p2w:241-242) by Newton's iteration
+    // Q <- (Q + Q^-T) / 2; the mean singular value is trace(Q^T M) / 3
+    double Q[3][3];
+    for (int r = 0; r < 3; ++r)
+        for (int q = 0; q < 3; ++q) Q[r][q] = M[r][q];
+    for (int it = 0; it < 40; ++it) {
+        double Qi[3][3];
+        inv3(Q, Qi);
+        double diff = 0.0, nrm = 0.0;
+        for (int r = 0; r < 3; ++r)
+            for (int q = 0; q < 3; ++q) {
+                const double n = 0.5 * (Q[r][q] + Qi[q][r]);
+                diff += (n - Q[r][q]) * (n - Q[r][q]);
+                nrm += n * n;
+                Q[r][q] = n;
+            }
+        if (diff <= 1e-32 * nrm) break;
+    }
+    double tr = 0.0;
+    for (int r = 0; r < 3; ++r)
+        for (int q = 0; q < 3; ++q) tr += Q[r][q] * M[r][q];
+    const double sigma_mean = tr / 3.0;
+    // R = Q^T (p2w:1801), T / mean(Sigma) (p2w:1802), C = -R T (p2w:1803)
+    double R[3][3];
+    for (int r = 0; r < 3; ++r)
+        for (int q = 0; q < 3; ++q) R[r][q] = Q[q][r];
+    for (int r = 0; r < 3; ++r)
+        a.C[3 * j + r] = -(R[r][0] * T[0] + R[r][1] * T[1] + R[r][2] * T[2]) / sigma_mean;
+    const double det = R[0][0] * (R[1][1] * R[2][2] - R[1][2] * R[2][1]) - R[0][1] * (R[1][0] * R[2][2] - R[1][2] * R[2][0]) +
+                       R[0][2] * (R[1][0] * R[2][1] - R[1][1] * R[2][0]);
+    const double sg = det > 0.0 ? 1.0 : (det < 0.0 ? -1.0 : 0.0);          // p2w:1805
+    for (int r = 0; r < 3; ++r)
+        for (int q = 0; q < 3; ++q) R[r][q] *= sg;
+    const double Cx = sqrt(R[1][0] * R[1][0] + R[1][1] * R[1][1]);          // get_rotations, p2w:260-266
+    a.Theta[3 * j + 0] = atan2(-R[1][2], Cx);
+    a.Theta[3 * j + 1] = atan2(R[0][2] / Cx, R[2][2] / Cx);
+    a.Theta[3 * j + 2] = atan2(R[1][0] / Cx, R[1][1] / Cx);
+}
+
+static int cdiv_n(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+}  // namespace ba
+
+using namespace ba;
+
+extern "C" {
+
+int ba_triangulate(int64_t N, int64_t K, const int64_t *row_ptr, const int32_t *oj, const double *uv, const double *C,
+                   const double *Theta, double phi_x, double W, double H, int normalize, int64_t rank_rows, double *P_work,
+                   double *X_out, void *stream) {
+    BA_REQUIRE(N > 0 && K > 0 && row_ptr && oj && uv && C && Theta && P_work && X_out, "ba_triangulate: bad argument");
+    BA_REQUIRE(phi_x > 0.0 && phi_x < 3.14159265358979323846, "ba_triangulate: phi_x outside (0, pi)");
+    hipStream_t st = (hipStream_t)stream;
+    const Intrinsics in = make_intrinsics(phi_x, W, H, normalize);
+    const double tol = (double)(rank_rows > 4 ? rank_rows : 4) * 2.220446049250313e-16;
+    const double thr = tol * tol > RANK_FLOOR ? tol * tol : RANK_FLOOR;
+    hipLaunchKernelGGL(k_projection_matrices, dim3(cdiv_n(K, 256)), dim3(256), 0, st, K, C, Theta, in, P_work);
+    hipLaunchKernelGGL(k_triangulate, dim3(cdiv_n(N, 256)), dim3(256), 0, st, N, row_ptr, oj, (const double2 *)uv, P_work, in,
+                       thr, X_out);
+    BA_HIP(hipGetLastError());
+    return BA_OK;
+}
+
+int ba_resect(int64_t N, int64_t K, const int64_t *col_ptr, const int32_t *oi_by_camera, const double *uv_by_camera,
+              const double *X, double phi_x, double W, double H, int normalize, int64_t rank_rows, double *C_out,
+              double *Theta_out, void *stream) {
+    BA_REQUIRE(N > 0 && K > 0 && col_ptr && oi_by_camera && uv_by_camera && X && C_out && Theta_out, "ba_resect: bad argument");
+    BA_REQUIRE(phi_x > 0.0 && phi_x < 3.14159265358979323846, "ba_resect: phi_x outside (0, pi)");
+    ResectArgs a;
+    a.K = K;
+    a.col_ptr = col_ptr;
+    a.oi = oi_by_camera;
+    a.uv = (const double2 *)uv_by_camera;
+    a.X = X;
+    a.in = make_intrinsics(phi_x, W, H, normalize);
+    const double tol = (double)(rank_rows > 12 ? rank_rows : 12) * 2.220446049250313e-16;
+    a.rank_thr = tol * tol > RANK_FLOOR ? tol * tol : RANK_FLOOR;
+    a.min_points = 6;
+    a.C = C_out;
+    a.Theta = Theta_out;
+    hipLaunchKernelGGL(k_resect, dim3((unsigned)K), dim3(64), 0, (hipStream_t)stream, a);
+    BA_HIP(hipGetLastError());
+    return BA_OK;
+}
+
+}  // extern "C"

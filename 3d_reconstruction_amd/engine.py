@@ -476,3 +476,65 @@ def reprojection_error(pix_xy, model, device='cuda:0'):
         check(lib.ba_reprojection_error(int(pix.shape[0]), ptr(pix), ptr(mod), ptr(sums), stream_ptr()))
     s = sums.cpu().numpy()
     return float(s[0]), int(s[1])
+
+
+def _ranges(keys, n):
+    """Offsets (int64, n + 1) of the runs of a sorted int key tensor with values in [0, n)."""
+    counts = torch.bincount(keys.to(torch.int64), minlength=n)
+    ptr = torch.zeros(n + 1, dtype=torch.int64, device=keys.device)
+    ptr[1:] = torch.cumsum(counts, 0)
+    return ptr, counts
+
+
+def triangulate(oi, oj, uv, N, C_, Theta, phi_x, W, H, normalize=False, device='cuda:0', row_ptr=None):
+    """Every point from the cameras that see it (ba_triangulate).  Observations sorted by point;
+    returns a device tensor (N,3), NaN where the reference leaves NaN."""
+    lib = _lib.load()
+    dev = torch.device(device)
+    oi = _dev_tensor(oi, torch.int32, dev)
+    oj = _dev_tensor(oj, torch.int32, dev)
+    uv = _dev_tensor(uv, F64, dev).view(-1, 2)
+    Cd, Td = _dev_tensor(C_, F64, dev), _dev_tensor(Theta, F64, dev)
+    K = int(Cd.shape[0])
+    if oi.numel() > 1 and not bool((oi[1:] >= oi[:-1]).all()):
+        raise _lib.BAError('observations must be sorted by point index')
+    if row_ptr is None:
+        row_ptr, counts = _ranges(oi, N)
+    else:
+        counts = row_ptr[1:] - row_ptr[:-1]
+    # cameras that see at least one point observed twice or more (p2w:1671-1677): numpy's rank tolerance counts them
+    sel = counts[oi.to(torch.int64)] >= 2
+    K0 = int(torch.unique(oj[sel]).numel()) if bool(sel.any()) else 0
+    X = torch.empty((N, 3), dtype=F64, device=dev)
+    P = torch.empty(12 * K, dtype=F64, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.ba_triangulate(N, K, ptr(row_ptr), ptr(oj), ptr(uv), ptr(Cd), ptr(Td), float(phi_x), float(W), float(H),
+                                 int(bool(normalize)), max(2 * K0, 4), ptr(P), ptr(X), stream_ptr()))
+    return X
+
+
+def resect(oi, oj, uv, K, X, phi_x, W, H, normalize=False, device='cuda:0'):
+    """Every camera from the points it sees (ba_resect); returns device tensors C (K,3), Theta (K,3)
+    with NaN where the reference leaves NaN.  Raises ValueError like the reference when no camera
+    sees 6 points (p2w:1742)."""
+    lib = _lib.load()
+    dev = torch.device(device)
+    oi = _dev_tensor(oi, torch.int32, dev)
+    oj = _dev_tensor(oj, torch.int32, dev)
+    uv = _dev_tensor(uv, F64, dev).view(-1, 2)
+    Xd = _dev_tensor(X, F64, dev)
+    N = int(Xd.shape[0])
+    order = torch.argsort(oj.to(torch.int64), stable=True)
+    oj_s = oj[order]
+    col_ptr, counts = _ranges(oj_s, K)
+    if not bool((counts >= 6).any()):
+        raise ValueError('Expected each camera to have at least 6 visible points')
+    sel = counts[oj.to(torch.int64)] >= 6
+    N0 = int(torch.unique(oi[sel]).numel())                        # p2w:1743-1744
+    oi_s, uv_s = oi[order].contiguous(), uv[order].contiguous()
+    C_out = torch.empty((K, 3), dtype=F64, device=dev)
+    T_out = torch.empty((K, 3), dtype=F64, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.ba_resect(N, K, ptr(col_ptr), ptr(oi_s), ptr(uv_s), ptr(Xd), float(phi_x), float(W), float(H),
+                            int(bool(normalize)), max(2 * N0, 12), ptr(C_out), ptr(T_out), stream_ptr()))
+    return C_out, T_out

@@ -249,3 +249,38 @@ def error(X_pix, X_model, device=None):
     dev = torch.device(device) if device is not None else _default_device()
     s, n = engine.reprojection_error(np.asarray(X_pix), np.asarray(X_model), dev)
     return np.float64(s) / (2 * n)
+
+
+def get_X_from_C_Theta(X_pix, C, Theta, phi_x, W, H, normalize=False, _validate=True, device=None):
+    """Linear triangulation of every point from the cameras (p2w:1655-1721): (N,3), NaN for points
+    seen fewer than twice or without enough parallax."""
+    if _validate:
+        N, K = validate_scene_parameters(X_pix=X_pix, C=C, Theta=Theta, phi_x=phi_x, ret_shapes=True)
+    else:
+        N, K = X_pix.shape[:2]
+    dev = torch.device(device) if device is not None else _default_device()
+    oi, oj, uv, row_ptr = engine.visibility_coo(np.asarray(X_pix), dev)
+    X = engine.triangulate(oi, oj, uv, N, C, Theta, phi_x, W, H, normalize, dev, row_ptr=row_ptr).cpu().numpy()
+    if np.isnan(X).all():
+        import warnings
+        seen_twice = bool((row_ptr[1:] - row_ptr[:-1] >= 2).any())
+        warnings.warn('Unable to solve the problem for any point, too little valuable information' if seen_twice
+                      else 'Expected each point to be visible at least 2 times', RuntimeWarning)      # p2w:1674, 1709
+    return X
+
+
+def get_C_Theta_from_X(X_pix, X, phi_x, W, H, normalize=False, _validate=True, device=None):
+    """DLT resection of every camera from the points (p2w:1724-1808): C (K,3), Theta (K,3), NaN for
+    cameras that see fewer than 6 points or whose points do not determine them."""
+    if _validate:
+        N, K = validate_scene_parameters(X_pix=X_pix, X=X, phi_x=phi_x, ret_shapes=True)
+    else:
+        N, K = X_pix.shape[:2]
+    dev = torch.device(device) if device is not None else _default_device()
+    oi, oj, uv, _ = engine.visibility_coo(np.asarray(X_pix), dev)
+    C, Theta = engine.resect(oi, oj, uv, K, X, phi_x, W, H, normalize, dev)
+    C, Theta = C.cpu().numpy(), Theta.cpu().numpy()
+    if np.isnan(C).all():
+        import warnings
+        warnings.warn('Unable to solve the problem for any camera, too little valuable information', RuntimeWarning)
+    return C, Theta

@@ -172,6 +172,28 @@ int ba_points_step(int64_t N, const double *X_in, double *X_out, const double *g
                    double *s_out, const double *r_in, double *r_out, int rule, double lr, double gscale,
                    double bc1, double bc2, const double *gauge, void *stream);
 
+/* ---- linear steps on either side of the bundle adjustment, on the visible pairs only.
+ * ba_triangulate replaces get_X_from_C_Theta (p2w:1655-1721): X_out[N][3] from the cameras; points seen
+ *   fewer than twice or whose rows have rank < 3 get NaN.  Observations sorted by point: row_ptr[N+1]
+ *   (int64) gives every point's range in oj / uv.  rank_rows = max(2 K0, 4) of numpy's rank tolerance
+ *   (K0: cameras that see a point of the selection, p2w:1676, 1707).  P_work: 12 K doubles of scratch.
+ * ba_resect replaces get_C_Theta_from_X (p2w:1724-1808): C_out[K][3], Theta_out[K][3] from the points
+ *   by DLT; cameras that see fewer than 6 points or whose rows have rank < 11 get NaN; observations of
+ *   points with NaN coordinates are skipped (p2w:1771-1772).  Observations sorted by camera:
+ *   col_ptr[K+1] (int64) gives every camera's range in oi_by_camera / uv_by_camera.  P is the
+ *   eigenvector of the smallest eigenvalue of A^T A, the reference's own method for large inputs
+ *   (p2w:1789-1792; for small inputs it takes the SVD of A), found by cyclic Jacobi rotations, which
+ *   keep the relative accuracy of the small eigenpairs: measured within 2e-11 of the SVD of A in pixel
+ *   units.  rank_rows = max(2 N0, 12) (p2w:1743, 1774).
+ * phi_x, W, H, normalize as in the reference (normalize: pixel centres shifted to the image centre
+ * and divided by max(W, H), p2w:1686-1691). */
+int ba_triangulate(int64_t N, int64_t K, const int64_t *row_ptr, const int32_t *oj, const double *uv,
+                   const double *C, const double *Theta, double phi_x, double W, double H, int normalize,
+                   int64_t rank_rows, double *P_work, double *X_out, void *stream);
+int ba_resect(int64_t N, int64_t K, const int64_t *col_ptr, const int32_t *oi_by_camera,
+              const double *uv_by_camera, const double *X, double phi_x, double W, double H, int normalize,
+              int64_t rank_rows, double *C_out, double *Theta_out, void *stream);
+
 /* ---- second-order extension: NO counterpart in the reference (its optimiser is first-order, p2w:336-362).
  * Gauss-Newton / Levenberg-Marquardt on the same energy.  All quantities un-normalised (J^T J, J^T r).
  * ba_eval_jtj: the fused pass of ba_eval plus the blocks of J^T J:

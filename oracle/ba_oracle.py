@@ -586,3 +586,103 @@ def error(X_pix, X_model):
     vis = (X_pix[:, :, 0] >= 0) & ~np.isnan(X_model[:, :, 0])
     diff = X_model[vis].ravel() - (X_pix[vis].ravel() + 0.5)
     return np.dot(diff, diff) / (2 * vis.sum())
+
+
+# --------------------------------------------------------------------------- #
+# linear initialisation steps on either side of the bundle adjustment
+# (p2w:1655-1721 get_X_from_C_Theta, p2w:1724-1808 get_C_Theta_from_X), on the visible pairs only
+# --------------------------------------------------------------------------- #
+def _intrinsics(phi_x, W, H, normalize):
+    """f_x = f_y, p_x, p_y and the map of a pixel centre (p2w:1681-1691, 1748-1758)."""
+    if not normalize:
+        return W / 2.0 / np.tan(phi_x / 2.0), W / 2.0, H / 2.0, 1.0, np.zeros(2)
+    m = max(W, H)
+    return W / m / 2.0 / np.tan(phi_x / 2.0), 0.0, 0.0, 1.0 / m, 0.5 * np.array([W, H])
+
+
+def triangulate_obs(i, j, uv, N, C, Theta, phi_x, W, H, normalize=False):
+    """`get_X_from_C_Theta` (p2w:1655-1721): linear triangulation of every point seen at least
+    twice from the rows u P_3 - P_1, v P_3 - P_2 of its observations (P = K [R^T | -R^T C],
+    p2w:1693-1704), solved through the 3x3 normal equations (p2w:1716-1719).  Points whose row
+    matrix has rank < 3 by numpy's rule (tolerance: largest singular value x max(2 K0, 4) x eps,
+    K0 = cameras that see a point of the selection, p2w:1676, 1707) stay NaN."""
+    X = np.full((N, 3), np.nan)
+    deg = np.bincount(i, minlength=N)
+    sel = deg[i] >= 2                                             # p2w:1671
+    if not sel.any():
+        return X
+    K0 = np.unique(j[sel]).size                                   # p2w:1676-1677
+    f, px, py, scale, shift = _intrinsics(phi_x, W, H, normalize)
+    c = (uv - shift) * scale                                      # p2w:1682 / 1688
+    R = ryxz(Theta)
+    RT = R.transpose(0, 2, 1)
+    P = np.array([[f, 0, px], [0, f, py], [0, 0, 1.0]]) @ np.concatenate((RT, -(RT @ C[:, :, None])), axis=2)
+    rows0 = c[:, 0:1] * P[j, 2, :] - P[j, 0, :]                   # p2w:1703
+    rows1 = c[:, 1:2] * P[j, 2, :] - P[j, 1, :]                   # p2w:1704
+    tol_rows = max(2 * K0, 4)
+    order = np.argsort(i, kind='stable')
+    start = np.concatenate(([0], np.cumsum(deg)))
+    for pt in np.nonzero(deg >= 2)[0]:
+        e = order[start[pt]:start[pt + 1]]
+        A = np.concatenate((rows0[e], rows1[e]))
+        s = np.linalg.svd(A, compute_uv=False)
+        if (s > s.max() * tol_rows * np.finfo(float).eps).sum() < 3:      # matrix_rank, p2w:1707
+            continue
+        M, b = A[:, :3], A[:, 3]
+        X[pt] = -np.linalg.solve(M.T @ M, M.T @ b)                # p2w:1717-1719
+    return X
+
+
+def resect_obs(i, j, uv, K, X, phi_x, W, H, normalize=False, use_gram=None):
+    """`get_C_Theta_from_X` (p2w:1724-1808): DLT resection of every camera that sees at least 6
+    points.  Rows (-Xh, 0, u Xh), (0, -Xh, v Xh) per observation (p2w:1767-1770), rows of points
+    with NaN coordinates zeroed (p2w:1771-1772), rank >= 11 required (p2w:1774), P = right
+    singular vector of the smallest singular value (SVD for small problems, smallest eigenpair
+    of A^T A for large ones, p2w:1785-1792; use_gram forces one of the two), then K^-1 P, the
+    rotation by orthogonalisation, T / mean singular value, C = -R T, Theta from R sign(det R)
+    (p2w:1794-1806)."""
+    C = np.full((K, 3), np.nan)
+    Theta = np.full((K, 3), np.nan)
+    deg = np.bincount(j, minlength=K)
+    if not (deg >= 6).any():
+        raise ValueError('Expected each camera to have at least 6 visible points')      # p2w:1742
+    J0 = np.nonzero(deg >= 6)[0]
+    N0 = np.unique(i[deg[j] >= 6]).size                           # p2w:1743-1744
+    f, px, py, scale, shift = _intrinsics(phi_x, W, H, normalize)
+    K_inv = np.array([[1.0 / f, 0.0, -px / f], [0.0, 1.0 / f, -py / f], [0.0, 0.0, 1.0]])
+    c = (uv - shift) * scale
+    Xh = np.ones((X.shape[0], 4))
+    Xh[:, :3] = X
+    mats = {}
+    for cam in J0:
+        e = np.nonzero(j == cam)[0]
+        xh = Xh[i[e]]
+        A = np.zeros((2 * e.size, 12))
+        A[0::2, 0:4] = -xh
+        A[1::2, 4:8] = -xh
+        A[0::2, 8:12] = c[e, 0:1] * xh
+        A[1::2, 8:12] = c[e, 1:2] * xh
+        A[np.isnan(A).any(axis=1)] = 0.0
+        s = np.linalg.svd(A, compute_uv=False)
+        if (s > s.max() * max(2 * N0, 12) * np.finfo(float).eps).sum() >= 11:
+            mats[cam] = A
+    if not mats:
+        return C, Theta
+    J1 = np.array(sorted(mats))
+    N1 = np.unique(i[np.isin(j, J1)]).size
+    gram = (N1 * J1.size > 25000) if use_gram is None else use_gram
+    for cam in J1:
+        A = mats[cam]
+        if gram:
+            w, v = np.linalg.eigh(A.T @ A)
+            p = v[:, 0]
+        else:
+            p = np.linalg.svd(A)[2][-1]
+        RT_scaled = K_inv @ p.reshape(3, 4)
+        U, Sigma, Vh = np.linalg.svd(RT_scaled[:, :3])            # orthogonolize_matrix, p2w:241-242
+        Rm = (U @ Vh).T
+        T = RT_scaled[:, 3] / Sigma.mean()
+        C[cam] = -(Rm @ T)
+        Rm = Rm * np.sign(np.linalg.det(Rm))
+        Theta[cam] = get_rotations(Rm[None])[0]
+    return C, Theta

@@ -332,6 +332,40 @@ def capture_f6(out):
     save_npz(os.path.join(out, 'f6_medium.npz'), **arrays)
 
 
+def capture_f7(out):
+    """Linear initialisation steps (p2w:1655-1808): triangulation from cameras and resection from
+    points on a sparse scene, with the true parameters and with perturbed ones, both pixel
+    normalisations.  Also a scene with degenerate points / cameras (too few observations)."""
+    import warnings
+    sc = make_scene(120, 24, seed=21, vis_frac=0.55)
+    X_pix = sc['X_pix'].copy()
+    X_pix[:3, 1:] = -1            # points seen once
+    X_pix[3, :] = -1              # a point never seen
+    X_pix[10:, 5] = -1            # a camera with fewer than 6 points (it keeps what points 0..9 give it)
+    vis = X_pix[:, :, 0] >= 0
+    ii, jj = np.nonzero(vis)
+    arrays = dict(N=120, K=24, W=sc['W'], H=sc['H'], phi_x=sc['phi_true'], obs_i=ii.astype(np.int32),
+                  obs_j=jj.astype(np.int32), obs_xy=X_pix[vis].astype(np.int32), X_true=sc['X_true'],
+                  C_true=sc['C_true'], Theta_true=sc['Theta_true'], X_noisy=sc['X_0'], C_noisy=sc['C_0'],
+                  Theta_noisy=sc['Theta_0'])
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for tag, (Xs, Cs, Ts) in dict(true=(sc['X_true'], sc['C_true'], sc['Theta_true']),
+                                      noisy=(sc['X_0'], sc['C_0'], sc['Theta_0'])).items():
+            for norm in (False, True):
+                n = 'norm' if norm else 'pix'
+                arrays[f'tri_{tag}_{n}'] = p.get_X_from_C_Theta(X_pix, Cs, Ts, sc['phi_true'], sc['W'], sc['H'],
+                                                              normalize=norm)
+                Cr, Tr = p.get_C_Theta_from_X(X_pix, Xs, sc['phi_true'], sc['W'], sc['H'], normalize=norm)
+                arrays[f'res_C_{tag}_{n}'], arrays[f'res_Theta_{tag}_{n}'] = Cr, Tr
+        # points with NaN coordinates (what a failed triangulation hands on) are skipped by the resection
+        Xn = sc['X_0'].copy()
+        Xn[20:30] = np.nan
+        Cr, Tr = p.get_C_Theta_from_X(X_pix, Xn, sc['phi_true'], sc['W'], sc['H'], normalize=True, _validate=False)
+        arrays['X_with_nan'], arrays['res_C_nan_norm'], arrays['res_Theta_nan_norm'] = Xn, Cr, Tr
+    save_npz(os.path.join(out, 'f7_linear_init.npz'), **arrays)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden'))
@@ -339,7 +373,7 @@ def main():
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     todo = dict(f1=capture_f1, f2=capture_f2, f3=capture_f3, f4=capture_f4, f5=capture_f5,
-                f6=capture_f6)
+                f6=capture_f6, f7=capture_f7)
     for name, fn in todo.items():
         if a.only and name not in a.only.split(','):
             continue

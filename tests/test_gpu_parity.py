@@ -420,6 +420,67 @@ def test_transform_and_error(ba, golden):
     assert ba.error(g['err_X_pix'], g['tr_default']) == pytest.approx(float(g['err_value']), rel=1e-12)
 
 
+# ---- linear initialisation steps (p2w:1655-1808) ------------------------------------------------
+def test_triangulation_and_resection_match_reference(ba, golden):
+    """get_X_from_C_Theta / get_C_Theta_from_X through the dense drop-in signatures vs the
+    reference's outputs, to 1e-9.  The device forms A^T A like the reference's large-input path
+    (p2w:1789-1792) while the goldens come from its SVD path; the cyclic Jacobi iteration keeps the
+    relative accuracy of the small eigenpairs (numpy.linalg.eigh on the same matrix is off by 1e-5
+    in pixel units), so both agree."""
+    g = golden('f7_linear_init.npz')
+    N, K, W, H, phi = int(g['N']), int(g['K']), int(g['W']), int(g['H']), float(g['phi_x'])
+    X_pix = np.full((N, K, 2), -1, dtype=np.int32)
+    X_pix[g['obs_i'], g['obs_j']] = g['obs_xy']
+    for tag in ('true', 'noisy'):
+        for norm, n in ((False, 'pix'), (True, 'norm')):
+            X, C, Th = g[f'X_{tag}'], g[f'C_{tag}'], g[f'Theta_{tag}']
+            got = ba.get_X_from_C_Theta(X_pix, C, Th, phi, W, H, normalize=norm)
+            want = g[f'tri_{tag}_{n}']
+            assert np.array_equal(np.isnan(got), np.isnan(want))
+            assert np.nanmax(np.abs(got - want)) < 1e-9
+            Cg, Tg = ba.get_C_Theta_from_X(X_pix, X, phi, W, H, normalize=norm)
+            tol = 1e-9
+            assert np.array_equal(np.isnan(Cg), np.isnan(g[f'res_C_{tag}_{n}']))
+            assert np.nanmax(np.abs(Cg - g[f'res_C_{tag}_{n}'])) < tol
+            assert np.nanmax(np.abs(Tg - g[f'res_Theta_{tag}_{n}'])) < tol
+    Cg, Tg = ba.get_C_Theta_from_X(X_pix, g['X_with_nan'], phi, W, H, normalize=True, _validate=False)
+    assert np.nanmax(np.abs(Cg - g['res_C_nan_norm'])) < 1e-9 and np.nanmax(np.abs(Tg - g['res_Theta_nan_norm'])) < 1e-9
+    few = X_pix.copy()
+    few[5:, :] = -1
+    with pytest.raises(ValueError, match='at least 6 visible points'):
+        ba.get_C_Theta_from_X(few, g['X_true'], phi, W, H)
+    with pytest.warns(RuntimeWarning, match='at least 2 times'):
+        once = X_pix.copy()
+        once[:, 1:] = -1
+        assert np.isnan(ba.get_X_from_C_Theta(once, g['C_true'], g['Theta_true'], phi, W, H)).all()
+
+
+def test_triangulation_and_resection_vs_oracle_and_round_trip(ba):
+    """A larger sparse scene: device vs the CPU restatement, and the round trip - points
+    triangulated from the true cameras reproject onto their pixels to within the half-pixel
+    quantisation, cameras resected from the true points land on the true cameras."""
+    sc = ba.scenes.orbit_scene(N=3000, K=60, track_len=12, seed=3)
+    N, K, W, H = sc['N_local'], sc['K'], sc['W'], sc['H']
+    i, j, uv = sc['i'], sc['j'], sc['uv']
+    Xt, Ct, Tt, phi = sc['X'], sc['C'], sc['Theta'], sc['phi_x']
+    for norm in (False, True):
+        Xd = ba.engine.triangulate(i, j, uv, N, Ct, Tt, phi, W, H, norm, DEV).cpu().numpy()
+        Xo = orc.triangulate_obs(i, j, uv, N, Ct, Tt, phi, W, H, norm)
+        assert np.array_equal(np.isnan(Xd), np.isnan(Xo))
+        assert np.nanmax(np.abs(Xd - Xo)) < 1e-9
+        Cd, Td = (t.cpu().numpy() for t in ba.engine.resect(i, j, uv, K, Xt, phi, W, H, norm, DEV))
+        Co, To = orc.resect_obs(i, j, uv, K, Xt, phi, W, H, norm, use_gram=False)     # the SVD of the rows
+        tol = 1e-9
+        assert np.array_equal(np.isnan(Cd), np.isnan(Co))
+        assert np.nanmax(np.abs(Cd - Co)) < tol and np.nanmax(np.abs(Td - To)) < tol
+    ok = ~np.isnan(Xd[:, 0])
+    assert ok.mean() > 0.95
+    model = orc.transform_obs(np.nan_to_num(Xd), Ct, Tt, phi, W, H, i, j)
+    vis = ok[i]
+    assert np.abs(model[vis] - uv[vis]).max() < 2.0            # pixel quantisation of the tracks
+    assert np.nanmax(np.abs(Cd - Ct)) < 5e-2 and np.nanmax(np.abs(Td - Tt)) < 5e-3
+
+
 # ---- full-size properties (N = 1 M points, K = 2 k cameras, ~10 M observations) ---------------
 def test_full_size_invariants(ba):
     import torch

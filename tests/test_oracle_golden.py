@@ -47,6 +47,35 @@ def test_f5_transform_and_error(golden):
     assert orc.error(g['err_X_pix'], shifted) == pytest.approx(float(g['err_value_shifted']), rel=1e-12)
 
 
+def _f7_cases(g):
+    for tag in ('true', 'noisy'):
+        for norm in (False, True):
+            yield tag, norm, 'norm' if norm else 'pix'
+
+
+def test_f7_triangulation_and_resection(golden):
+    """Linear initialisation steps (p2w:1655-1808) restated on the visible pairs vs the reference's
+    own outputs: same NaN pattern (points seen < 2 times, cameras with < 6 points), values to
+    rounding for the triangulation and the SVD resection; the Gram-matrix resection (the
+    reference's path for large inputs) within what squaring the condition number allows."""
+    g = golden('f7_linear_init.npz')
+    N, K, W, H, phi = int(g['N']), int(g['K']), int(g['W']), int(g['H']), float(g['phi_x'])
+    i, j, uv = g['obs_i'], g['obs_j'], g['obs_xy'] + 0.5
+    for tag, norm, n in _f7_cases(g):
+        X, C, Th = g[f'X_{tag}'], g[f'C_{tag}'], g[f'Theta_{tag}']
+        got = orc.triangulate_obs(i, j, uv, N, C, Th, phi, W, H, norm)
+        want = g[f'tri_{tag}_{n}']
+        assert np.array_equal(np.isnan(got), np.isnan(want)) and np.isnan(want[:4]).all()
+        assert np.nanmax(np.abs(got - want)) < 1e-12
+        for gram, tol in ((False, 1e-10), (True, 1e-6 if not norm else 1e-10)):
+            Cg, Tg = orc.resect_obs(i, j, uv, K, X, phi, W, H, norm, use_gram=gram)
+            assert np.array_equal(np.isnan(Cg), np.isnan(g[f'res_C_{tag}_{n}'])) and np.isnan(Cg[5]).all()
+            assert np.nanmax(np.abs(Cg - g[f'res_C_{tag}_{n}'])) < tol
+            assert np.nanmax(np.abs(Tg - g[f'res_Theta_{tag}_{n}'])) < tol
+    Cg, Tg = orc.resect_obs(i, j, uv, K, g['X_with_nan'], phi, W, H, True, use_gram=False)
+    assert np.nanmax(np.abs(Cg - g['res_C_nan_norm'])) < 1e-10 and np.nanmax(np.abs(Tg - g['res_Theta_nan_norm'])) < 1e-10
+
+
 def test_visibility_indexing_bit_exact(golden):
     g = golden('f2_moscow_ride.npz')
     N, K = int(g['N']), int(g['K'])
