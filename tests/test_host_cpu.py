@@ -191,3 +191,36 @@ def test_orbit_scene_is_well_formed():
     b = scenes.orbit_scene(N=3000, K=120, seed=3, part=1, parts=2)
     assert np.array_equal(a['C'], b['C']) and np.array_equal(a['Theta_0'], b['Theta_0'])
     assert a['N_local'] + b['N_local'] == 3000 and b['point_offset'] == a['N_local']
+
+
+def test_track_files_round_trip(tmp_path):
+    """The reference's pickle layout (written here with pickle, read back without unpickling) and the
+    visible-pair .npz give the same observation list, in numpy.nonzero order."""
+    import importlib
+    import pickle
+    tracks = importlib.import_module('3d_reconstruction_amd.tracks')
+    rng = np.random.default_rng(4)
+    N, K, W, H = 37, 11, 3840, 2160
+    X_pix = rng.integers(0, 2000, (N, K, 2)).astype(np.int32)
+    X_pix[rng.random((N, K)) < 0.6] = -1
+    ref = tmp_path / 'input.txt'
+    with open(ref, 'wb') as fh:
+        pickle.dump((X_pix, W, H), fh, protocol=4)
+    a = tracks.load_tracks(str(ref))
+    ii, jj = np.nonzero(X_pix[:, :, 0] >= 0)
+    assert (a['N'], a['K'], a['W'], a['H']) == (N, K, W, H)
+    assert np.array_equal(a['i'], ii) and np.array_equal(a['j'], jj)
+    assert np.array_equal(a['xy'], X_pix[ii, jj]) and np.array_equal(a['uv'], X_pix[ii, jj] + 0.5)
+    npz = tmp_path / 'tracks.npz'
+    perm = rng.permutation(ii.size)
+    tracks.save_tracks(str(npz), a['i'][perm], a['j'][perm], a['xy'][perm], N, K, W, H)     # any order in, sorted out
+    b = tracks.load_tracks(str(npz))
+    for k in ('i', 'j', 'xy', 'uv'):
+        assert np.array_equal(a[k], b[k])
+    assert np.array_equal(tracks.coo_to_dense(b['i'], b['j'], b['xy'], N, K), X_pix)
+    # a pickle that names anything else is refused, unread
+    evil = tmp_path / 'evil.txt'
+    with open(evil, 'wb') as fh:
+        pickle.dump((X_pix, W, H, print), fh, protocol=4)
+    with pytest.raises(ValueError, match='not a pickled'):
+        tracks.load_tracks(str(evil))
