@@ -11,7 +11,7 @@ import torch
 
 from . import _lib
 from ._lib import check, ptr, stream_ptr
-from .sharding import allreduce_sum_
+from .sharding import StreamAllReduce, allreduce_sum_
 
 F64 = torch.float64
 
@@ -99,6 +99,7 @@ class Shard:
         # RCCL sums device tensors in place; with a gloo group (rehearsals of the multi-rank path on
         # one GPU) the buffers are staged through the host explicitly
         self._stage_reduce = self.distributed and torch.distributed.get_backend(group) == 'gloo'
+        self._stream_allreduce = False     # not yet tried; then a StreamAllReduce or None (torch.distributed)
         self._out_ptrs = [t.data_ptr() for t in (self.E_sum, self.gX, self.gC, self.gTheta, self.gphi)]
         self._E_host = C.c_double(0.0)
         # Several GPUs: the sums a deferred pass leaves for the camera step (camera-frame sums, per-tile partial
@@ -155,6 +156,11 @@ class Shard:
         return bool(t.item() > 0.5)
 
     def _sum_over_ranks(self, t):
+        if self._stream_allreduce is False:      # first use: every rank gets here in the same iteration
+            self._stream_allreduce = None if self._stage_reduce else StreamAllReduce.create(self.group, self.device)
+        if self._stream_allreduce is not None:
+            self._stream_allreduce(t, self.stream)
+            return
         if self._stage_reduce:
             host = t.cpu()
             torch.distributed.all_reduce(host, op=torch.distributed.ReduceOp.SUM, group=self.group)

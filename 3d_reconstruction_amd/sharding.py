@@ -69,3 +69,78 @@ def all_gather_rows(x_local, point_bounds, group=None):
     parts = [x_local.new_zeros((m, width)) for _ in range(world)]
     torch.distributed.all_gather(parts, padded, group=group)
     return torch.cat([p[:n] for p, n in zip(parts, sizes)], dim=0)
+
+
+class StreamAllReduce:
+    """Sum of an fp64 device tensor over the ranks of a group, queued on the CALLER's stream.
+
+    `torch.distributed.all_reduce` runs the RCCL kernel on a stream of its own, i.e. two event
+    hand-overs between streams per call (~10 us on the critical path of an iteration whose kernels
+    take ~75 us).  Here `ncclAllReduce` of the RCCL library that torch has already loaded is called
+    directly, on the stream the neighbouring kernels use.  The communicator is created from a unique
+    id made on the group's first rank and broadcast through torch.distributed; a trial sum is
+    compared with torch.distributed's before the object is used.  `StreamAllReduce.create` returns
+    None (callers then stay with torch.distributed) whenever any of that is not possible."""
+
+    NCCL_FLOAT64, NCCL_SUM = 8, 0
+
+    def __init__(self, lib, comm):
+        self._lib, self._comm = lib, comm
+
+    def __call__(self, t, stream):
+        import ctypes as C
+        p = C.c_void_p(t.data_ptr())
+        st = stream if isinstance(stream, C.c_void_p) else C.c_void_p(stream)
+        rc = self._lib.ncclAllReduce(p, p, C.c_size_t(t.numel()), self.NCCL_FLOAT64, self.NCCL_SUM, self._comm, st)
+        if rc != 0:
+            raise RuntimeError(f'ncclAllReduce failed with status {rc}')
+
+    @classmethod
+    def create(cls, group, device):
+        import ctypes as C
+        import os
+        dist = torch.distributed
+        try:
+            if dist.get_backend(group) != 'nccl' or os.environ.get('BA_TORCH_ALLREDUCE'):
+                return None
+            path = os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')
+            ok = torch.tensor([1.0 if os.path.exists(path) else 0.0], dtype=torch.float64, device=device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            if float(ok.item()) < 0.5:
+                return None
+            lib = C.CDLL(path)
+
+            class UniqueId(C.Structure):
+                _fields_ = [('internal', C.c_byte * 128)]
+
+            lib.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
+            lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+            lib.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+            for fn in (lib.ncclGetUniqueId, lib.ncclCommInitRank, lib.ncclAllReduce):
+                fn.restype = C.c_int
+            rank, world = dist.get_rank(group), dist.get_world_size(group)
+            uid = UniqueId()
+            if rank == 0 and lib.ncclGetUniqueId(C.byref(uid)) != 0:
+                uid = UniqueId()        # all zeros: the trial below fails on every rank
+            raw = torch.tensor(list(bytes(uid)), dtype=torch.int32, device=device)
+            dist.broadcast(raw, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            uid = UniqueId.from_buffer_copy(bytes(int(v) & 0xff for v in raw.tolist()))
+            comm = C.c_void_p()
+            with torch.cuda.device(device):
+                rc = lib.ncclCommInitRank(C.byref(comm), world, uid, rank)
+            good = torch.tensor([1.0 if rc == 0 and comm.value else 0.0], dtype=torch.float64, device=device)
+            dist.all_reduce(good, op=dist.ReduceOp.MIN, group=group)
+            if float(good.item()) < 0.5:
+                return None
+            obj = cls(lib, comm)
+            # trial: the same sum both ways
+            a = torch.arange(1, 1025, dtype=torch.float64, device=device) * (rank + 1)
+            b = a.clone()
+            with torch.cuda.device(device):
+                obj(a, torch.cuda.current_stream().cuda_stream)
+            dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group)
+            same = torch.tensor([1.0 if torch.equal(a, b) else 0.0], dtype=torch.float64, device=device)
+            dist.all_reduce(same, op=dist.ReduceOp.MIN, group=group)
+            return obj if float(same.item()) > 0.5 else None
+        except Exception:
+            return None
