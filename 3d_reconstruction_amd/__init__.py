@@ -8,6 +8,7 @@ there is no CPU fallback."""
 from .pix2world import (error, fit_scene, fit_scene_sparse, gd_func_dict, get_C_Theta_from_X,  # noqa: F401
                         get_X_from_C_Theta, transform, validate_scene_parameters)
 from .fit_loop import SceneFit  # noqa: F401
-from . import engine, scenes, sharding, tracks  # noqa: F401
+from .subscenes import fit_subscenes_GD  # noqa: F401
+from . import engine, scenes, sharding, subscenes, tracks  # noqa: F401
 
 __version__ = '0.1.0'

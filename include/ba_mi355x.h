@@ -239,6 +239,24 @@ int ba_project(int64_t N, int64_t K, int64_t n, const int32_t *i, const int32_t 
 int ba_reprojection_error(int64_t n, const int32_t *pix_xy, const double *model, double *sums,
                           void *stream);
 
+/* ---- joint alignment of subscenes by gradient descent (fit_subscenes_GD, p2w:729-949) on the present entries.
+ * Input of the reference: X[N][P][3], NaN where subscene j does not hold point i.  Here: the present entries
+ * sorted by point: row_ptr[N+1], entry_subscene[n], entry_x[n][3].  params = [S (P) | T (3P) | Psi (3P)].
+ * ba_subscenes_eval (p2w:813-818, 848-849, 886-924): sums[1 + 7P] = [sum of squared differences | dE/dS |
+ *   dE/dT | dE/dPsi], without the reference's factors 1/(2n) and 2/n; table_work: 40 P doubles of scratch.
+ * ba_subscenes_step (p2w:926-937): SGD (rule 1) or Adam (rule 2; moments s, r of 7P doubles each, bc = 1 - rho^t)
+ *   with the gradient 2/n x sums, then the gauge of the reference (subscene 0 becomes the identity); writes
+ *   new buffers, the inputs stay valid (a rejected step is dropped by the caller).
+ * ba_subscenes_transform (p2w:943-944): x_new[n][3] = S_j R_j x + T_j for every entry. */
+int ba_subscenes_eval(int64_t N, int64_t P, const int64_t *row_ptr, const int32_t *entry_subscene,
+                      const double *entry_x, const double *params, double *table_work, double *sums,
+                      void *stream);
+int ba_subscenes_step(int64_t P, int rule, double lr, double bc1, double bc2, double n_entries,
+                      const double *sums, const double *params, double *params_out, const double *s_in,
+                      double *s_out, const double *r_in, double *r_out, void *stream);
+int ba_subscenes_transform(int64_t P, int64_t n_entries, const int32_t *entry_subscene, const double *entry_x,
+                           const double *params, double *table_work, double *x_new, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -686,3 +686,132 @@ def resect_obs(i, j, uv, K, X, phi_x, W, H, normalize=False, use_gram=None):
         Rm = Rm * np.sign(np.linalg.det(Rm))
         Theta[cam] = get_rotations(Rm[None])[0]
     return C, Theta
+
+
+# --------------------------------------------------------------------------- #
+# joint alignment of subscenes  (fit_subscenes_GD, p2w:729-949)
+# --------------------------------------------------------------------------- #
+def subscene_entries(X):
+    """Present entries of X (N, P, 3) (p2w:754: first coordinate not NaN) in C order:
+    (i int32[n], j int32[n], x float64[n, 3])."""
+    X = np.asarray(X, dtype=np.float64)
+    present = ~np.isnan(X[:, :, 0])
+    i, j = np.nonzero(present)
+    return i.astype(np.int32), j.astype(np.int32), np.ascontiguousarray(X[present])
+
+
+def subscenes_forward(i, j, x, N, S, T, R):
+    """`inner_transform` of fit_subscenes_GD on the present entries (p2w:813-818):
+    x_rot = R_j x, x_new = S_j x_rot + T_j, diff = x_new - mean over the point's entries."""
+    x_rot = np.einsum('nkl,nl->nk', R[j], x)
+    x_new = S[j][:, None] * x_rot + T[j]
+    cnt = np.bincount(i, minlength=N).astype(np.float64)
+    with np.errstate(invalid='ignore', divide='ignore'):
+        mean = _segment_sum(i, x_new, N) / cnt[:, None]
+    return x_new - mean[i], x_rot, x_new
+
+
+def subscenes_energy_and_gradients(i, j, x, N, P, S, T, Psi, R=None, factors=None):
+    """Energy (p2w:848-849) and the three gradients as the reference forms them (p2w:886-924;
+    note its factor 2/NP against 1/(2 NP) in the energy).  `factors` = (Rx, Ry, Rz)."""
+    if factors is None:
+        factors = rx(Psi[:, 0]), ry(Psi[:, 1]), rz(Psi[:, 2])
+    if R is None:
+        R = factors[1] @ factors[0] @ factors[2]
+    n = float(len(i))
+    diff, x_rot, _ = subscenes_forward(i, j, x, N, S, T, R)
+    E = float(np.dot(diff.ravel(), diff.ravel()) / (2.0 * n))
+    cnt = np.bincount(i, minlength=N).astype(np.float64)
+    with np.errstate(invalid='ignore', divide='ignore'):
+        dc = diff - (_segment_sum(i, diff, N) / cnt[:, None])[i]          # p2w:886
+    gS = 2.0 / n * np.bincount(j, weights=np.einsum('nk,nk->n', dc, x_rot), minlength=P)      # p2w:888
+    gT = 2.0 / n * _segment_sum(j, dc, P)                                                      # p2w:890
+    D = _d_R_d_theta(*factors)                                                                 # p2w:905-919
+    d_rot = np.einsum('nkml,nm->nkl', D[j], x)                                                 # p2w:921-922
+    gPsi = 2.0 / n * _segment_sum(j, np.einsum('nk,nkl->nl', dc, d_rot) * S[j][:, None], P)    # p2w:923-924
+    return E, gS, gT, gPsi
+
+
+def subscenes_gauge(S, T, Psi):
+    """Subscene 0 becomes the identity similarity (p2w:932-937).  Returns S, T, Psi, R."""
+    R = ryxz(Psi)
+    T = (T - T[0]) @ R[0] / S[0]
+    R = R[0].T @ R
+    Psi = get_rotations(R)
+    S = np.abs(S)
+    S = S / S[0]
+    return S, T, Psi, R
+
+
+def fit_subscenes(X, lr, max_iters, S_0=None, T_0=None, Psi_0=None, optimizer='Adam', patience=1000,
+                  factor=2.0, stop_value=0.0, stop_diff=1e-12, ret_all_iters=False, log=None, trace=None):
+    """fit_subscenes_GD (p2w:729-949) on the present entries only.  Returns what the reference
+    returns: [X_new (N, P, 3), S, T, Psi, E[:iters+1]] (+ per-iteration copies).  `trace`, when a
+    list, receives (iters, S, T, Psi, gS, gT, gPsi) before every update."""
+    X = np.asarray(X, dtype=np.float64)
+    N, P = X.shape[:2]
+    i, j, x = subscene_entries(X)
+    S = np.ones(P) if S_0 is None else np.array(S_0, dtype=np.float64).ravel().copy()
+    T = np.zeros((P, 3)) if T_0 is None else np.array(T_0, dtype=np.float64).copy()
+    Psi = np.zeros((P, 3)) if Psi_0 is None else np.array(Psi_0, dtype=np.float64).copy()
+    params = {'S': {'main': S}, 'T': {'main': T}, 'Psi': {'main': Psi}}
+    form_params_dict(params, optimizer, ret_all_iters, max_iters)
+    n = float(len(i))
+
+    def evaluate(R=None):
+        """inner_transform with calc_Rs=True unless R is given (p2w:793-820)."""
+        factors = None
+        if R is None:
+            factors = rx(Psi[:, 0]), ry(Psi[:, 1]), rz(Psi[:, 2])
+            R = factors[1] @ factors[0] @ factors[2]
+        diff, _, _ = subscenes_forward(i, j, x, N, S, T, R)
+        return float(np.dot(diff.ravel(), diff.ravel()) / (2.0 * n)), R, factors
+
+    E = np.zeros(max_iters)
+    E_min = E_min_temp = np.inf
+    patience_timer, success_timer = 0, patience
+    began_decreasing = increased = False
+    iters, R = 0, None
+    while iters < max_iters:
+        first = iters == 0
+        E[iters], R_now, factors = evaluate(None if first else R)
+        if first:
+            R = R_now
+        state, redo = lr_manager(lr, iters, E, E_min, E_min_temp, patience_timer, success_timer,
+                                 began_decreasing, increased, patience, factor, params, ret_all_iters,
+                                 recompute=lambda: evaluate(None), log=log)
+        lr, iters, E_min, E_min_temp, patience_timer, success_timer, began_decreasing, increased = state
+        if lr == 0.0:
+            break
+        if stop_diff > 0.0 and iters > 2 * patience:
+            d = E[:iters - 2 * patience].min() - E_min
+            if 0.0 < d < stop_diff:
+                break
+        if E[iters] < stop_value:
+            break
+        if iters == max_iters - 1:
+            break
+        if redo:
+            _, R, factors = redo[0]
+        if factors is None:                                             # p2w:892-903
+            factors = camera_rotation_tables(R=R, Theta_for_sign=Psi)
+        _, gS, gT, gPsi = subscenes_energy_and_gradients(i, j, x, N, P, S, T, Psi, R=R, factors=factors)
+        if trace is not None:
+            trace.append((iters, S.copy(), T.copy(), Psi.copy(), gS, gT, gPsi))
+        for name, g in (('S', gS), ('T', gT), ('Psi', gPsi)):           # p2w:926-930
+            val = params[name]
+            new, state_new = GD_FUNCS[optimizer](val['main'], g, lr, **val['gd'])
+            val['main'][:] = new
+            for key, v in state_new.items():
+                val['gd'][key][:] = v
+        S[:], T[:], Psi[:], R = subscenes_gauge(S, T, Psi)
+        iters += 1
+
+    R_fin = ryxz(Psi)
+    _, _, x_new = subscenes_forward(i, j, x, N, S, T, R_fin)
+    X_new = np.full((N, P, 3), np.nan)
+    X_new[i, j] = x_new
+    out = [X_new, S, T, Psi, E[:iters + 1]]
+    if ret_all_iters:
+        out.extend([np.array(params[k]['all_iters']) for k in ('S', 'T', 'Psi')])
+    return out

@@ -366,6 +366,79 @@ def capture_f7(out):
     save_npz(os.path.join(out, 'f7_linear_init.npz'), **arrays)
 
 
+def make_subscenes(N, P, seed, present_frac=0.7, noise=0.01):
+    """P noisy copies of one point cloud, each in its own similarity frame, with missing entries
+    (the input of p2w:729: X (N, P, 3), NaN where a subscene does not hold a point)."""
+    rng = np.random.default_rng(seed)
+    X_true = rng.normal(0, 2.0, (N, 3))
+    S = np.exp(rng.normal(0, 0.3, P))
+    Psi = rng.normal(0, 0.4, (P, 3))
+    T = rng.normal(0, 1.0, (P, 3))
+    S[0], Psi[0], T[0] = 1.0, 0.0, 0.0
+    R = p.ryxz(Psi)
+    # subscene j holds x_ij with  S_j R_j x_ij + T_j = X_i (+ noise)
+    X = np.einsum('jlk,ijl->ijk', R, (X_true[:, None, :] - T[None]) / S[None, :, None])
+    X = X + rng.normal(0, noise, X.shape)
+    X[rng.random((N, P)) > present_frac] = np.nan
+    return X, S, T, Psi
+
+
+def run_reference_subscenes(X, lr, max_iters, optimizer='Adam', **kw):
+    """p.fit_subscenes_GD with the recording hook in the optimiser registry (groups S, T, Psi)."""
+    names, cur, steps = ['S', 'T', 'Psi'], {}, []
+    orig_update = p.gd_func_dict[optimizer]
+
+    def rec_update(x, grad, lr_, **state):
+        name = names[len(cur)]
+        cur[name] = (np.array(x, dtype=np.float64).copy(), np.array(grad, dtype=np.float64).copy())
+        if len(cur) == len(names):
+            steps.append(dict(cur))
+            cur.clear()
+        return orig_update(x, grad, lr_, **state)
+
+    p.gd_func_dict[optimizer] = rec_update
+    out = io.StringIO()
+    try:
+        with contextlib.redirect_stdout(out):
+            ret = p.fit_subscenes_GD(X, lr, max_iters, optimizer=optimizer, **kw)
+    finally:
+        p.gd_func_dict[optimizer] = orig_update
+    res = {'X_new': ret[0], 'final_S': ret[1], 'final_T': ret[2], 'final_Psi': ret[3], 'E': ret[4],
+           'log': out.getvalue().splitlines()}
+    for n in names:
+        res['step_' + n] = np.array([s[n][0] for s in steps])
+        res['grad_' + n] = np.array([s[n][1] for s in steps])
+    return res
+
+
+def capture_f8(out):
+    """fit_subscenes_GD (p2w:729-949): Adam and SGD from the default start, Adam from a given start,
+    and a run with a short patience so that the schedule raises and lowers the learning rate (cut at 56
+    iterations: a little later the run sits at its optimum, the schedule compares energies that are
+    equal up to rounding, and its decisions stop being reproducible by any other summation order)."""
+    import warnings
+    X, S, T, Psi = make_subscenes(90, 6, seed=31)
+    arrays = dict(X=X, S_true=S, T_true=T, Psi_true=Psi)
+    rng = np.random.default_rng(32)
+    S0 = S * np.exp(rng.normal(0, 0.05, S.shape))
+    T0 = T + rng.normal(0, 0.1, T.shape)
+    P0 = Psi + rng.normal(0, 0.05, Psi.shape)
+    arrays.update(S_0=S0, T_0=T0, Psi_0=P0)
+    runs = dict(adam=dict(lr=1e-2, max_iters=40, optimizer='Adam'),
+                sgd=dict(lr=1e-2, max_iters=40, optimizer='SGD'),
+                start=dict(lr=1e-3, max_iters=300, optimizer='Adam', S_0=S0, T_0=T0, Psi_0=P0),
+                events=dict(lr=2e-3, max_iters=56, optimizer='Adam', S_0=S0, T_0=T0, Psi_0=P0, patience=12))
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for tag, kw in runs.items():
+            kw = dict(kw)
+            res = run_reference_subscenes(X, kw.pop('lr'), kw.pop('max_iters'), **kw)
+            for k, v in res.items():
+                arrays[f'{tag}_{k}'] = v
+            print(tag, 'E0', res['E'][0], 'E_last', res['E'][-1], 'log lines', len(res['log']))
+    save_npz(os.path.join(out, 'f8_subscenes.npz'), **arrays)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden'))
@@ -373,7 +446,7 @@ def main():
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     todo = dict(f1=capture_f1, f2=capture_f2, f3=capture_f3, f4=capture_f4, f5=capture_f5,
-                f6=capture_f6, f7=capture_f7)
+                f6=capture_f6, f7=capture_f7, f8=capture_f8)
     for name, fn in todo.items():
         if a.only and name not in a.only.split(','):
             continue

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, rel_err
+from conftest import GOLDEN, logs_match, rel_err
 from oracle import ba_oracle as orc
 
 TOL = 1e-9       # per-iteration energy / gradient contract (relative, max-norm)
@@ -254,3 +254,53 @@ def test_c_oracle_matches_golden_and_numpy_oracle(golden):
     it = c_oracle.Iterator(i, j, uv, g['free__X_0'], g['C_0'], g['Theta_0'], float(g['phi_x_0']), W, H, 1e-3)
     E = np.array([it.step() for _ in range(60)])
     assert rel_err(E, g['free__E'][:60]) < 1e-9
+
+
+# ---- F8: joint alignment of subscenes (p2w:729-949) ----------------------------------------------
+F8_RUNS = dict(adam=dict(lr=1e-2, max_iters=40, optimizer='Adam'),
+               sgd=dict(lr=1e-2, max_iters=40, optimizer='SGD'),
+               start=dict(lr=1e-3, max_iters=300, optimizer='Adam', start=True),
+               events=dict(lr=2e-3, max_iters=56, optimizer='Adam', start=True, patience=12))
+
+
+def f8_kwargs(g, tag):
+    kw = dict(F8_RUNS[tag])
+    if kw.pop('start', False):
+        kw.update(S_0=g['S_0'], T_0=g['T_0'], Psi_0=g['Psi_0'])
+    return kw
+
+
+def test_f8_subscene_gradients_teacher_forced(golden):
+    """Energy and the three gradients at the reference's own iterates."""
+    g = golden('f8_subscenes.npz')
+    X = g['X']
+    N, P = X.shape[:2]
+    i, j, x = orc.subscene_entries(X)
+    for tag in ('adam', 'sgd', 'start'):
+        S_, T_, Psi_ = g[f'{tag}_step_S'], g[f'{tag}_step_T'], g[f'{tag}_step_Psi']
+        for t in range(0, S_.shape[0], 7):
+            E, gS, gT, gPsi = orc.subscenes_energy_and_gradients(i, j, x, N, P, S_[t], T_[t], Psi_[t])
+            assert abs(E - g[f'{tag}_E'][t]) <= 1e-12 * g[f'{tag}_E'][t]
+            assert rel_err(gS, g[f'{tag}_grad_S'][t]) < 1e-11
+            assert rel_err(gT, g[f'{tag}_grad_T'][t]) < 1e-11
+            assert rel_err(gPsi, g[f'{tag}_grad_Psi'][t]) < 1e-11
+
+
+@pytest.mark.parametrize('tag', list(F8_RUNS))
+def test_f8_subscene_runs(golden, tag):
+    """Free runs: energies, every update's parameters and gradients, the event log and the results."""
+    g = golden('f8_subscenes.npz')
+    kw = f8_kwargs(g, tag)
+    log, trace = [], []
+    out = orc.fit_subscenes(g['X'], kw.pop('lr'), kw.pop('max_iters'), log=log, trace=trace, **kw)
+    E_ref = g[f'{tag}_E']
+    assert out[4].shape == E_ref.shape
+    assert rel_err(out[4], E_ref) < 1e-9
+    assert len(trace) == g[f'{tag}_step_S'].shape[0]
+    for name, k in (('S', 1), ('T', 2), ('Psi', 3)):
+        got = np.array([t[k] for t in trace]).reshape(g[f'{tag}_step_{name}'].shape)
+        assert np.abs(got - g[f'{tag}_step_{name}']).max() < 1e-9
+        assert np.abs(out[k].reshape(g[f'{tag}_final_{name}'].shape) - g[f'{tag}_final_{name}']).max() < 1e-9
+    np.testing.assert_allclose(out[0], g[f'{tag}_X_new'], rtol=0, atol=1e-9, equal_nan=True)
+    events = [ln for ln in g[f'{tag}_log'].tolist() if 'LR to' in ln]
+    assert logs_match(log, events)
