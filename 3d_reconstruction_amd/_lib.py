@@ -61,6 +61,7 @@ SIGNATURES = {
     'ba_gauge_fix': (_int, [_i64, _i64, _p, _p, _p, _p, _p, _p]),
     'ba_project': (_int, [_i64, _i64, _i64, _p, _p, _p, _p, _p, _dbl, _dbl, _dbl, _int, _int, _p, _p]),
     'ba_reprojection_error': (_int, [_i64, _p, _p, _p, _p]),
+    'ba_homography_diff_matrix': (_int, [_i64, _p, _p, _p, _dbl, _dbl, _int, _int, _p, _p]),
     'ba_subscenes_eval': (_int, [_i64, _i64] + [_p] * 7),
     'ba_subscenes_step': (_int, [_i64, _int, _dbl, _dbl, _dbl, _dbl] + [_p] * 8),
     'ba_subscenes_transform': (_int, [_i64, _i64] + [_p] * 6),

@@ -544,3 +544,23 @@ def resect(oi, oj, uv, K, X, phi_x, W, H, normalize=False, device='cuda:0'):
         check(lib.ba_resect(N, K, ptr(col_ptr), ptr(oi_s), ptr(uv_s), ptr(Xd), float(phi_x), float(W), float(H),
                             int(bool(normalize)), max(2 * N0, 12), ptr(C_out), ptr(T_out), stream_ptr()))
     return C_out, T_out
+
+
+def homography_diff_matrix(oi, oj, uv, N, K, normalize=False, W=None, H=None, min_common=10, device='cuda:0'):
+    """Homography misfit of every camera pair with at least `min_common` common points
+    (ba_homography_diff_matrix; get_H_diff_matrix, p2w:1945-1995): device tensor (K, K), NaN elsewhere.
+    `uv` are pixel centres; the observations may come in any order."""
+    lib = _lib.load()
+    dev = torch.device(device)
+    oi = _dev_tensor(oi, torch.int32, dev)
+    oj = _dev_tensor(oj, torch.int32, dev)
+    uv = _dev_tensor(uv, F64, dev).view(-1, 2)
+    order = torch.argsort(oj.to(torch.int64) * int(N) + oi.to(torch.int64))       # by camera, points ascending
+    oj_s = oj[order]
+    col_ptr, _ = _ranges(oj_s, K)
+    oi_s, uv_s = oi[order].contiguous(), uv[order].contiguous()
+    out = torch.empty((K, K), dtype=F64, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.ba_homography_diff_matrix(K, ptr(col_ptr), ptr(oi_s), ptr(uv_s), float(W or 0.0), float(H or 0.0),
+                                            int(bool(normalize)), int(min_common), ptr(out), stream_ptr()))
+    return out

@@ -20,7 +20,8 @@ from .fit_loop import SceneFit, extra_optimizers, gd_func_dict  # noqa: F401  (g
 from .lm import LMFit
 from .sharding import partition_points, connected_components_count
 
-__all__ = ['fit_scene', 'fit_scene_sparse', 'transform', 'error', 'validate_scene_parameters', 'gd_func_dict']
+__all__ = ['fit_scene', 'fit_scene_sparse', 'transform', 'error', 'validate_scene_parameters', 'gd_func_dict',
+           'get_X_from_C_Theta', 'get_C_Theta_from_X', 'get_H_diff_matrix']
 
 
 # --------------------------------------------------------------------------------------------- #
@@ -284,3 +285,18 @@ def get_C_Theta_from_X(X_pix, X, phi_x, W, H, normalize=False, _validate=True, d
         import warnings
         warnings.warn('Unable to solve the problem for any camera, too little valuable information', RuntimeWarning)
     return C, Theta
+
+
+def get_H_diff_matrix(X_pix, normalize=False, W=None, H=None, _validate=True, device=None):
+    """Mean squared transfer error of the best homography between every pair of cameras with at
+    least 10 common points (p2w:1945-1995): (K, K), symmetric, NaN for the other pairs and on the
+    diagonal.  A large value means parallax between the two views."""
+    if _validate:
+        N, K = validate_scene_parameters(X_pix=X_pix, ret_shapes=True)
+        if normalize and (W is None or H is None):
+            raise ValueError('With normalize = True W and H have to be passed')
+    else:
+        N, K = X_pix.shape[:-1]
+    dev = torch.device(device) if device is not None else _default_device()
+    oi, oj, uv, _ = engine.visibility_coo(np.asarray(X_pix), dev)
+    return engine.homography_diff_matrix(oi, oj, uv, N, K, normalize, W, H, 10, dev).cpu().numpy()

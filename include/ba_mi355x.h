@@ -239,6 +239,16 @@ int ba_project(int64_t N, int64_t K, int64_t n, const int32_t *i, const int32_t 
 int ba_reprojection_error(int64_t n, const int32_t *pix_xy, const double *model, double *sums,
                           void *stream);
 
+/* ---- get_H_diff_matrix (p2w:1945-1995): for every pair of cameras with at least min_common (reference: 10)
+ * common points, the homography between the two views by DLT (p2w:1976-1987) and the mean squared transfer
+ * error of the common points (p2w:1989-1993) -> H_diff[K][K], symmetric, NaN for all other pairs and the
+ * diagonal.  Observations sorted by camera, points ascending within a camera: col_ptr[K+1], oi_by_camera[n],
+ * uv_by_camera[n][2] (pixel centres); normalize: centres -> (centre - (W, H)/2) / max(W, H) (p2w:1963-1964).
+ * K <= 65535. */
+int ba_homography_diff_matrix(int64_t K, const int64_t *col_ptr, const int32_t *oi_by_camera,
+                              const double *uv_by_camera, double W, double H, int normalize, int min_common,
+                              double *H_diff, void *stream);
+
 /* ---- joint alignment of subscenes by gradient descent (fit_subscenes_GD, p2w:729-949) on the present entries.
  * Input of the reference: X[N][P][3], NaN where subscene j does not hold point i.  Here: the present entries
  * sorted by point: row_ptr[N+1], entry_subscene[n], entry_x[n][3].  params = [S (P) | T (3P) | Psi (3P)].

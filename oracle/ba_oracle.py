@@ -815,3 +815,45 @@ def fit_subscenes(X, lr, max_iters, S_0=None, T_0=None, Psi_0=None, optimizer='A
     if ret_all_iters:
         out.extend([np.array(params[k]['all_iters']) for k in ('S', 'T', 'Psi')])
     return out
+
+
+# --------------------------------------------------------------------------- #
+# homography misfit of every camera pair  (get_H_diff_matrix, p2w:1945-1995)
+# --------------------------------------------------------------------------- #
+def h_diff_matrix_obs(i, j, uv, K, normalize=False, W=None, H=None, use_gram=None):
+    """For every pair of cameras with at least 10 common points (p2w:1973-1974): homography by DLT
+    from the rows (-x1, 0, u2 x1), (0, -x1, v2 x1) (p2w:1976-1979), h = right singular vector of the
+    smallest singular value (SVD below 50 points, smallest eigenpair of A^T A through ARPACK from
+    there on, p2w:1981-1986; use_gram forces one of the two), and the mean squared transfer error of
+    the common points (p2w:1989-1993).  NaN elsewhere.  `uv` are pixel centres (X_pix + 0.5)."""
+    from scipy.sparse.linalg import eigsh
+    c = np.asarray(uv, dtype=np.float64)
+    if normalize:
+        c = (c - 0.5 * np.array([W, H])) / max(W, H)              # p2w:1963-1964
+    out = np.full((K, K), np.nan)
+    pts = [dict() for _ in range(K)]
+    for e, (pi, cj) in enumerate(zip(np.asarray(i).tolist(), np.asarray(j).tolist())):
+        pts[cj][pi] = e
+    for j1 in range(K):
+        for j2 in range(j1 + 1, K):
+            common = sorted(pts[j1].keys() & pts[j2].keys())
+            n = len(common)
+            if n < 10:
+                continue
+            x1 = np.ones((n, 3))
+            x1[:, :2] = c[[pts[j1][q] for q in common]]
+            x2 = c[[pts[j2][q] for q in common]]
+            A = np.zeros((2 * n, 9))
+            A[0::2, 0:3] = A[1::2, 3:6] = -x1
+            A[0::2, 6:9] = x2[:, 0:1] * x1
+            A[1::2, 6:9] = x2[:, 1:2] * x1
+            gram = (n >= 50) if use_gram is None else use_gram
+            if gram:
+                _, h = eigsh(A.T @ A, k=1, which='SM', v0=np.eye(3).ravel())
+            else:
+                h = np.linalg.svd(A)[2][-1]
+            y = x1 @ h.reshape(3, 3).T
+            y = y / y[:, [2]]
+            d = (x2 - y[:, :2]).ravel()
+            out[j1, j2] = out[j2, j1] = np.dot(d, d) / n
+    return out

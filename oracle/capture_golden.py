@@ -439,6 +439,25 @@ def capture_f8(out):
     save_npz(os.path.join(out, 'f8_subscenes.npz'), **arrays)
 
 
+def capture_f9(out):
+    """get_H_diff_matrix (p2w:1945-1995) on a sparse scene: pairs with fewer than 10 common points,
+    with 10..49 (SVD branch) and with 50 or more (ARPACK branch), both pixel normalisations."""
+    sc = make_scene(260, 10, seed=41, vis_frac=0.6)
+    X_pix = sc['X_pix'].copy()
+    X_pix[40:, 7] = -1                  # a camera with few points
+    X_pix[8:, 8] = -1                   # ... and one with fewer than 10
+    X_pix[:130, 9] = -1
+    vis = X_pix[:, :, 0] >= 0
+    ii, jj = np.nonzero(vis)
+    common = vis.T.astype(int) @ vis.astype(int)
+    print('common points per pair: min', common.min(), 'max', common.max())
+    arrays = dict(N=260, K=10, W=sc['W'], H=sc['H'], obs_i=ii.astype(np.int32), obs_j=jj.astype(np.int32),
+                  obs_xy=X_pix[vis].astype(np.int32), common=common)
+    arrays['H_diff_pix'] = p.get_H_diff_matrix(X_pix)
+    arrays['H_diff_norm'] = p.get_H_diff_matrix(X_pix, normalize=True, W=sc['W'], H=sc['H'])
+    save_npz(os.path.join(out, 'f9_h_diff.npz'), **arrays)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden'))
@@ -446,7 +465,7 @@ def main():
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     todo = dict(f1=capture_f1, f2=capture_f2, f3=capture_f3, f4=capture_f4, f5=capture_f5,
-                f6=capture_f6, f7=capture_f7, f8=capture_f8)
+                f6=capture_f6, f7=capture_f7, f8=capture_f8, f9=capture_f9)
     for name, fn in todo.items():
         if a.only and name not in a.only.split(','):
             continue

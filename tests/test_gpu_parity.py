@@ -520,3 +520,48 @@ def test_full_size_invariants(ba):
     sh.eval()
     assert abs(sh.energy() - E1) / E1 < 1e-9
     sh.close()
+
+
+# ---- get_H_diff_matrix (p2w:1945-1995) ---------------------------------------------------------------
+def test_h_diff_matrix_matches_reference(ba, golden):
+    """Against the reference's own matrices.  Normalised pixels: 1e-9 everywhere.  Raw pixels: the
+    columns of the DLT matrix then differ by six orders of magnitude and every solution that goes
+    through A^T A loses digits: the reference's own ARPACK branch (50 common points and more) sits
+    1.4e-6 from the SVD of the same rows; the device (Jacobi on A^T A) stays within 1e-6 of the SVD
+    form of the oracle on every pair and of the reference's SVD branch, and within 1e-5 of its
+    ARPACK branch."""
+    g = golden('f9_h_diff.npz')
+    X_pix = _dense_from_coo(g)
+    W, H = float(g['W']), float(g['H'])
+    small = g['common'] < 50
+    uv = g['obs_xy'] + 0.5
+    for tag, kw in (('pix', dict()), ('norm', dict(normalize=True, W=W, H=H))):
+        tol = TOL if tag == 'norm' else 1e-6
+        ref = g['H_diff_' + tag]
+        got = ba.get_H_diff_matrix(X_pix, **kw)
+        assert np.array_equal(np.isnan(got), np.isnan(ref))
+        ok = ~np.isnan(ref)
+        assert np.array_equal(got, got.T, equal_nan=True)
+        rel = np.where(ok, np.abs(got - ref) / np.where(ok, ref, 1.0), 0.0)
+        assert rel[small].max() < tol
+        assert rel.max() < (TOL if tag == 'norm' else 1e-5)
+        svd = orc.h_diff_matrix_obs(g['obs_i'], g['obs_j'], uv, int(g['K']), bool(kw), W, H, use_gram=False)
+        assert (np.abs(got - svd)[ok] <= tol * svd[ok]).all()
+    with pytest.raises(ValueError, match='W and H have to be passed'):
+        ba.get_H_diff_matrix(X_pix, normalize=True)
+
+
+def test_h_diff_matrix_video_tracks_vs_oracle(ba):
+    """Track-shaped visibility (a point is seen by a window of consecutive cameras), observations
+    handed over in random order; against the SVD form of the oracle (normalised pixels 1e-9; raw
+    pixels 1e-5: some pairs here are close to degenerate, values up to 1e8)."""
+    sc = ba.scenes.orbit_scene(1500, 40, track_len=8, seed=5)
+    rng = np.random.default_rng(0)
+    perm = rng.permutation(sc['i'].size)
+    for kw, tol in ((dict(), 1e-5), (dict(normalize=True, W=sc['W'], H=sc['H']), TOL)):
+        got = ba.engine.homography_diff_matrix(sc['i'][perm], sc['j'][perm], sc['uv'][perm], sc['N'], sc['K'],
+                                               device=DEV, **kw).cpu().numpy()
+        ref = orc.h_diff_matrix_obs(sc['i'], sc['j'], sc['uv'], sc['K'], use_gram=False, **kw)
+        assert np.array_equal(np.isnan(got), np.isnan(ref)) and (~np.isnan(ref)).sum() > 100
+        ok = ~np.isnan(ref)
+        assert (np.abs(got - ref)[ok] <= tol * ref[ok]).all()

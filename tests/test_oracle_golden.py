@@ -304,3 +304,16 @@ def test_f8_subscene_runs(golden, tag):
     np.testing.assert_allclose(out[0], g[f'{tag}_X_new'], rtol=0, atol=1e-9, equal_nan=True)
     events = [ln for ln in g[f'{tag}_log'].tolist() if 'LR to' in ln]
     assert logs_match(log, events)
+
+
+# ---- F9: homography misfit of the camera pairs (p2w:1945-1995) -------------------------------------
+def test_f9_h_diff_matrix(golden):
+    g = golden('f9_h_diff.npz')
+    uv = g['obs_xy'] + 0.5
+    W, H = float(g['W']), float(g['H'])
+    for tag, norm in (('pix', False), ('norm', True)):
+        ref = g['H_diff_' + tag]
+        got = orc.h_diff_matrix_obs(g['obs_i'], g['obs_j'], uv, int(g['K']), norm, W, H)
+        assert np.array_equal(np.isnan(got), np.isnan(ref))
+        ok = ~np.isnan(ref)
+        assert (np.abs(got - ref)[ok] <= 1e-9 * ref[ok]).all()
