@@ -78,7 +78,7 @@ struct RunArgs {
     int K = 0;
     int cam_cap = 0;              // LDS capacity in cameras (max over tiles)
     int pt_stride = 0;            // S: LDS capacity in points is 8 * S
-    int cam_rep = 1;              // copies of the camera accumulators (power of two)
+    int cam_rep = 1;              // copies of the camera accumulators the LDS space is sized for (at cam_cap cameras)
     const double *X = nullptr;
     const double *X_gauge = nullptr;    // optional: the true points are ((X - C0) @ R0) * factor of this record
                               // (R0 row-major [0..8], C0 [9..11], factor [12]); applied while loading
@@ -149,10 +149,13 @@ __global__ void __launch_bounds__(TILE_BLOCK, sizeof(typename Rec::raw_t) <= 8 ?
     }
 
     constexpr int PREC = pt_record_doubles(NPV);                // doubles of a point's LDS record
-    const int rep = a.cam_rep, S = a.pt_stride;
+    // copies of the camera accumulators: the space is sized for cam_cap cameras x cam_rep copies; a tile with fewer
+    // cameras spreads its flushes over as many copies as fit (copy = round mod rep, by multiply and shift)
+    const int rep = min(15, (a.cam_cap * a.cam_rep) / nc), rep_inv = (256 + rep - 1) / rep;
+    const int S = a.pt_stride;
     double *rows = lds;                                         // cam_cap x ROW_LDS
     double *cacc = rows + (size_t)a.cam_cap * ROW_LDS;          // rep x NCVL x nc (component-major, used sums only)
-    double *pts = cacc + (size_t)a.cam_cap * NCVL * rep;         // 8 S records of PREC doubles: x (3), sums (NPV)
+    double *pts = cacc + (size_t)a.cam_cap * NCVL * a.cam_rep;         // 8 S records of PREC doubles: x (3), sums (NPV)
 
     for (int idx = tid; idx < nc * (ROW_LDS / 2); idx += TILE_BLOCK) {
         const int row = idx / (ROW_LDS / 2), piece = idx - row * (ROW_LDS / 2);
@@ -227,7 +230,7 @@ __global__ void __launch_bounds__(TILE_BLOCK, sizeof(typename Rec::raw_t) <= 8 ?
                 __hip_atomic_fetch_add(pt_cur + 3 + v, pv[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __builtin_amdgcn_sched_barrier(0);     // keep the eight bodies apart: their live ranges add up otherwise
         }
-        double *acc = cacc + (size_t)(round & (rep - 1)) * NCVL * nc + slot;
+        double *acc = cacc + (size_t)(round - rep * ((round * rep_inv) >> 8)) * NCVL * nc + slot;
 #pragma unroll
         for (int k = 0; k < NCV; ++k)
             if (Op::cv_used(k))

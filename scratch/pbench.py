@@ -3,6 +3,8 @@ fit loop) and J^T J pass; median kernel time from the library's HIP events."""
 import importlib, sys, os, numpy as np, torch
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '.'))
 ba = importlib.import_module('3d_reconstruction_amd')
+if os.environ.get('BA_LIB'):      # an experimental build of the library (timing only)
+    importlib.import_module('3d_reconstruction_amd._lib').LIB_PATH = os.path.abspath(os.environ['BA_LIB'])
 sc = ba.scenes.orbit_scene(N=1_000_000, K=2000, track_len=10, seed=0)
 N, K = sc['N_local'], sc['K']
 nv = sc['i'].size
