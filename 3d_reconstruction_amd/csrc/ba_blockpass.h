@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(256, Op::WAVES_PER_EU) k_block_pass(BlockArgs 
 #pragma unroll
         for (int k = 0; k < NCV; ++k) {
             if (!Op::cv_used(k)) continue;
-            double v = cv[k];
+            double v = op.cv_flush(k, cv[k]);
             v += row_shr<1>(v);
             v += row_shr<2>(v);
             v += row_shr<4>(v);

@@ -750,8 +750,13 @@ struct GradOp {
     __host__ __device__ static constexpr int cv_lds(int k) { return k; }
     __host__ __device__ static constexpr int cv_from_lds(int c) { return c; }
     double f, pcx, pcy;
-    __device__ explicit GradOp(const double *scalars) : f(scalars[SC_F]), pcx(scalars[SC_CX]), pcy(scalars[SC_CY]) {}
-    // cv: camera-frame force (3) and torque (3); pv: world-frame dE/dX_i part; part: r.r, m.r
+    __device__ explicit GradOp(const double *scalars, double pix_shift = 0.0)
+        : f(scalars[SC_F]), pcx(scalars[SC_CX] - pix_shift), pcy(scalars[SC_CY] - pix_shift) {}
+    // the torque sums are kept without their common factor: q x a = f (m0, m1, 1) x (r0, r1, -m.r) exactly,
+    // because a = (f / q2) (r0, r1, -m.r) and q = q2 (m0, m1, 1)
+    __device__ __forceinline__ double cv_flush(int k, double v) const { return k < 3 ? v : (k == 3 ? -f * v : f * v); }
+    // cv: camera-frame force (3) and torque / f (3; the first one negated); pv: world-frame dE/dX_i part;
+    // part: r.r, m.r.  uv: pixel centre minus the shift given to the constructor
     __device__ __forceinline__ void obs(bool valid, const double (&x)[3], const double2 (&rw)[6], double2 uv,
                                         double (&cv)[6], double (&pv)[3], double (&part)[2]) const {
         const double R00 = rw[0].x, R01 = rw[0].y, R02 = rw[1].x, R10 = rw[1].y, R11 = rw[2].x, R12 = rw[2].y,
@@ -762,10 +767,10 @@ struct GradOp {
         const double q2 = R02 * d0 + R12 * d1 + R22 * d2;
         const double inv = fast_rcp(q2);
         const double m0 = q0 * inv, m1 = q1 * inv;
-        const double r0 = valid ? f * m0 + pcx - uv.x : 0.0;
-        const double r1 = valid ? f * m1 + pcy - uv.y : 0.0;
-        part[0] += r0 * r0 + r1 * r1;
-        const double mr = m0 * r0 + m1 * r1;
+        const double r0 = valid ? fma(f, m0, pcx - uv.x) : 0.0;
+        const double r1 = valid ? fma(f, m1, pcy - uv.y) : 0.0;
+        part[0] = fma(r0, r0, fma(r1, r1, part[0]));
+        const double mr = fma(m0, r0, m1 * r1);
         part[1] += mr;
         const double fi = f * inv;
         const double a0 = fi * r0, a1 = fi * r1, a2 = -fi * mr;
@@ -775,9 +780,9 @@ struct GradOp {
         cv[0] += a0;
         cv[1] += a1;
         cv[2] += a2;
-        cv[3] += q1 * a2 - q2 * a1;
-        cv[4] += q2 * a0 - q0 * a2;
-        cv[5] += q0 * a1 - q1 * a0;
+        cv[3] = fma(m1, mr, cv[3] + r1);
+        cv[4] = fma(m0, mr, cv[4] + r0);
+        cv[5] = fma(m0, r1, fma(-m1, r0, cv[5]));
     }
 };
 

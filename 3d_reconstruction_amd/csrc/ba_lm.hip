@@ -66,8 +66,8 @@ __device__ __forceinline__ ObsJac obs_jacobian(const double *x, const double2 *r
     const double inv = valid ? fast_rcp(o.q2) : 0.0;
     o.m0 = o.q0 * inv;
     o.m1 = o.q1 * inv;
-    o.r0 = f * o.m0 + pcx - uv.x;
-    o.r1 = f * o.m1 + pcy - uv.y;
+    o.r0 = fma(f, o.m0, pcx - uv.x);
+    o.r1 = fma(f, o.m1, pcy - uv.y);
     const double fi = f * inv;
     o.fi = fi;
     o.jx0[0] = fi * (R00 - o.m0 * R02);
@@ -238,7 +238,9 @@ struct JtjOp {
     __host__ __device__ static constexpr int cv_lds(int k) { return k < 7 ? k : (k < 12 ? k - 1 : k - 2); }
     __host__ __device__ static constexpr int cv_from_lds(int c) { return c < 7 ? c : (c < 11 ? c + 1 : c + 2); }
     double f, pcx, pcy;
-    __device__ explicit JtjOp(const double *scalars) : f(scalars[SC_F]), pcx(scalars[SC_CX]), pcy(scalars[SC_CY]) {}
+    __device__ explicit JtjOp(const double *scalars, double pix_shift = 0.0)
+        : f(scalars[SC_F]), pcx(scalars[SC_CX] - pix_shift), pcy(scalars[SC_CY] - pix_shift) {}
+    __device__ __forceinline__ double cv_flush(int, double v) const { return v; }
     // Sums of products are written as chains of fused multiply-adds into the accumulator (two
     // instructions per two-term product instead of multiply, multiply-add, add).
     __device__ __forceinline__ void obs(bool valid, const double (&x)[3], const double2 (&rw)[6], double2 uv,

@@ -57,6 +57,10 @@ struct RecF64 {
     static __device__ __forceinline__ uint32_t pack(const raw_t &r) { return r.pack; }
     static __device__ __forceinline__ bool valid(const raw_t &r) { return r.uv.x == r.uv.x; }
     static __device__ __forceinline__ double2 uv(const raw_t &r) { return r.uv; }
+    // pixel centre minus PIX_SHIFT in both components: what the pass hands to the Op, which folds the shift into
+    // its principal-point constants
+    static constexpr double PIX_SHIFT = 0.0;
+    static __device__ __forceinline__ double2 pix(const raw_t &r) { return r.uv; }
 };
 struct RecI16 {
     typedef uint2 raw_t;    // x: pack, y: pixel x (low half) and y (high half) as int16
@@ -65,6 +69,10 @@ struct RecI16 {
     static __device__ __forceinline__ bool valid(const raw_t &r) { return (r.y & 0xffffu) != 0x8000u; }
     static __device__ __forceinline__ double2 uv(const raw_t &r) {
         return make_double2((double)(int)(short)(r.y & 0xffffu) + 0.5, (double)((int)r.y >> 16) + 0.5);
+    }
+    static constexpr double PIX_SHIFT = 0.5;      // the integer pixel itself: no addition per record
+    static __device__ __forceinline__ double2 pix(const raw_t &r) {
+        return make_double2((double)(int)(short)(r.y & 0xffffu), (double)((int)r.y >> 16));
     }
 };
 
@@ -116,7 +124,8 @@ __host__ __device__ inline size_t run_pass_lds_doubles(int cam_cap, int pt_strid
     return run_pass_lds_doubles(Op::NCV_LDS, Op::NPV, cam_cap, pt_stride, rep);
 }
 
-// Op supplies:  Op(scalars), WAVES_PER_EU / WAVES_PER_EU_COMPACT (register budget with long / 8-byte records),
+// Op supplies:  Op(scalars, pix_shift) (pix_shift: what the records' pixels lack to the pixel centre), cv_flush(k, v)
+//   (the value camera sum k contributes when a run's sums are flushed: constant factors left out of obs()), WAVES_PER_EU / WAVES_PER_EU_COMPACT (register budget with long / 8-byte records),
 //   cv_used(k) (false: camera sum k is never accumulated and is not flushed), NCV_LDS (number of used sums),
 //   cv_lds(k) / cv_from_lds(c) (position of sum k among the used ones and back; the LDS accumulators hold only
 //   those: with 160 KB of LDS per CU in granules of 1280 bytes, three workgroups fit if each stays within 53 760
@@ -186,7 +195,7 @@ __global__ void __launch_bounds__(TILE_BLOCK, sizeof(typename Rec::raw_t) <= 8 ?
             for (int v = 0; v < NPV; ++v) rec_pt[3 + v] = 0.0;
         }
     }
-    const Op op(a.scalars);
+    const Op op(a.scalars, Rec::PIX_SHIFT);
     __syncthreads();
 
     double part[NPART];
@@ -214,7 +223,7 @@ __global__ void __launch_bounds__(TILE_BLOCK, sizeof(typename Rec::raw_t) <= 8 ?
             double *pt_cur = pt_next;
             const double x[3] = {xn[0], xn[1], xn[2]};
             const bool valid = Rec::valid(rec[k]);
-            const double2 uv = Rec::uv(rec[k]);
+            const double2 uv = Rec::pix(rec[k]);
             if (k + 1 < RUN_LEN) {      // the next observation's point, ahead of this observation's atomics
                 pt_next = pts + pt_swz((int)(Rec::pack(rec[k + 1]) >> 16), S) * PREC;
                 xn[0] = pt_next[0];
@@ -234,7 +243,8 @@ __global__ void __launch_bounds__(TILE_BLOCK, sizeof(typename Rec::raw_t) <= 8 ?
 #pragma unroll
         for (int k = 0; k < NCV; ++k)
             if (Op::cv_used(k))
-                __hip_atomic_fetch_add(acc + Op::cv_lds(k) * nc, cv[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(acc + Op::cv_lds(k) * nc, op.cv_flush(k, cv[k]), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 
 #pragma unroll
