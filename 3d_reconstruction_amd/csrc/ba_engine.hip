@@ -2612,8 +2612,8 @@ static UpdateRule make_rule(int mode, double lr, double gscale, double bc1, doub
     u.mode = mode;
     u.lr = lr;
     u.gscale = gscale;
-    u.bc1 = bc1;
-    u.bc2 = bc2;
+    u.ibc1 = 1.0 / bc1;
+    u.ibc2 = 1.0 / bc2;
     return u;
 }
 

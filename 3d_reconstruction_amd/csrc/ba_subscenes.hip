@@ -242,8 +242,8 @@ int ba_subscenes_step(int64_t P, int rule, double lr, double bc1, double bc2, do
     u.mode = rule;
     u.lr = lr;
     u.gscale = 2.0 / n_entries;        // p2w:888, 890, 923
-    u.bc1 = bc1;
-    u.bc2 = bc2;
+    u.ibc1 = 1.0 / bc1;
+    u.ibc2 = 1.0 / bc2;
     hipLaunchKernelGGL(k_subscene_step, dim3(1), dim3(256), 0, (hipStream_t)stream, P, u, sums, params, params_out, s_in,
                        s_out, r_in, r_out);
     BA_HIP(hipGetLastError());
