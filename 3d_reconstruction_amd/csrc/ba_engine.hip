@@ -2252,8 +2252,8 @@ int ba_problem_create(int64_t N, int64_t K, int64_t nV, const int32_t *i, const 
     BA_REQUIRE(out, "ba_problem_create: null out pointer");
     *out = nullptr;
     BA_REQUIRE(N > 0 && K > 0 && nV > 0, "ba_problem_create: N, K and nV must be positive");
-    BA_REQUIRE(nV < (1ll << 31) - 64 && N < (1ll << 31) && K < (1ll << 31) / 8,
-               "ba_problem_create: shard too large for 32-bit indices");
+    BA_REQUIRE(nV < (1ll << 31) - 64 && N < (1ll << 31) / 3 && K < (1ll << 31) / 8,
+               "ba_problem_create: shard too large for 32-bit indices (3 N, 8 K and nV must stay below 2^31)");
     BA_REQUIRE(i && j && uv, "ba_problem_create: null observation array");
     BA_HIP(hipSetDevice(device));
     ba_problem *p = new ba_problem();

@@ -259,16 +259,19 @@ __global__ void __launch_bounds__(TILE_BLOCK, sizeof(typename Rec::raw_t) <= 8 ?
     // next tile's first point (zeros)
     const int lo = tm.wlo - p0, hi = tm.whi - p0;
     if (a.upd.mode) {
-        for (int64_t gi = 3 * (int64_t)tm.wlo + tid; gi < 3 * (int64_t)tm.whi; gi += TILE_BLOCK) {
-            const int64_t gpt = gi / 3;
-            const int comp = (int)(gi - 3 * gpt), pt = (int)(gpt - p0);
+        // component li of the tile's write range (32-bit index arithmetic: the loop runs 3 x points / 256 times)
+        const int n_comp = 3 * (tm.whi - tm.wlo);
+        const int64_t g0 = 3 * (int64_t)tm.wlo;
+        for (int li = tid; li < n_comp; li += TILE_BLOCK) {
+            const int lpt = li / 3, comp = li - 3 * lpt, pt = lpt + lo;
+            const int64_t gi = g0 + li;
             double x, g = 0.0;
             if (pt >= 0 && pt < np) {
                 const double *rec_pt = pts + pt_swz(pt, S) * PREC;
                 x = rec_pt[comp];
                 g = rec_pt[3 + comp];     // the gradient is the first slice of the per-point sums
             } else if (a.X_gauge) {   // a point nobody observes: only the stored value changes frame
-                const double *G = a.X_gauge, *xp = a.X + 3 * gpt;
+                const double *G = a.X_gauge, *xp = a.X + (gi - comp);
                 x = ((xp[0] - G[9]) * G[comp] + (xp[1] - G[10]) * G[3 + comp] + (xp[2] - G[11]) * G[6 + comp]) * G[12];
             } else {
                 x = a.X[gi];
