@@ -814,7 +814,7 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_run_count(const uint32_t *__rest
 __global__ void __launch_bounds__(TILE_BLOCK) k_run_fill(const uint32_t *__restrict__ opack,
                                                          const double2 *__restrict__ ouv,
                                                          const TileMeta *__restrict__ meta,
-                                                         const int64_t *__restrict__ run_ptr, int cam_cap,
+                                                         const int64_t *__restrict__ run_ptr, int cam_cap, int pt_stride,
                                                          uint32_t *__restrict__ rpack, double2 *__restrict__ ruv,
                                                          uint2 *__restrict__ rrec) {
     extern __shared__ int sm[];
@@ -853,19 +853,20 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_run_fill(const uint32_t *__restr
             return pos;
         };
         int q = 0, rho = -1, run = 0;
-        uint32_t first_pk = 0;
+        uint32_t first_word = 0;
         for (int e = 0; e < n; ++e) {
             const uint32_t pk = spack[e];
             if ((int)(pk & 0xffffu) != c) continue;
             if ((q % RUN_LEN) == 0) {
                 ++rho;
                 run = run_index(rho);
-                first_pk = pk;
             }
             const int plane = ((q % RUN_LEN) - c) & (RUN_LEN - 1);
             const int64_t idx = rb * RUN_LEN + (int64_t)plane * nruns + run;
-            const uint32_t word = (pk & 0xffff0000u) | ((uint32_t)(rho & 15) << RUN_SLOT_BITS) | (uint32_t)c;
+            // the point's position in the LDS record array (pt_swz), so that the pass needs no index arithmetic
+            const uint32_t word = ((uint32_t)pt_swz((int)(pk >> 16), pt_stride) << 16) | ((uint32_t)(rho & 15) << RUN_SLOT_BITS) | (uint32_t)c;
             const double2 uv = ouv[tm.e0 + e];
+            if ((q % RUN_LEN) == 0) first_word = word;
             if (rrec) {
                 const int px = (int)(uv.x - 0.5), py = (int)(uv.y - 0.5);
                 rrec[idx] = make_uint2(word, ((uint32_t)px & 0xffffu) | ((uint32_t)py << 16));
@@ -879,7 +880,7 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_run_fill(const uint32_t *__restr
         for (; my_runs > 0 && q < my_runs * RUN_LEN; ++q) {
             const int plane = ((q % RUN_LEN) - c) & (RUN_LEN - 1);
             const int64_t idx = rb * RUN_LEN + (int64_t)plane * nruns + run;
-            const uint32_t word = (first_pk & 0xffff0000u) | ((uint32_t)(rho & 15) << RUN_SLOT_BITS) | (uint32_t)c;
+            const uint32_t word = (first_word & 0xffff0000u) | ((uint32_t)(rho & 15) << RUN_SLOT_BITS) | (uint32_t)c;
             if (rrec) {
                 rrec[idx] = make_uint2(word, 0x8000u);
             } else {
@@ -1996,7 +1997,7 @@ static int build_runs(ba_problem *p) {
     hipFree(tile_sums);
     BA_HIP(e);
     const size_t fill_lds = sizeof(int) * ((size_t)p->cam_cap + (p->cam_cap + 7) / 8 + 1) + sizeof(uint32_t) * (size_t)h_max_obs;
-    if (fill_lds > 64 * 1024 || p->total_runs == 0 || p->cam_cap > RUN_MAX_CAMS) {   // leave the point-major tiles in charge
+    if (fill_lds > 64 * 1024 || p->total_runs == 0 || p->cam_cap > RUN_MAX_CAMS || p->pt_cap > 65000) {   // leave the point-major tiles in charge
         hipFree(p->run_ptr);
         p->run_ptr = nullptr;
         p->total_runs = 0;
@@ -2009,11 +2010,11 @@ static int build_runs(ba_problem *p) {
         BA_HIP(hipMalloc(&p->rpack, sizeof(uint32_t) * n_rec));
         BA_HIP(hipMalloc(&p->ruv, sizeof(double2) * n_rec));
     }
-    hipLaunchKernelGGL(k_run_fill, dim3(nt), dim3(TILE_BLOCK), fill_lds, 0, p->opack, p->ouv,
-                       (const TileMeta *)p->tile_meta, p->run_ptr, p->cam_cap, p->rpack, p->ruv, p->rrec);
-    BA_HIP(hipGetLastError());
     p->run_pt_stride = (p->pt_cap + 7) / 8;
     while ((p->run_pt_stride & 3) != 2) ++p->run_pt_stride;   // 2 * odd, see pt_swz
+    hipLaunchKernelGGL(k_run_fill, dim3(nt), dim3(TILE_BLOCK), fill_lds, 0, p->opack, p->ouv,
+                       (const TileMeta *)p->tile_meta, p->run_ptr, p->cam_cap, p->run_pt_stride, p->rpack, p->ruv, p->rrec);
+    BA_HIP(hipGetLastError());
     // copies of the camera accumulators: as many as keep the workgroup near a quarter of the LDS budget
     const size_t budget = 64 * 1024;
     auto pick_rep = [&](int ncv, int npv, int cam_cap, size_t limit, const char *env_name) {

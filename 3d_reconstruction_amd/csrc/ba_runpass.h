@@ -40,7 +40,7 @@
 namespace ba {
 
 constexpr int RUN_LEN = 8;
-constexpr int RUN_SLOT_BITS = 12;    // record: point << 16 | (round & 15) << 12 | camera slot
+constexpr int RUN_SLOT_BITS = 12;    // record: pt_swz(point in tile) << 16 | (round & 15) << 12 | camera slot
 constexpr int RUN_MAX_CAMS = 1 << RUN_SLOT_BITS;
 
 // Two record formats.  RecF64: the pack word and the pixel centre as two doubles (20 bytes).
@@ -77,7 +77,7 @@ struct RecI16 {
 };
 
 struct RunArgs {
-    const uint32_t *rpack = nullptr;    // RecF64: (point index - tile's first point) << 16 | (round & 15) << 12 | camera slot
+    const uint32_t *rpack = nullptr;    // RecF64: pt_swz(point index - tile's first point) << 16 | (round & 15) << 12 | camera slot
     const double2 *ruv = nullptr;       // RecF64: pixel centre
     const uint2 *rrec = nullptr;        // RecI16 records
     const int64_t *run_ptr = nullptr;   // n_tiles + 1: first run of every tile
@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(TILE_BLOCK, sizeof(typename Rec::raw_t) <= 8 ?
         double cv[NCV];
 #pragma unroll
         for (int k = 0; k < NCV; ++k) cv[k] = 0.0;
-        double *pt_next = pts + pt_swz((int)(Rec::pack(rec[0]) >> 16), S) * PREC;
+        double *pt_next = pts + (Rec::pack(rec[0]) >> 16) * PREC;
         double xn[3] = {pt_next[0], pt_next[1], pt_next[2]};
 #pragma unroll
         for (int k = 0; k < RUN_LEN; ++k) {
@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(TILE_BLOCK, sizeof(typename Rec::raw_t) <= 8 ?
             const bool valid = Rec::valid(rec[k]);
             const double2 uv = Rec::pix(rec[k]);
             if (k + 1 < RUN_LEN) {      // the next observation's point, ahead of this observation's atomics
-                pt_next = pts + pt_swz((int)(Rec::pack(rec[k + 1]) >> 16), S) * PREC;
+                pt_next = pts + (Rec::pack(rec[k + 1]) >> 16) * PREC;
                 xn[0] = pt_next[0];
                 xn[1] = pt_next[1];
                 xn[2] = pt_next[2];
