@@ -115,10 +115,9 @@ __global__ void __launch_bounds__(256, Op::WAVES_PER_EU) k_block_pass(BlockArgs 
     double *rows = lds;                                   // cam_cap x ROW_LDS
     double *pts = rows + (size_t)a.cam_cap * ROW_LDS;     // 8 S records of PREC doubles
 
-    for (int idx = tid; idx < nc * (ROW_LDS / 2); idx += nthr) {
-        const int row = idx / (ROW_LDS / 2), piece = idx - row * (ROW_LDS / 2);
+    for (int row = tid; row < nc; row += nthr) {
         const int j = tm.j0 >= 0 ? tm.j0 + row : a.cam_list[cb + row];
-        ((double2 *)rows)[idx] = ((const double2 *)(a.T + (int64_t)j * CAM_ROW))[piece];
+        stage_camera_row_rt(a.T + (int64_t)j * CAM_ROW, rows + row * ROW_LDS);
     }
     // every point slot of the tile's chunks: x (zero past the tile's last point: such slots only
     // meet zero-weight records, which need finite coordinates) and zeroed sums

@@ -761,10 +761,10 @@ struct GradOp {
                                         double (&cv)[6], double (&pv)[3], double (&part)[2]) const {
         const double R00 = rw[0].x, R01 = rw[0].y, R02 = rw[1].x, R10 = rw[1].y, R11 = rw[2].x, R12 = rw[2].y,
                      R20 = rw[3].x, R21 = rw[3].y, R22 = rw[4].x;
-        const double d0 = x[0] - rw[4].y, d1 = x[1] - rw[5].x, d2 = x[2] - rw[5].y;
-        const double q0 = R00 * d0 + R10 * d1 + R20 * d2;
-        const double q1 = R01 * d0 + R11 * d1 + R21 * d2;
-        const double q2 = R02 * d0 + R12 * d1 + R22 * d2;
+        // rw[4].y, rw[5]: t = -R^T C (stage_camera_row_rt), q = R^T x + t
+        const double q0 = fma(R00, x[0], fma(R10, x[1], fma(R20, x[2], rw[4].y)));
+        const double q1 = fma(R01, x[0], fma(R11, x[1], fma(R21, x[2], rw[5].x)));
+        const double q2 = fma(R02, x[0], fma(R12, x[1], fma(R22, x[2], rw[5].y)));
         const double inv = fast_rcp(q2);
         const double m0 = q0 * inv, m1 = q1 * inv;
         const double r0 = valid ? fma(f, m0, pcx - uv.x) : 0.0;

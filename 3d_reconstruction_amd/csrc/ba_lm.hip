@@ -53,16 +53,24 @@ struct ObsJac {
 
 // valid = false (a zero-weight record, any point / camera pair): every Jacobian entry and m come out
 // as zero (they carry the factor 1 / q2, which is replaced by 0)
+// ROW_T: the last three entries of the row are t = -R^T C (stage_camera_row_rt) instead of C
+template <bool ROW_T = false>
 __device__ __forceinline__ ObsJac obs_jacobian(const double *x, const double2 *rw, double f, double pcx, double pcy,
                                                double2 uv, bool valid = true) {
     const double2 t0 = rw[0], t1 = rw[1], t2 = rw[2], t3 = rw[3], t4 = rw[4], t5 = rw[5];
     const double R00 = t0.x, R01 = t0.y, R02 = t1.x, R10 = t1.y, R11 = t2.x, R12 = t2.y, R20 = t3.x, R21 = t3.y,
                  R22 = t4.x;
     ObsJac o;
-    const double d0 = x[0] - t4.y, d1 = x[1] - t5.x, d2 = x[2] - t5.y;
-    o.q0 = R00 * d0 + R10 * d1 + R20 * d2;
-    o.q1 = R01 * d0 + R11 * d1 + R21 * d2;
-    o.q2 = R02 * d0 + R12 * d1 + R22 * d2;
+    if (ROW_T) {
+        o.q0 = fma(R00, x[0], fma(R10, x[1], fma(R20, x[2], t4.y)));
+        o.q1 = fma(R01, x[0], fma(R11, x[1], fma(R21, x[2], t5.x)));
+        o.q2 = fma(R02, x[0], fma(R12, x[1], fma(R22, x[2], t5.y)));
+    } else {
+        const double d0 = x[0] - t4.y, d1 = x[1] - t5.x, d2 = x[2] - t5.y;
+        o.q0 = R00 * d0 + R10 * d1 + R20 * d2;
+        o.q1 = R01 * d0 + R11 * d1 + R21 * d2;
+        o.q2 = R02 * d0 + R12 * d1 + R22 * d2;
+    }
     const double inv = valid ? fast_rcp(o.q2) : 0.0;
     o.m0 = o.q0 * inv;
     o.m1 = o.q1 * inv;
@@ -245,7 +253,7 @@ struct JtjOp {
     // instructions per two-term product instead of multiply, multiply-add, add).
     __device__ __forceinline__ void obs(bool valid, const double (&x)[3], const double2 (&rw)[6], double2 uv,
                                         double (&cv)[CAMV], double (&pv)[PTV], double (&part)[3]) const {
-        const ObsJac o = obs_jacobian(x, rw, f, pcx, pcy, uv, valid);
+        const ObsJac o = obs_jacobian<true>(x, rw, f, pcx, pcy, uv, valid);
         const double r0 = valid ? o.r0 : 0.0, r1 = valid ? o.r1 : 0.0;
         part[0] = fma(r0, r0, fma(r1, r1, part[0]));
         part[1] = fma(o.m0, r0, fma(o.m1, r1, part[1]));

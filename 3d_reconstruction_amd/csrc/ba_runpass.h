@@ -166,10 +166,9 @@ __global__ void __launch_bounds__(TILE_BLOCK, sizeof(typename Rec::raw_t) <= 8 ?
     double *cacc = rows + (size_t)a.cam_cap * ROW_LDS;          // rep x NCVL x nc (component-major, used sums only)
     double *pts = cacc + (size_t)a.cam_cap * NCVL * a.cam_rep;         // 8 S records of PREC doubles: x (3), sums (NPV)
 
-    for (int idx = tid; idx < nc * (ROW_LDS / 2); idx += TILE_BLOCK) {
-        const int row = idx / (ROW_LDS / 2), piece = idx - row * (ROW_LDS / 2);
+    for (int row = tid; row < nc; row += TILE_BLOCK) {
         const int j = tm.j0 >= 0 ? tm.j0 + row : a.cam_list[cb + row];
-        ((double2 *)rows)[idx] = ((const double2 *)(a.T + (int64_t)j * CAM_ROW))[piece];
+        stage_camera_row_rt(a.T + (int64_t)j * CAM_ROW, rows + row * ROW_LDS);
     }
     for (int idx = tid; idx < NCVL * nc * rep; idx += TILE_BLOCK) cacc[idx] = 0.0;
     {
