@@ -1602,6 +1602,7 @@ __global__ void __launch_bounds__(256) k_camera_step_quad(CameraStep a, CameraSt
     const int64_t jj = j < K ? j : 0;
     const int cc = comp < 3 ? comp : 0;
 
+    const double dphi_old = (FINALIZE && blockIdx.x == 0) ? a.scalars[SC_DPHI] : 0.0;
     if (FINALIZE && blockIdx.x == 0) {
         double e = 0.0, ps = 0.0;
         const double2 *pp = (const double2 *)fz.partials;
@@ -1621,12 +1622,39 @@ __global__ void __launch_bounds__(256) k_camera_step_quad(CameraStep a, CameraSt
         if (tid == 0) {
             const double e_sum = (red_e[0][0] + red_e[0][1]) + (red_e[0][2] + red_e[0][3]);
             fz.g_out[6 * K + 1] = e_sum;
-            fz.g_out[6 * K] = a.scalars[SC_DPHI] * ((red_e[1][0] + red_e[1][1]) + (red_e[1][2] + red_e[1][3]));
+            fz.g_out[6 * K] = dphi_old * ((red_e[1][0] + red_e[1][1]) + (red_e[1][2] + red_e[1][3]));
             if (fz.mailbox) {
                 fz.mailbox[0] = e_sum;
                 __threadfence_system();
                 fz.mailbox[1] = fz.seq;
             }
+        }
+    }
+    // phi_x and the scalars that depend on it: one thread of workgroup 0, off the tail of the kernel (nothing
+    // else in this launch reads them; the old d f / d phi factor was read above)
+    if (blockIdx.x == 0 && tid == 64) {
+        const int64_t t = 6 * K;
+        double ph = a.cam_in[t];
+        if (a.rule.mode && t >= a.lo && t < a.hi) {
+            double sv = 0.0, rv = 0.0;
+            if (a.rule.mode == 2) {
+                sv = a.s_in[t];
+                rv = a.r_in[t];
+            }
+            const double gphi = FINALIZE ? dphi_old * ((red_e[1][0] + red_e[1][1]) + (red_e[1][2] + red_e[1][3])) : a.g[t];
+            ph = apply_rule(a.rule, ph, gphi, &sv, &rv);
+            if (a.rule.mode == 2) {
+                a.s[t] = sv;
+                a.r[t] = rv;
+            }
+        }
+        a.cam[t] = ph;
+        if (a.scalars) {
+            const double f = a.W / 2.0 / tan(ph / 2.0);
+            a.scalars[SC_F] = f;
+            a.scalars[SC_CX] = a.W / 2.0;
+            a.scalars[SC_CY] = a.H / 2.0;
+            a.scalars[SC_DPHI] = -f / sin(ph);
         }
     }
 
@@ -1641,6 +1669,10 @@ __global__ void __launch_bounds__(256) k_camera_step_quad(CameraStep a, CameraSt
         if (own || stage0) {
             fz.g_out[3 * jj + cc] = gc;
             fz.g_out[3 * K + 3 * jj + cc] = gt;
+        }
+        if (own) {      // the sums are consumed: leave them at zero for the next pass (camera 0: in the tail)
+            fz.cam_sums[cc * K + jj] = 0.0;
+            fz.cam_sums[(3 + cc) * K + jj] = 0.0;
         }
     } else {
         gc = a.g ? a.g[3 * jj + cc] : 0.0;
@@ -1793,6 +1825,14 @@ __global__ void __launch_bounds__(256) k_camera_step_quad(CameraStep a, CameraSt
     __syncthreads();
     // every load below is issued before its first use: the caches were just invalidated, and a
     // chain of dependent misses is what this tail costs
+    // first batch of the centres to be scaled below: requested together with the workgroups' maxima
+    const int n3 = (int)(3 * K);
+    double v[24];
+#pragma unroll
+    for (int u = 0; u < 24; ++u) {
+        const int idx = 3 + u * 256 + tid;
+        v[u] = idx < n3 ? a.cam[idx] : 0.0;
+    }
     double bv = -1.0;
     long long bj = K;
     for (int b = tid; b < (int)gridDim.x; b += 256) {
@@ -1861,49 +1901,27 @@ __global__ void __launch_bounds__(256) k_camera_step_quad(CameraStep a, CameraSt
             }
         }
     }
-    if (tid == 64) {  // phi_x and the scalars that depend on it
-        const int64_t t = 6 * K;
-        double ph = a.cam_in[t];
-        if (a.rule.mode && t >= a.lo && t < a.hi) {
-            double sv = 0.0, rv = 0.0;
-            if (a.rule.mode == 2) {
-                sv = a.s_in[t];
-                rv = a.r_in[t];
-            }
-            ph = apply_rule(a.rule, ph, FINALIZE ? fz.g_out[t] : a.g[t], &sv, &rv);
-            if (a.rule.mode == 2) {
-                a.s[t] = sv;
-                a.r[t] = rv;
-            }
-        }
-        a.cam[t] = ph;
-        if (a.scalars) {
-            const double f = a.W / 2.0 / tan(ph / 2.0);
-            a.scalars[SC_F] = f;
-            a.scalars[SC_CX] = a.W / 2.0;
-            a.scalars[SC_CY] = a.H / 2.0;
-            a.scalars[SC_DPHI] = -f / sin(ph);
-        }
-    }
-    if (FINALIZE) {
-        for (int64_t idx = tid; idx < 6 * K; idx += 256) fz.cam_sums[idx] = 0.0;
-    }
+    if (FINALIZE && tid >= 96 && tid < 102) fz.cam_sums[(tid - 96) * K] = 0.0;     // camera 0 (read by every workgroup)
     __syncthreads();
+    // scale of the centres: 24 loads per thread in flight at once (the caches were just invalidated, so a batch
+    // costs a round trip to memory; K = 2000 is one batch, the one requested above)
     const double factor = s_factor;
-    for (int64_t base = 3; base < 3 * K; base += 8 * 256) {
-        double v[8];
+    for (int base = 3; base < n3; base += 24 * 256) {
+        if (base > 3) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int64_t idx = base + u * 256 + tid;
-            v[u] = idx < 3 * K ? a.cam[idx] : 0.0;
+            for (int u = 0; u < 24; ++u) {
+                const int idx = base + u * 256 + tid;
+                v[u] = idx < n3 ? a.cam[idx] : 0.0;
+            }
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int64_t idx = base + u * 256 + tid;
-            if (idx < 3 * K) {
+        for (int u = 0; u < 24; ++u) {
+            const int idx = base + u * 256 + tid;
+            if (idx < n3) {
                 const double c = v[u] * factor;
                 a.cam[idx] = c;
-                if (a.T) a.T[(idx / 3) * CAM_ROW + 9 + (idx % 3)] = c;
+                const int jc = idx / 3;
+                if (a.T) a.T[(int64_t)jc * CAM_ROW + 9 + (idx - 3 * jc)] = c;
             }
         }
     }
