@@ -1602,15 +1602,52 @@ __global__ void __launch_bounds__(256) k_camera_step_quad(CameraStep a, CameraSt
     const int64_t jj = j < K ? j : 0;
     const int cc = comp < 3 ? comp : 0;
 
+    // ---- everything this lane reads, requested before workgroup 0 adds up the partial sums (one trip to memory
+    // on its path instead of two: the last ticket is drawn when the slowest workgroup arrives)
+    double in_sums[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, in_row[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (FINALIZE) {
+        const double *row = a.T + jj * CAM_ROW;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) in_sums[k] = fz.cam_sums[k * K + jj];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            in_row[k] = row[3 * cc + k];
+            in_row[3 + k] = row[3 + k];
+        }
+        in_row[6] = row[12];
+        in_row[7] = row[13];
+    }
+    double in_x[2], in_s[2] = {0.0, 0.0}, in_r[2] = {0.0, 0.0}, in_g[2] = {0.0, 0.0};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int64_t t = (h == 0 ? 0 : 3 * K) + 3 * jj + cc;
+        in_x[h] = a.cam_in[t];
+        if (a.rule.mode == 2 && t >= a.lo && t < a.hi) {
+            in_s[h] = a.s_in[t];
+            in_r[h] = a.r_in[t];
+        }
+        if (!FINALIZE && a.g) in_g[h] = a.g[t];
+    }
+
     const double dphi_old = (FINALIZE && blockIdx.x == 0) ? a.scalars[SC_DPHI] : 0.0;
     if (FINALIZE && blockIdx.x == 0) {
         double e = 0.0, ps = 0.0;
         const double2 *pp = (const double2 *)fz.partials;
-        for (int t = tid; t < fz.n_partials; t += 256) {
-            const double2 v = pp[t];
-            e += v.x;
-            ps += v.y;
-            if (t >= fz.n_own) ((double2 *)fz.partials)[t] = make_double2(0.0, 0.0);
+        // 12 loads per thread in flight (a load per loop trip would cost a trip to memory each)
+        for (int t0 = 0; t0 < fz.n_partials; t0 += 12 * 256) {
+            double2 v[12];
+#pragma unroll
+            for (int u = 0; u < 12; ++u) {
+                const int t = t0 + u * 256 + tid;
+                v[u] = t < fz.n_partials ? pp[t] : make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int u = 0; u < 12; ++u) {
+                const int t = t0 + u * 256 + tid;
+                e += v[u].x;
+                ps += v[u].y;
+                if (t >= fz.n_own && t < fz.n_partials) ((double2 *)fz.partials)[t] = make_double2(0.0, 0.0);
+            }
         }
         e = wave_sum(e);
         ps = wave_sum(ps);
@@ -1661,11 +1698,9 @@ __global__ void __launch_bounds__(256) k_camera_step_quad(CameraStep a, CameraSt
     // ---- un-normalised gradient of C[comp], Theta[comp] of this quad's camera
     double gc, gt;
     if (FINALIZE) {
-        const double *row = a.T + jj * CAM_ROW;
-        const double s0 = fz.cam_sums[0 * K + jj], s1 = fz.cam_sums[1 * K + jj], s2 = fz.cam_sums[2 * K + jj];
-        const double w0 = fz.cam_sums[3 * K + jj], w1 = fz.cam_sums[4 * K + jj], w2 = fz.cam_sums[5 * K + jj];
-        gc = -(row[3 * cc + 0] * s0 + row[3 * cc + 1] * s1 + row[3 * cc + 2] * s2);
-        gt = cc == 0 ? -(row[12] * w0 - row[13] * w1) : (cc == 1 ? -(row[3] * w0 + row[4] * w1 + row[5] * w2) : -w2);
+        const double s0 = in_sums[0], s1 = in_sums[1], s2 = in_sums[2], w0 = in_sums[3], w1 = in_sums[4], w2 = in_sums[5];
+        gc = -(in_row[0] * s0 + in_row[1] * s1 + in_row[2] * s2);
+        gt = cc == 0 ? -(in_row[6] * w0 - in_row[7] * w1) : (cc == 1 ? -(in_row[3] * w0 + in_row[4] * w1 + in_row[5] * w2) : -w2);
         if (own || stage0) {
             fz.g_out[3 * jj + cc] = gc;
             fz.g_out[3 * K + 3 * jj + cc] = gt;
@@ -1675,8 +1710,8 @@ __global__ void __launch_bounds__(256) k_camera_step_quad(CameraStep a, CameraSt
             fz.cam_sums[(3 + cc) * K + jj] = 0.0;
         }
     } else {
-        gc = a.g ? a.g[3 * jj + cc] : 0.0;
-        gt = a.g ? a.g[3 * K + 3 * jj + cc] : 0.0;
+        gc = in_g[0];
+        gt = in_g[1];
     }
 
     // ---- update rule (p2w:704-708) on the two parameters of this lane
@@ -1684,12 +1719,12 @@ __global__ void __launch_bounds__(256) k_camera_step_quad(CameraStep a, CameraSt
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int64_t t = (h == 0 ? 0 : 3 * K) + 3 * jj + cc;
-        const double xo = a.cam_in[t];
+        const double xo = in_x[h];
         double xn = xo;
         if (a.rule.mode && t >= a.lo && t < a.hi) {
             if (a.rule.mode == 2) {
-                snew[h] = a.s_in[t];
-                rnew[h] = a.r_in[t];
+                snew[h] = in_s[h];
+                rnew[h] = in_r[h];
             }
             xn = apply_rule(a.rule, xo, h == 0 ? gc : gt, &snew[h], &rnew[h]);
             if (own && a.rule.mode == 2) {
