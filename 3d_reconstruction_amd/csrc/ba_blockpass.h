@@ -64,7 +64,8 @@ struct BlockArgs {
     int cam_cap = 0;
     int pt_stride = 0;                  // S: LDS capacity in points is 8 * S
     const double *X = nullptr;
-    const double *T = nullptr;
+    const double *T = nullptr;          // camera table: rotations
+    const double *C = nullptr;          // camera centres (K x 3)
     const double *scalars = nullptr;
     double *out[3] = {nullptr, nullptr, nullptr};   // per-point outputs (see the Op), any may be null
     double *cam_sums = nullptr;         // Op::NCV x K, component-major, accumulated with atomics
@@ -117,7 +118,7 @@ __global__ void __launch_bounds__(256, Op::WAVES_PER_EU) k_block_pass(BlockArgs 
 
     for (int row = tid; row < nc; row += nthr) {
         const int j = tm.j0 >= 0 ? tm.j0 + row : a.cam_list[cb + row];
-        stage_camera_row_rt(a.T + (int64_t)j * CAM_ROW, rows + row * ROW_LDS);
+        stage_camera_row_rt(a.T + (int64_t)j * CAM_ROW, a.C + 3 * (int64_t)j, rows + row * ROW_LDS);
     }
     // every point slot of the tile's chunks: x (zero past the tile's last point: such slots only
     // meet zero-weight records, which need finite coordinates) and zeroed sums

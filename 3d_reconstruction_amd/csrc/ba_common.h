@@ -90,6 +90,8 @@ struct ba_problem {
     int blk_waves = 0;                // waves per workgroup of the block pass
     // scratch owned by the handle (device)
     double *cam_table = nullptr;  // K x CAM_ROW
+    int table_centres_stale = 0;  // the merged camera step left the centres of the rows unwritten: only the run
+                                  // pass (which takes the centres from C itself) may reuse the table as it is
     double *sum_block = nullptr;  // owned: [cam_sums | partials]
     double *cam_sums = nullptr;   // 6 x K camera-frame sums (SoA: component-major), zero between passes
     double *partials = nullptr;   // 2 per wave / tile, directly behind cam_sums

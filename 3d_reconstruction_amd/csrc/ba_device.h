@@ -98,12 +98,15 @@ constexpr int ROW_LDS = 12;  // doubles of a camera row kept in LDS: R (9), C (3
 
 // Camera row of the table -> LDS row [R (9) | t = -R^T C (3)] for the run / block passes, which then form
 // q = R^T (x - C) as R^T x + t: three instructions fewer per observation (one thread per row)
-__device__ __forceinline__ void stage_camera_row_rt(const double *__restrict__ src, double *__restrict__ dst) {
+// (the centre comes from the parameter vector, not from the row: the merged camera step leaves the rows' centres
+// to whoever needs them, see ba_problem::table_centres_stale)
+__device__ __forceinline__ void stage_camera_row_rt(const double *__restrict__ src, const double *__restrict__ centre,
+                                                    double *__restrict__ dst) {
     const double2 *s2 = (const double2 *)src;
     double2 v[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) v[k] = s2[k];
-    const double c0 = v[4].y, c1 = v[5].x, c2 = v[5].y;
+    for (int k = 0; k < 5; ++k) v[k] = s2[k];
+    const double c0 = centre[0], c1 = centre[1], c2 = centre[2];
     const double t0 = -(v[0].x * c0 + v[1].y * c1 + v[3].x * c2);   // column 0 of R: R00, R10, R20
     const double t1 = -(v[0].y * c0 + v[2].x * c1 + v[3].y * c2);
     const double t2 = -(v[1].x * c0 + v[2].y * c1 + v[4].x * c2);

@@ -1098,6 +1098,7 @@ struct CameraStep {
     int do_gauge;
     double W, H;
     double *T;            // camera table (K x CAM_ROW), may be null
+    int table_centres;    // 0: leave the centres of the rows unwritten (quad kernel only)
     double *scalars;      // may be null
     double *R_out;        // optional K x 9
     double *gauge;        // optional 16
@@ -1956,7 +1957,7 @@ __global__ void __launch_bounds__(256) k_camera_step_quad(CameraStep a, CameraSt
                 const double c = v[u] * factor;
                 a.cam[idx] = c;
                 const int jc = idx / 3;
-                if (a.T) a.T[(int64_t)jc * CAM_ROW + 9 + (idx - 3 * jc)] = c;
+                if (a.T && a.table_centres) a.T[(int64_t)jc * CAM_ROW + 9 + (idx - 3 * jc)] = c;
             }
         }
     }
@@ -2023,6 +2024,7 @@ static int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 using namespace ba;
 
 int ba::camera_table(ba_problem *p, const double *C, const double *Theta, const double *phi, hipStream_t st) {
+    p->table_centres_stale = 0;
     hipLaunchKernelGGL(k_camera_table, dim3(cdiv(p->K, 256)), dim3(256), 0, st, p->K, C, Theta, phi, p->W, p->H,
                        p->cam_table, p->scalars);
     BA_HIP(hipGetLastError());
@@ -2451,9 +2453,11 @@ static int eval_impl(ba_problem *p, const double *X, const double *C, const doub
     hipStream_t st = (hipStream_t)stream;
     const int64_t K = p->K;
 
-    if (!(flags & BA_EVAL_REUSE_TABLE))
-        hipLaunchKernelGGL(k_camera_table, dim3(cdiv(K, 256)), dim3(256), 0, st, K, C, Theta, phi, p->W, p->H,
-                           p->cam_table, p->scalars);
+    // a table whose rows lack the centres (merged camera step) serves the run pass only
+    const bool runs_expected = p->tiled && p->tiles_worth && p->run_ptr && ((flags >> 6) & 7) == 0 &&
+                               !(flags & (BA_EVAL_CAM_ATOMICS | BA_EVAL_UNTILED | BA_EVAL_POINT_MAJOR));
+    if (!(flags & BA_EVAL_REUSE_TABLE) || (p->table_centres_stale && !runs_expected))
+        if (int rc = camera_table(p, C, Theta, phi, st)) return rc;
     const bool want_gx = (flags & BA_EVAL_GRAD_X) != 0;
     const bool use_tiles = p->tiled && p->tiles_worth && !(flags & (BA_EVAL_CAM_ATOMICS | BA_EVAL_UNTILED));
     // the tiled pass writes every point's gradient itself; the wave-chunk pass only the observed ones
@@ -2507,6 +2511,7 @@ static int eval_impl(ba_problem *p, const double *X, const double *C, const doub
         ra.s_out = fu ? fu->s_out : nullptr;
         ra.r_out = fu ? fu->r_out : nullptr;
         ra.T = p->cam_table;
+        ra.C = C;
         ra.scalars = p->scalars;
         ra.out[0] = a.gX;
         ra.out[1] = ra.out[2] = nullptr;
@@ -2743,6 +2748,10 @@ static int camera_step_impl(ba_problem *p, const double *cam_in, double *cam_out
     a.W = p->W;
     a.H = p->H;
     a.T = p->cam_table;
+    // merged form: its consumer is the next run pass, which takes the centres from the parameter vector; writing
+    // them into the 128-byte rows as well (one cache line per camera, from one workgroup) was a quarter of the kernel
+    a.table_centres = (gauge && finalize) ? 0 : 1;
+    if (!a.table_centres) p->table_centres_stale = 1;
     a.scalars = p->scalars;
     a.R_out = R_out;
     a.gauge = gauge_out;

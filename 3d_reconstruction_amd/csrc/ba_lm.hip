@@ -856,7 +856,7 @@ int ba_eval_jtj(ba_problem *p, const double *X, const double *C, const double *T
     }
     if (!p->cam_sums_jtj) BA_HIP(hipMalloc(&p->cam_sums_jtj, sizeof(double) * CAMV * K));
     if (!p->partials_jtj) BA_HIP(hipMalloc(&p->partials_jtj, sizeof(double) * 3 * (size_t)p->n_tiles));
-    if (!(flags & BA_EVAL_REUSE_TABLE))
+    if (!(flags & BA_EVAL_REUSE_TABLE) || p->table_centres_stale)     // the Schur kernels read the rows' centres
         if (int rc = camera_table(p, C, Theta, phi, st)) return rc;
     BA_HIP(hipMemsetAsync(p->cam_sums_jtj, 0, sizeof(double) * CAMV * K, st));
     JtjArgs a;
@@ -887,6 +887,7 @@ int ba_eval_jtj(ba_problem *p, const double *X, const double *C, const double *T
     ra.cam_rep = p->run_rep_jtj;
     ra.X = X;
     ra.T = p->cam_table;
+    ra.C = C;
     ra.scalars = p->scalars;
     ra.out[0] = gX;
     ra.out[1] = V;
@@ -903,6 +904,7 @@ int ba_eval_jtj(ba_problem *p, const double *X, const double *C, const double *T
     bk.pt_stride = p->blk_pt_stride;
     bk.X = X;
     bk.T = p->cam_table;
+    bk.C = C;
     bk.scalars = p->scalars;
     bk.out[0] = gX;
     bk.out[1] = V;

@@ -90,7 +90,8 @@ struct RunArgs {
     const double *X = nullptr;
     const double *X_gauge = nullptr;    // optional: the true points are ((X - C0) @ R0) * factor of this record
                               // (R0 row-major [0..8], C0 [9..11], factor [12]); applied while loading
-    const double *T = nullptr;
+    const double *T = nullptr;          // camera table: rotations
+    const double *C = nullptr;          // camera centres (K x 3)
     const double *scalars = nullptr;
     // optional fused point update (upd.mode != 0): every point's gradient is complete when its
     // tile ends, so the tile applies the update rule right there and writes X_out / s_out / r_out
@@ -168,7 +169,7 @@ __global__ void __launch_bounds__(TILE_BLOCK, sizeof(typename Rec::raw_t) <= 8 ?
 
     for (int row = tid; row < nc; row += TILE_BLOCK) {
         const int j = tm.j0 >= 0 ? tm.j0 + row : a.cam_list[cb + row];
-        stage_camera_row_rt(a.T + (int64_t)j * CAM_ROW, rows + row * ROW_LDS);
+        stage_camera_row_rt(a.T + (int64_t)j * CAM_ROW, a.C + 3 * (int64_t)j, rows + row * ROW_LDS);
     }
     for (int idx = tid; idx < NCVL * nc * rep; idx += TILE_BLOCK) cacc[idx] = 0.0;
     {

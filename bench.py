@@ -101,7 +101,10 @@ def main():
     total = args.steps + args.warmup
     fit = ba.SceneFit(sh, lr=1e-3, max_iters=total + 8, patience=1000, print_step=10 ** 9,
                       printer=lambda *a: None)
-    fit.timed_every = 4          # HIP events around every 4th launch of the observation-pass kernel
+    # HIP events around every n-th launch of the observation-pass kernel.  A timed launch costs the loop about
+    # 70 us (the two event packets stall the queue), which the whole-job figure pays: three samples at the default
+    # 50 steps, more in longer runs
+    fit.timed_every = max(1, min(16, args.steps // 3))
 
     def sync():
         torch.cuda.synchronize()
