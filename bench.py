@@ -66,8 +66,8 @@ def cpu_baseline(sc, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=50)
     ap.add_argument('--points-per-gpu', type=int, default=1_000_000)
     ap.add_argument('--cameras', type=int, default=2000)
     ap.add_argument('--track-len', type=int, default=10)
@@ -102,8 +102,8 @@ def main():
     fit = ba.SceneFit(sh, lr=1e-3, max_iters=total + 8, patience=1000, print_step=10 ** 9,
                       printer=lambda *a: None)
     # HIP events around every n-th launch of the observation-pass kernel.  A timed launch costs the loop about
-    # 70 us (the two event packets stall the queue), which the whole-job figure pays: three samples at the default
-    # 50 steps, more in longer runs
+    # 70 us (the two event packets stall the queue), which the whole-job figure pays: every 16th launch (12 samples
+    # at the default 200 steps), at least three samples in short runs
     fit.timed_every = max(1, min(16, args.steps // 3))
 
     def sync():
