@@ -2081,7 +2081,7 @@ static int build_runs(ba_problem *p) {
         return rep;
     };
     p->run_rep_grad = pick_rep(6, 3, p->cam_cap, budget / 2, "BA_CAM_REP");
-    p->run_rep_jtj = pick_rep(31, 9, p->cam_cap, 78 * 1024, "BA_CAM_REP_JTJ");   // two workgroups per CU at least
+    p->run_rep_jtj = pick_rep(28, 9, p->cam_cap, 78 * 1024, "BA_CAM_REP_JTJ");   // two workgroups per CU at least
     if (getenv("BA_VERBOSE"))
         fprintf(stderr, "[ba] runs: records=%s total=%lld (%.3f x nV/8) pt_stride=%d rep_grad=%d rep_jtj=%d\n",
                 p->compact ? "i16" : "f64", (long long)p->total_runs, (double)p->total_runs * RUN_LEN / (double)p->nV, p->run_pt_stride,
