@@ -155,7 +155,10 @@ int ba_camera_step(ba_problem *p, const double *cam_in, double *cam_out, const d
  * the per-tile partials -> energy and d E / d phi_x, camera-frame sums -> d E / d C, d E / d Theta, all
  * written to g_out = [gC (3K) | gTheta (3K) | gphi | E_sum]; `post` also posts the energy to the
  * mailbox (see ba_wait_energy).  One launch instead of two for a single-GPU iteration (with several
- * GPUs the camera-block reduction sits between the two kernels). */
+ * GPUs the camera-block reduction sits between the two kernels).  It leaves the rotations of the camera table
+ * valid for cam_out but not the rows' centres: the camera-run pass (ba_eval, ba_eval_update with
+ * BA_EVAL_REUSE_TABLE) takes the centres from its C argument, every other user of the table rebuilds it first
+ * by itself. */
 int ba_camera_step_finalize(ba_problem *p, const double *cam_in, double *cam_out, double *g_out, int post,
                             const double *s_in, double *s_out, const double *r_in, double *r_out, int64_t lo,
                             int64_t hi, int rule, double lr, double gscale, double bc1, double bc2, double *R_out,
