@@ -16,6 +16,15 @@ from .sharding import StreamAllReduce, allreduce_sum_
 F64 = torch.float64
 
 
+def _take_rows(t, idx):
+    """t[idx] for a 2-D tensor, column by column.  torch's row gather (vectorized_gather_kernel) of this
+    ROCm build returns wrong rows for large inputs - measured: an (80 M, 2) float64 tensor, wrong from
+    row 12 891 136 on, while the 1-D indexing used here is correct at that size."""
+    if t.dim() == 1:
+        return t[idx]
+    return torch.stack([t[:, c][idx] for c in range(t.shape[1])], dim=1)
+
+
 def _dev_tensor(a, dtype, device):
     if isinstance(a, torch.Tensor):
         return a.to(device=device, dtype=dtype).contiguous()
@@ -213,19 +222,23 @@ class Shard:
         new_i = inv[i64]
         order = torch.argsort(new_i, stable=True)
         self.perm = perm
-        return new_i[order].to(torch.int32), oj[order].contiguous(), uv[order].contiguous()
+        return new_i[order].to(torch.int32), oj[order].contiguous(), _take_rows(uv, order)
 
     def points_to_engine(self, a):
         """(N, ...) array in the caller's point order -> device tensor in engine order."""
         t = _dev_tensor(a, F64, self.device)
-        return t if self.perm is None else t[self.perm]
+        return t if self.perm is None else _take_rows(t, self.perm)
 
     def points_to_caller(self, t):
         """Device tensor indexed by engine point order -> same data in the caller's order."""
         if self.perm is None:
             return t
         out = torch.empty_like(t)
-        out[self.perm] = t
+        if t.dim() == 1:
+            out[self.perm] = t
+        else:                       # column by column, see _take_rows
+            for c in range(t.shape[1]):
+                out[:, c][self.perm] = t[:, c]
         return out
 
     # ---- parameters -------------------------------------------------------------------------
@@ -537,7 +550,7 @@ def resect(oi, oj, uv, K, X, phi_x, W, H, normalize=False, device='cuda:0'):
         raise ValueError('Expected each camera to have at least 6 visible points')
     sel = counts[oj.to(torch.int64)] >= 6
     N0 = int(torch.unique(oi[sel]).numel())                        # p2w:1743-1744
-    oi_s, uv_s = oi[order].contiguous(), uv[order].contiguous()
+    oi_s, uv_s = oi[order].contiguous(), _take_rows(uv, order)
     C_out = torch.empty((K, 3), dtype=F64, device=dev)
     T_out = torch.empty((K, 3), dtype=F64, device=dev)
     with torch.cuda.device(dev):
@@ -558,7 +571,7 @@ def homography_diff_matrix(oi, oj, uv, N, K, normalize=False, W=None, H=None, mi
     order = torch.argsort(oj.to(torch.int64) * int(N) + oi.to(torch.int64))       # by camera, points ascending
     oj_s = oj[order]
     col_ptr, _ = _ranges(oj_s, K)
-    oi_s, uv_s = oi[order].contiguous(), uv[order].contiguous()
+    oi_s, uv_s = oi[order].contiguous(), _take_rows(uv, order)
     out = torch.empty((K, K), dtype=F64, device=dev)
     with torch.cuda.device(dev):
         check(lib.ba_homography_diff_matrix(K, ptr(col_ptr), ptr(oi_s), ptr(uv_s), float(W or 0.0), float(H or 0.0),

@@ -565,3 +565,21 @@ def test_h_diff_matrix_video_tracks_vs_oracle(ba):
         assert np.array_equal(np.isnan(got), np.isnan(ref)) and (~np.isnan(ref)).sum() > 100
         ok = ~np.isnan(ref)
         assert (np.abs(got - ref)[ok] <= tol * ref[ok]).all()
+
+
+def test_eighty_million_observations(ba):
+    """A shard beyond the size at which torch's 2-D row gather of this ROCm build goes wrong (the
+    engine reorders the observation list with it no longer): energy of the initial guess against
+    the oracle's forward model, and the points come back in the caller's order."""
+    sc = ba.scenes.orbit_scene(8_000_000, 2000, track_len=10, seed=0)
+    sh = ba.engine.Shard(sc['i'], sc['j'], sc['uv'], sc['N'], sc['K'], sc['W'], sc['H'], DEV)
+    sh.set_params(sc['X_0'], sc['C_0'], sc['Theta_0'], sc['phi_x_0'])
+    sh.eval()
+    E = sh.energy()
+    f = sc['W'] / 2.0 / np.tan(sc['phi_x_0'] / 2.0)
+    res, _, _ = orc.forward_obs(sc['X_0'], sc['C_0'], orc.ryxz(sc['Theta_0']), f, sc['W'], sc['H'],
+                                sc['i'], sc['j'], sc['uv'])
+    E_ref = float((res * res).sum() / (2.0 * sc['i'].size))
+    assert abs(E - E_ref) <= TOL * E_ref
+    assert np.array_equal(sh.points_to_caller(sh.X).cpu().numpy(), sc['X_0'])
+    sh.close()
