@@ -1099,6 +1099,7 @@ struct CameraStep {
     double W, H;
     double *T;            // camera table (K x CAM_ROW), may be null
     int table_centres;    // 0: leave the centres of the rows unwritten (quad kernel only)
+    int scale_later;      // 1: k_scale_centres follows and applies the scale factor (quad kernel only)
     double *scalars;      // may be null
     double *R_out;        // optional K x 9
     double *gauge;        // optional 16
@@ -1867,7 +1868,7 @@ __global__ void __launch_bounds__(256) k_camera_step_quad(CameraStep a, CameraSt
 #pragma unroll
     for (int u = 0; u < 24; ++u) {
         const int idx = 3 + u * 256 + tid;
-        v[u] = idx < n3 ? a.cam[idx] : 0.0;
+        v[u] = (idx < n3 && !a.scale_later) ? a.cam[idx] : 0.0;
     }
     double bv = -1.0;
     long long bj = K;
@@ -1942,6 +1943,7 @@ __global__ void __launch_bounds__(256) k_camera_step_quad(CameraStep a, CameraSt
     // scale of the centres: 24 loads per thread in flight at once (the caches were just invalidated, so a batch
     // costs a round trip to memory; K = 2000 is one batch, the one requested above)
     const double factor = s_factor;
+    if (a.scale_later) return;
     for (int base = 3; base < n3; base += 24 * 256) {
         if (base > 3) {
 #pragma unroll
@@ -1960,6 +1962,21 @@ __global__ void __launch_bounds__(256) k_camera_step_quad(CameraStep a, CameraSt
                 if (a.T && a.table_centres) a.T[(int64_t)jc * CAM_ROW + 9 + (idx - 3 * jc)] = c;
             }
         }
+    }
+}
+
+// Scale of the camera centres by the factor of a gauge record, for camera counts at which one workgroup (the
+// tail of k_camera_step_quad) would spend tens of microseconds on it: cam[3 .. 3K) and, if T is given, the rows'
+// centres.
+__global__ void __launch_bounds__(256) k_scale_centres(int64_t K, double *__restrict__ cam, double *__restrict__ T,
+                                                       const double *__restrict__ gauge) {
+    const int64_t idx = 3 + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 3 * K) return;
+    const double c = cam[idx] * gauge[12];
+    cam[idx] = c;
+    if (T) {
+        const int64_t jc = idx / 3;
+        T[jc * CAM_ROW + 9 + (idx - 3 * jc)] = c;
     }
 }
 
@@ -2752,6 +2769,7 @@ static int camera_step_impl(ba_problem *p, const double *cam_in, double *cam_out
     // them into the 128-byte rows as well (one cache line per camera, from one workgroup) was a quarter of the kernel
     a.table_centres = (gauge && finalize) ? 0 : 1;
     if (!a.table_centres) p->table_centres_stale = 1;
+    a.scale_later = (gauge && p->K > 2048) ? 1 : 0;     // beyond one batch of the kernel's last workgroup
     a.scalars = p->scalars;
     a.R_out = R_out;
     a.gauge = gauge_out;
@@ -2778,6 +2796,9 @@ static int camera_step_impl(ba_problem *p, const double *cam_in, double *cam_out
             hipLaunchKernelGGL(k_camera_step_quad<false>, dim3(cdiv(p->K - 1, 63)), dim3(256), 0, (hipStream_t)stream,
                                a, sh, fz);
         }
+        if (a.scale_later)
+            hipLaunchKernelGGL(k_scale_centres, dim3(cdiv(3 * p->K - 3, 256)), dim3(256), 0, (hipStream_t)stream, p->K,
+                               a.cam, a.table_centres ? a.T : nullptr, a.gauge);
     } else {
         hipLaunchKernelGGL(k_camera_step_mb, dim3(cdiv(p->K, 256)), dim3(256), 0, (hipStream_t)stream, a, sh);
     }

@@ -583,3 +583,25 @@ def test_eighty_million_observations(ba):
     assert abs(E - E_ref) <= TOL * E_ref
     assert np.array_equal(sh.points_to_caller(sh.X).cpu().numpy(), sc['X_0'])
     sh.close()
+
+
+def test_many_cameras_fit_matches_oracle(ba):
+    """More than 2048 cameras: the centres are scaled by a kernel of its own after the camera step
+    (both the merged and the unfused form), and the camera step runs on many workgroups.  Five
+    updates of fit_scene on the device against the oracle."""
+    sc = ba.scenes.orbit_scene(30_000, 2500, track_len=10, seed=3)
+    K = sc['K']
+    ref = orc.fit_scene(sc['i'], sc['j'], sc['uv'], sc['N'], K, sc['W'], sc['H'], 1e-3, 6, sc['X_0'], sc['C_0'],
+                        sc['Theta_0'], sc['phi_x_0'])
+    for fuse in (True, False):
+        sh = ba.engine.Shard(sc['i'], sc['j'], sc['uv'], sc['N'], K, sc['W'], sc['H'], DEV)
+        sh.set_params(sc['X_0'], sc['C_0'], sc['Theta_0'], sc['phi_x_0'])
+        fit = ba.SceneFit(sh, 1e-3, 6, printer=lambda *a: None, fuse=fuse).run()
+        assert fit.fuse == fuse
+        assert rel_err(fit.energies(), ref[4]) < TOL
+        cam = sh.cam.cpu().numpy()
+        assert np.abs(sh.points_to_caller(sh.X).cpu().numpy() - ref[0]).max() < 1e-9
+        assert np.abs(cam[:3 * K].reshape(K, 3) - ref[1]).max() < 1e-9
+        assert np.abs(cam[3 * K:6 * K].reshape(K, 3) - ref[2]).max() < 1e-9
+        assert abs(cam[6 * K] - ref[3]) < 1e-12
+        sh.close()
