@@ -605,3 +605,32 @@ def test_many_cameras_fit_matches_oracle(ba):
         assert np.abs(cam[3 * K:6 * K].reshape(K, 3) - ref[2]).max() < 1e-9
         assert abs(cam[6 * K] - ref[3]) < 1e-12
         sh.close()
+
+
+def test_table_consumers_after_a_merged_camera_step(ba, golden):
+    """The merged camera step leaves the table rows' centres unwritten; every other consumer of the
+    table (point-major and chunk kernels, the second-order pass) must rebuild it on its own."""
+    g = golden('f6_medium.npz')
+    N, K = int(g['N']), int(g['K'])
+    sh = ba.engine.Shard(g['obs_i'], g['obs_j'], g['obs_xy'] + 0.5, N, K, int(g['W']), int(g['H']), DEV)
+    sh.set_params(g['X_0'], g['C_0'], g['Theta_0'], float(g['phi_x_0']))
+    fit = ba.SceneFit(sh, 1e-3, 50, printer=lambda *a: None)
+    assert fit.fuse
+    for _ in range(3):
+        fit.step()
+    assert sh._table_cam is sh.cam                     # the next pass would reuse the table
+    sh.eval()                                          # camera runs: centres from the parameter vector
+    E0, gC0, gX0 = sh.energy(), sh.gC.cpu().numpy().copy(), sh.gX.cpu().numpy().copy()
+    for kw in (dict(point_major=True), dict(untiled=True), dict(cam_atomics=True)):
+        sh._table_cam = sh.cam                         # claim the table is current, as the loop would
+        sh.eval(**kw)
+        assert abs(sh.energy() - E0) <= 1e-12 * E0, kw
+        assert rel_err(sh.gC.cpu().numpy(), gC0) < 1e-11 and rel_err(sh.gX.cpu().numpy(), gX0) < 1e-11, kw
+    for _ in range(2):
+        fit.step()
+    sh._table_cam = sh.cam
+    sh.eval_jtj()
+    gC_j = sh.gC.cpu().numpy().copy()
+    sh.eval()
+    assert rel_err(gC_j, sh.gC.cpu().numpy()) < 1e-11
+    sh.close()
