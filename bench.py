@@ -102,9 +102,9 @@ def main():
     fit = ba.SceneFit(sh, lr=1e-3, max_iters=total + 8, patience=1000, print_step=10 ** 9,
                       printer=lambda *a: None)
     # HIP events around every n-th launch of the observation-pass kernel.  A timed launch costs the loop about
-    # 70 us (the two event packets stall the queue), which the whole-job figure pays: every 16th launch (12 samples
+    # 70 us (the two event packets stall the queue), which the whole-job figure pays: every 32nd launch (6 samples
     # at the default 200 steps), at least three samples in short runs
-    fit.timed_every = max(1, min(16, args.steps // 3))
+    fit.timed_every = max(1, min(32, args.steps // 3))
 
     def sync():
         torch.cuda.synchronize()
