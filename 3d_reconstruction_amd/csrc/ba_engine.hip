@@ -20,6 +20,8 @@
 #include <atomic>
 #include <chrono>
 #include "ba_device.h"
+
+#include <hip/hip_ext.h>
 #include "ba_runpass.h"
 #include "ba_blockpass.h"
 
@@ -2506,7 +2508,14 @@ static int eval_impl(ba_problem *p, const double *X, const double *C, const doub
         set_error("ba_eval_update: needs the camera-run layout of the observation pass");
         return BA_ERR_STATE;
     }
-    if (timed) BA_HIP(hipEventRecord(p->ev_begin[p->ev_count], st));
+    // a timed launch hands its two events to the dispatch itself (hipExtLaunchKernelGGL): they receive the kernel's
+    // own begin and end, and no event packets sit in the queue (recording events around the launch stalls it)
+    hipEvent_t ev_b = timed ? p->ev_begin[p->ev_count] : nullptr, ev_e = timed ? p->ev_end[p->ev_count] : nullptr;
+#define BA_LAUNCH_MAYBE_TIMED(kern, grid, block, lds, arg)                                   \
+    do {                                                                                     \
+        if (timed) hipExtLaunchKernelGGL(kern, grid, block, (uint32_t)(lds), st, ev_b, ev_e, 0, arg); \
+        else hipLaunchKernelGGL(kern, grid, block, lds, st, arg);                            \
+    } while (0)
     if (use_runs) {
         RunArgs ra;
         ra.rpack = p->rpack;
@@ -2538,8 +2547,8 @@ static int eval_impl(ba_problem *p, const double *X, const double *C, const doub
         const size_t lds = sizeof(double) * run_pass_lds_doubles<GradOp>(p->cam_cap, p->run_pt_stride, p->run_rep_grad);
         const void *fn = p->compact ? (const void *)k_run_pass<GradOp, RecI16> : (const void *)k_run_pass<GradOp, RecF64>;
         if (lds > 64 * 1024) BA_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        if (p->compact) hipLaunchKernelGGL((k_run_pass<GradOp, RecI16>), dim3(p->n_tiles), dim3(TILE_BLOCK), lds, st, ra);
-        else hipLaunchKernelGGL((k_run_pass<GradOp, RecF64>), dim3(p->n_tiles), dim3(TILE_BLOCK), lds, st, ra);
+        if (p->compact) BA_LAUNCH_MAYBE_TIMED((k_run_pass<GradOp, RecI16>), dim3(p->n_tiles), dim3(TILE_BLOCK), lds, ra);
+        else BA_LAUNCH_MAYBE_TIMED((k_run_pass<GradOp, RecF64>), dim3(p->n_tiles), dim3(TILE_BLOCK), lds, ra);
     } else if (use_tiles) {
         TileArgs ta;
         ta.opack = p->opack;
@@ -2559,20 +2568,18 @@ static int eval_impl(ba_problem *p, const double *X, const double *C, const doub
         ta.partials = p->partials;
         ta.debug = a.debug;
         n_partials = p->n_tiles;
-        hipLaunchKernelGGL(k_eval_tiled, dim3(p->n_tiles), dim3(TILE_BLOCK), p->tile_lds_bytes, st, ta);
+        BA_LAUNCH_MAYBE_TIMED(k_eval_tiled, dim3(p->n_tiles), dim3(TILE_BLOCK), p->tile_lds_bytes, ta);
     } else if (use_lds) {
         if (lds_bytes > 64 * 1024)
             BA_HIP(hipFuncSetAttribute((const void *)k_eval<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds_bytes));
-        hipLaunchKernelGGL(k_eval<true>, dim3(p->grid), dim3(EVAL_BLOCK), lds_bytes, st, a);
+        BA_LAUNCH_MAYBE_TIMED(k_eval<true>, dim3(p->grid), dim3(EVAL_BLOCK), lds_bytes, a);
     } else {
-        hipLaunchKernelGGL(k_eval<false>, dim3(p->grid), dim3(EVAL_BLOCK), 0, st, a);
+        BA_LAUNCH_MAYBE_TIMED(k_eval<false>, dim3(p->grid), dim3(EVAL_BLOCK), 0, a);
     }
+#undef BA_LAUNCH_MAYBE_TIMED
     BA_HIP(hipGetLastError());
-    if (timed) {
-        BA_HIP(hipEventRecord(p->ev_end[p->ev_count], st));
-        p->ev_count++;
-    }
+    if (timed) p->ev_count++;
     const bool want_cam = (flags & BA_EVAL_GRAD_CAM) != 0;
     if (flags & BA_EVAL_DEFER_FINALIZE) {   // ba_camera_step_finalize finishes the pass
         BA_REQUIRE(want_cam && (flags & BA_EVAL_GRAD_PHI), "ba_eval: BA_EVAL_DEFER_FINALIZE needs the camera and phi gradients");

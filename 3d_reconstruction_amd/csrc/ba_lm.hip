@@ -17,6 +17,7 @@
 #include "ba_runpass.h"
 #include "ba_blockpass.h"
 
+#include <hip/hip_ext.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -969,22 +970,26 @@ int ba_eval_jtj(ba_problem *p, const double *X, const double *C, const double *T
                      : p->compact ? (const void *)k_run_pass<JtjOp, RecI16> : (const void *)k_run_pass<JtjOp, RecF64>;
     if (lds > 64 * 1024) BA_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const bool timed = (flags & BA_EVAL_TIMED) != 0 && p->ev_count < TIMING_RING;
-    if (timed) BA_HIP(hipEventRecord(p->ev_begin[p->ev_count], st));
+    // a timed launch hands its events to the dispatch itself: the kernel's own begin and end, no event packets
+    hipEvent_t ev_b = timed ? p->ev_begin[p->ev_count] : nullptr, ev_e = timed ? p->ev_end[p->ev_count] : nullptr;
+#define BA_LAUNCH_MAYBE_TIMED(kern, grid, block, arg)                                          \
+    do {                                                                                       \
+        if (timed) hipExtLaunchKernelGGL(kern, grid, block, (uint32_t)lds, st, ev_b, ev_e, 0, arg); \
+        else hipLaunchKernelGGL(kern, grid, block, lds, st, arg);                              \
+    } while (0)
     if (use_blocks && p->compact)
-        hipLaunchKernelGGL((k_block_pass<JtjOp, BlkRecI16>), dim3(p->n_tiles), dim3(64 * p->blk_waves), lds, st, bk);
+        BA_LAUNCH_MAYBE_TIMED((k_block_pass<JtjOp, BlkRecI16>), dim3(p->n_tiles), dim3(64 * p->blk_waves), bk);
     else if (use_blocks)
-        hipLaunchKernelGGL((k_block_pass<JtjOp, BlkRecF64>), dim3(p->n_tiles), dim3(64 * p->blk_waves), lds, st, bk);
+        BA_LAUNCH_MAYBE_TIMED((k_block_pass<JtjOp, BlkRecF64>), dim3(p->n_tiles), dim3(64 * p->blk_waves), bk);
     else if (use_runs && p->compact)
-        hipLaunchKernelGGL((k_run_pass<JtjOp, RecI16>), dim3(p->n_tiles), dim3(TILE_BLOCK), lds, st, ra);
+        BA_LAUNCH_MAYBE_TIMED((k_run_pass<JtjOp, RecI16>), dim3(p->n_tiles), dim3(TILE_BLOCK), ra);
     else if (use_runs)
-        hipLaunchKernelGGL((k_run_pass<JtjOp, RecF64>), dim3(p->n_tiles), dim3(TILE_BLOCK), lds, st, ra);
+        BA_LAUNCH_MAYBE_TIMED((k_run_pass<JtjOp, RecF64>), dim3(p->n_tiles), dim3(TILE_BLOCK), ra);
     else
-        hipLaunchKernelGGL(k_jtj_tiled, dim3(p->n_tiles), dim3(TILE_BLOCK), lds, st, a);
+        BA_LAUNCH_MAYBE_TIMED(k_jtj_tiled, dim3(p->n_tiles), dim3(TILE_BLOCK), a);
+#undef BA_LAUNCH_MAYBE_TIMED
     BA_HIP(hipGetLastError());
-    if (timed) {
-        BA_HIP(hipEventRecord(p->ev_end[p->ev_count], st));
-        p->ev_count++;
-    }
+    if (timed) p->ev_count++;
     hipLaunchKernelGGL(k_jtj_finalize, dim3(cdiv_i(K, 256)), dim3(256), 0, st, K, p->n_tiles, p->partials_jtj,
                        p->cam_sums_jtj, p->cam_table, p->scalars, E_sum, gphi, hphi, gC, gTheta, B, bphi,
                        (use_runs || use_blocks) ? 1 : 0);

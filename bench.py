@@ -66,8 +66,9 @@ def cpu_baseline(sc, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--warmup', type=int, default=50)
+    ap.add_argument('--steps', type=int, default=300)
+    ap.add_argument('--warmup', type=int, default=300,
+                    help='the first few hundred iterations of a process run 5-10 %% slower than the steady state')
     ap.add_argument('--points-per-gpu', type=int, default=1_000_000)
     ap.add_argument('--cameras', type=int, default=2000)
     ap.add_argument('--track-len', type=int, default=10)
@@ -101,10 +102,9 @@ def main():
     total = args.steps + args.warmup
     fit = ba.SceneFit(sh, lr=1e-3, max_iters=total + 8, patience=1000, print_step=10 ** 9,
                       printer=lambda *a: None)
-    # HIP events around every n-th launch of the observation-pass kernel.  A timed launch costs the loop about
-    # 70 us (the two event packets stall the queue), which the whole-job figure pays: every 32nd launch (6 samples
-    # at the default 200 steps), at least three samples in short runs
-    fit.timed_every = max(1, min(32, args.steps // 3))
+    # HIP events on every 16th launch of the observation-pass kernel (handed to the dispatch itself, so they hold the
+    # kernel's own begin and end), at least three samples in short runs
+    fit.timed_every = max(1, min(16, args.steps // 3))
 
     def sync():
         torch.cuda.synchronize()
