@@ -634,3 +634,22 @@ def test_table_consumers_after_a_merged_camera_step(ba, golden):
     sh.eval()
     assert rel_err(gC_j, sh.gC.cpu().numpy()) < 1e-11
     sh.close()
+
+
+def test_parkour_shaped_scene(ba):
+    """The second configuration of the benchmark list has no observation data in the reference (frames
+    only); its shape - 100 keypoints over 300 frames of 3840 x 2160, tracks of up to a quarter of the
+    frames - as a synthetic scene: many more cameras than points, so the tiles hold most cameras.
+    Forty iterations of fit_scene against the oracle, every energy and the final parameters."""
+    sc = ba.scenes.orbit_scene(100, 300, track_len=75, seed=11, W=3840, H=2160)
+    N, K = sc['N'], sc['K']
+    assert sc['i'].size > 2000          # about 8 % of the pairs: the field of view cuts the 75-frame windows short
+    ref = orc.fit_scene(sc['i'], sc['j'], sc['uv'], N, K, sc['W'], sc['H'], 1e-3, 41, sc['X_0'], sc['C_0'],
+                        sc['Theta_0'], sc['phi_x_0'])
+    with contextlib.redirect_stdout(io.StringIO()):
+        got = ba.fit_scene_sparse(sc['i'], sc['j'], sc['uv'], N, K, sc['W'], sc['H'], 1e-3, 41, sc['X_0'], sc['C_0'],
+                                  sc['Theta_0'], sc['phi_x_0'])
+    assert got[4].shape == ref[4].shape and rel_err(got[4], ref[4]) < TOL
+    for a, b in zip(got[:3], ref[:3]):
+        assert np.abs(a - b).max() < 1e-6
+    assert abs(got[3] - ref[3]) < 1e-6
