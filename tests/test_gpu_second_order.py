@@ -78,7 +78,7 @@ def test_cholesky_solve_random_spd(ba):
     lib = ba.engine._lib.load()
     import ctypes as C
     rng = np.random.default_rng(0)
-    for n in (64, 200, 700, 1000, 1500):
+    for n in (64, 200, 700, 1000, 1500, 3400):       # 3400: four outer panels
         ld = (n + 63) // 64 * 64
         A = rng.normal(size=(n, 2 * n))
         S = A @ A.T + n * np.eye(n)
