@@ -30,8 +30,8 @@
 // slower).  Every field of a point is then a constant offset from one address register.
 //
 // Latencies: the LDS returns results in order, so a read issued behind the 3 / 9 atomics of the
-// previous observation waits for them; the point of observation k + 1 is therefore fetched before
-// the arithmetic of observation k starts, and the records of the thread's next run are requested
+// previous observation waits for them; the point of observation k + 1 is therefore fetched between
+// the arithmetic of observation k and its atomics, and the records of the thread's next run are requested
 // as soon as those of the current run have been decoded.
 #pragma once
 
@@ -224,16 +224,21 @@ __global__ void __launch_bounds__(TILE_BLOCK, sizeof(typename Rec::raw_t) <= 8 ?
             const double x[3] = {xn[0], xn[1], xn[2]};
             const bool valid = Rec::valid(rec[k]);
             const double2 uv = Rec::pix(rec[k]);
-            if (k + 1 < RUN_LEN) {      // the next observation's point, ahead of this observation's atomics
-                pt_next = pts + (Rec::pack(rec[k + 1]) >> 16) * PREC;
-                xn[0] = pt_next[0];
-                xn[1] = pt_next[1];
-                xn[2] = pt_next[2];
-            }
+            const uint32_t next_pack = k + 1 < RUN_LEN ? Rec::pack(rec[k + 1]) : 0u;
             // this slot of the thread's next run (of this run again after the last one: no branch)
             rec[k] = Rec::load(a, base_next + (int64_t)k * nruns);
             double pv[NPV];
             op.obs(valid, x, rw, uv, cv, pv, part);
+            if (k + 1 < RUN_LEN) {
+                // the next observation's point: requested behind this observation's arithmetic (its coordinates are
+                // then not live at the register peak: the J^T J pass fits 168 registers without spills) but ahead
+                // of its atomics, which the LDS would otherwise finish first
+                __builtin_amdgcn_sched_barrier(0);
+                pt_next = pts + (next_pack >> 16) * PREC;
+                xn[0] = pt_next[0];
+                xn[1] = pt_next[1];
+                xn[2] = pt_next[2];
+            }
 #pragma unroll
             for (int v = 0; v < NPV; ++v)
                 __hip_atomic_fetch_add(pt_cur + 3 + v, pv[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
