@@ -79,7 +79,7 @@ struct ba_problem {
     int64_t *run_ptr = nullptr;       // n_tiles + 1
     int64_t total_runs = 0;
     int run_pt_stride = 0;            // LDS point capacity / 8
-    int run_rep_grad = 1, run_rep_jtj = 1;   // copies of the camera accumulators per pass
+    int run_slots_grad = 0, run_slots_jtj = 0;   // camera columns of the LDS accumulator space per pass (see RunArgs)
     // dense block layout of the tiles (see ba_blockpass.h); null when its padding would cost too much
     uint32_t *brec = nullptr;         // total_units x 512 compact records
     double2 *buv = nullptr;           // ... or pixel centres as doubles

@@ -2089,22 +2089,32 @@ static int build_runs(ba_problem *p) {
     hipLaunchKernelGGL(k_run_fill, dim3(nt), dim3(TILE_BLOCK), fill_lds, 0, p->opack, p->ouv,
                        (const TileMeta *)p->tile_meta, p->run_ptr, p->cam_cap, p->run_pt_stride, p->rpack, p->ruv, p->rrec);
     BA_HIP(hipGetLastError());
-    // copies of the camera accumulators: as many as keep the workgroup near a quarter of the LDS budget
+    // LDS accumulator space for the camera sums: two copies at the largest tile (one if that is too much), plus
+    // whatever the workgroup's LDS allocation leaves unused: the LDS of a CU (160 KB) is handed out in granules of
+    // 1280 bytes, so a workgroup can grow to the largest size that keeps the number of workgroups per CU
     const size_t budget = 64 * 1024;
-    auto pick_rep = [&](int ncv, int npv, int cam_cap, size_t limit, const char *env_name) {
+    auto pick_slots = [&](int ncv, int npv, size_t limit, const char *env_name) {
         int rep = 2;
         if (const char *env = getenv(env_name)) rep = atoi(env);
         if (rep < 1) rep = 1;
-        while (rep > 1 && sizeof(double) * run_pass_lds_doubles(ncv, npv, cam_cap, p->run_pt_stride, rep) > limit)
+        while (rep > 1 && sizeof(double) * run_pass_lds_doubles(ncv, npv, p->cam_cap, p->run_pt_stride, p->cam_cap * rep) > limit)
             rep >>= 1;
-        return rep;
+        int slots = p->cam_cap * rep;
+        const size_t lds_cu = 160 * 1024, granule = 1280, fixed = 256;     // fixed: the kernel's static arrays
+        const size_t base = sizeof(double) * run_pass_lds_doubles(ncv, npv, p->cam_cap, p->run_pt_stride, slots) + fixed;
+        const size_t per_cu = lds_cu / base;
+        if (per_cu >= 1 && !getenv("BA_NO_LDS_SLACK")) {
+            const size_t room = (lds_cu / per_cu) / granule * granule;
+            if (room > base) slots += (int)((room - base) / (sizeof(double) * ncv));
+        }
+        return slots;
     };
-    p->run_rep_grad = pick_rep(6, 3, p->cam_cap, budget / 2, "BA_CAM_REP");
-    p->run_rep_jtj = pick_rep(28, 9, p->cam_cap, 78 * 1024, "BA_CAM_REP_JTJ");   // two workgroups per CU at least
+    p->run_slots_grad = pick_slots(6, 3, budget / 2, "BA_CAM_REP");
+    p->run_slots_jtj = pick_slots(28, 9, 78 * 1024, "BA_CAM_REP_JTJ");   // two workgroups per CU at least
     if (getenv("BA_VERBOSE"))
-        fprintf(stderr, "[ba] runs: records=%s total=%lld (%.3f x nV/8) pt_stride=%d rep_grad=%d rep_jtj=%d\n",
+        fprintf(stderr, "[ba] runs: records=%s total=%lld (%.3f x nV/8) pt_stride=%d accumulator columns grad=%d jtj=%d (largest tile: %d cameras)\n",
                 p->compact ? "i16" : "f64", (long long)p->total_runs, (double)p->total_runs * RUN_LEN / (double)p->nV, p->run_pt_stride,
-                p->run_rep_grad, p->run_rep_jtj);
+                p->run_slots_grad, p->run_slots_jtj, p->cam_cap);
     return BA_OK;
 }
 
@@ -2527,7 +2537,7 @@ static int eval_impl(ba_problem *p, const double *X, const double *C, const doub
         ra.K = (int)K;
         ra.cam_cap = p->cam_cap;
         ra.pt_stride = p->run_pt_stride;
-        ra.cam_rep = p->run_rep_grad;
+        ra.cacc_slots = p->run_slots_grad;
         ra.X = X;
         ra.X_gauge = fu ? fu->X_gauge : nullptr;
         ra.upd = fu ? fu->rule : UpdateRule{0, 0.0, 0.0, 1.0, 1.0};
@@ -2544,7 +2554,7 @@ static int eval_impl(ba_problem *p, const double *X, const double *C, const doub
         ra.cam_sums = p->cam_sums;
         ra.partials = p->partials;
         n_partials = p->n_tiles;
-        const size_t lds = sizeof(double) * run_pass_lds_doubles<GradOp>(p->cam_cap, p->run_pt_stride, p->run_rep_grad);
+        const size_t lds = sizeof(double) * run_pass_lds_doubles<GradOp>(p->cam_cap, p->run_pt_stride, p->run_slots_grad);
         const void *fn = p->compact ? (const void *)k_run_pass<GradOp, RecI16> : (const void *)k_run_pass<GradOp, RecF64>;
         if (lds > 64 * 1024) BA_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (p->compact) BA_LAUNCH_MAYBE_TIMED((k_run_pass<GradOp, RecI16>), dim3(p->n_tiles), dim3(TILE_BLOCK), lds, ra);

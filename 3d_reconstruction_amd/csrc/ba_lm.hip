@@ -898,7 +898,7 @@ int ba_eval_jtj(ba_problem *p, const double *X, const double *C, const double *T
     }
     hipStream_t st = (hipStream_t)stream;
     const int64_t K = p->K;
-    const size_t lds_runs = sizeof(double) * run_pass_lds_doubles<JtjOp>(p->cam_cap, p->run_pt_stride, p->run_rep_jtj);
+    const size_t lds_runs = sizeof(double) * run_pass_lds_doubles<JtjOp>(p->cam_cap, p->run_pt_stride, p->run_slots_jtj);
     const size_t lds_blocks = sizeof(double) * block_pass_lds_doubles(PTV, p->cam_cap, p->blk_pt_stride);
     const bool use_blocks = p->blk_ptr && (flags & BA_EVAL_DENSE_BLOCKS) && !(flags & BA_EVAL_POINT_MAJOR) && lds_blocks <= 160 * 1024 - 256;
     const bool use_runs = !use_blocks && p->run_ptr && !(flags & BA_EVAL_POINT_MAJOR) && lds_runs <= 160 * 1024 - 256;
@@ -939,7 +939,7 @@ int ba_eval_jtj(ba_problem *p, const double *X, const double *C, const double *T
     ra.K = (int)K;
     ra.cam_cap = p->cam_cap;
     ra.pt_stride = p->run_pt_stride;
-    ra.cam_rep = p->run_rep_jtj;
+    ra.cacc_slots = p->run_slots_jtj;
     ra.X = X;
     ra.T = p->cam_table;
     ra.C = C;

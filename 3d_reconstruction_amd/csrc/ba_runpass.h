@@ -86,7 +86,8 @@ struct RunArgs {
     int K = 0;
     int cam_cap = 0;              // LDS capacity in cameras (max over tiles)
     int pt_stride = 0;            // S: LDS capacity in points is 8 * S
-    int cam_rep = 1;              // copies of the camera accumulators the LDS space is sized for (at cam_cap cameras)
+    int cacc_slots = 0;           // camera columns the LDS accumulator space holds (each Op::NCV_LDS doubles): a tile
+                                  // with nc cameras uses cacc_slots / nc copies
     const double *X = nullptr;
     const double *X_gauge = nullptr;    // optional: the true points are ((X - C0) @ R0) * factor of this record
                               // (R0 row-major [0..8], C0 [9..11], factor [12]); applied while loading
@@ -117,12 +118,12 @@ __device__ __forceinline__ int pt_swz(int p, int S) { return (p & 7) * S + (p >>
 __host__ __device__ constexpr int pt_record_doubles(int npv) { return (3 + npv) | 1; }
 
 // LDS doubles a workgroup of the pass needs
-__host__ __device__ inline size_t run_pass_lds_doubles(int ncv, int npv, int cam_cap, int pt_stride, int rep) {
-    return (size_t)cam_cap * ROW_LDS + (size_t)cam_cap * ncv * rep + (size_t)pt_record_doubles(npv) * 8 * pt_stride;
+__host__ __device__ inline size_t run_pass_lds_doubles(int ncv, int npv, int cam_cap, int pt_stride, int cacc_slots) {
+    return (size_t)cam_cap * ROW_LDS + (size_t)cacc_slots * ncv + (size_t)pt_record_doubles(npv) * 8 * pt_stride;
 }
 template <class Op>
-__host__ __device__ inline size_t run_pass_lds_doubles(int cam_cap, int pt_stride, int rep) {
-    return run_pass_lds_doubles(Op::NCV_LDS, Op::NPV, cam_cap, pt_stride, rep);
+__host__ __device__ inline size_t run_pass_lds_doubles(int cam_cap, int pt_stride, int cacc_slots) {
+    return run_pass_lds_doubles(Op::NCV_LDS, Op::NPV, cam_cap, pt_stride, cacc_slots);
 }
 
 // Op supplies:  Op(scalars, pix_shift) (pix_shift: what the records' pixels lack to the pixel centre), cv_flush(k, v)
@@ -159,13 +160,13 @@ __global__ void __launch_bounds__(TILE_BLOCK, sizeof(typename Rec::raw_t) <= 8 ?
     }
 
     constexpr int PREC = pt_record_doubles(NPV);                // doubles of a point's LDS record
-    // copies of the camera accumulators: the space is sized for cam_cap cameras x cam_rep copies; a tile with fewer
-    // cameras spreads its flushes over as many copies as fit (copy = round mod rep, by multiply and shift)
-    const int rep = min(15, (a.cam_cap * a.cam_rep) / nc), rep_inv = (256 + rep - 1) / rep;
+    // copies of the camera accumulators: a tile spreads its flushes over as many copies as the accumulator space
+    // holds for its camera count (copy = round mod rep, by multiply and shift)
+    const int rep = min(15, a.cacc_slots / nc), rep_inv = (256 + rep - 1) / rep;
     const int S = a.pt_stride;
     double *rows = lds;                                         // cam_cap x ROW_LDS
     double *cacc = rows + (size_t)a.cam_cap * ROW_LDS;          // rep x NCVL x nc (component-major, used sums only)
-    double *pts = cacc + (size_t)a.cam_cap * NCVL * a.cam_rep;         // 8 S records of PREC doubles: x (3), sums (NPV)
+    double *pts = cacc + (size_t)a.cacc_slots * NCVL;         // 8 S records of PREC doubles: x (3), sums (NPV)
 
     for (int row = tid; row < nc; row += TILE_BLOCK) {
         const int j = tm.j0 >= 0 ? tm.j0 + row : a.cam_list[cb + row];
