@@ -65,6 +65,13 @@ SIGNATURES = {
     'ba_subscenes_eval': (_int, [_i64, _i64] + [_p] * 7),
     'ba_subscenes_step': (_int, [_i64, _int, _dbl, _dbl, _dbl, _dbl] + [_p] * 8),
     'ba_subscenes_transform': (_int, [_i64, _i64] + [_p] * 6),
+    'ba_exchange_create': (_int, [_int, _int, _i64, _p]),
+    'ba_exchange_export': (_int, [_p, _p]),
+    'ba_exchange_import': (_int, [_p, _int, _p]),
+    'ba_exchange_sum': (_int, [_p, _p, _i64, _p]),
+    'ba_exchange_status': (_int, [_p]),
+    'ba_exchange_set_wait': (_int, [_p, _dbl]),
+    'ba_exchange_destroy': (None, [_p]),
 }
 
 _lib = None

@@ -1,0 +1,241 @@
+// Sum of a short fp64 vector over the GPUs of one node without a collective library: every GPU
+// publishes its vector in a window of its own memory that the other GPUs have mapped (HIP IPC), a
+// flag exchange tells when all windows are filled, and every GPU adds the windows up in rank order
+// (the same order everywhere: all ranks end with bit-identical sums).  One kernel, one trip over
+// xGMI for the flags and one for the data; meant for the per-iteration camera-block sum of the fit
+// loop (~100 KB), where a ring or tree collective is bound by its latency.
+//
+// Window (memory allocated "uncached", so that stores go out to memory and loads of another GPU
+// never meet a stale line):
+//   flags  uint32 [EX_MAX_BLOCKS][EX_MAX_RANKS]   flag[b][r] = last call whose block b rank r has published
+//   slots  double [2][capacity]                   call e uses slot e & 1
+// A rank can overwrite slot e & 1 (in call e + 2) only after it has passed the flag exchange of call
+// e + 1, i.e. after every other rank has launched call e + 1, which its stream starts only after its
+// kernel of call e has finished reading: two slots are enough, and no second flag exchange is needed
+// at the end of a call.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <string>
+
+#include "ba_common.h"
+#include "ba_mi355x.h"
+
+namespace ba {
+
+constexpr int EX_MAX_RANKS = 16;
+constexpr int EX_MAX_BLOCKS = 256;
+constexpr int EX_BLOCK = 256;
+constexpr int EX_CHUNK = 1024;                    // doubles one workgroup publishes and sums
+constexpr size_t EX_FLAG_BYTES = sizeof(uint32_t) * EX_MAX_BLOCKS * EX_MAX_RANKS;
+
+struct ExchangeArgs {
+    char *window[EX_MAX_RANKS];                   // window[rank] is this GPU's own
+    double *buf;
+    int64_t n, capacity;
+    int rank, world;
+    uint32_t call;
+    long long wait_ticks;                         // upper bound for the flag wait (wall_clock64 ticks, 100 MHz)
+    int *status;                                  // host memory: set to 1 when a wait ran out
+};
+
+__global__ void __launch_bounds__(EX_BLOCK) k_exchange_sum(ExchangeArgs a) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int64_t lo = (int64_t)b * EX_CHUNK;
+    const int64_t hi = lo + EX_CHUNK < a.n ? lo + EX_CHUNK : a.n;
+    const size_t slot_off = EX_FLAG_BYTES + sizeof(double) * (size_t)(a.call & 1u) * (size_t)a.capacity;
+
+    // 1. publish this workgroup's chunk.  The window is uncached memory and every access to it is a system-scope
+    // atomic (the access goes to memory, past both cache levels), so no cache has to be written back or
+    // invalidated: a fence of system scope would write back the whole L2, which is full of the pass's point
+    // state at this moment.  Waiting for the stores' completion is all the ordering the flag needs.
+    constexpr int PER = EX_CHUNK / EX_BLOCK;                    // elements per thread
+    double *mine = (double *)(a.window[a.rank] + slot_off);
+    {
+        double v[PER];
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const int64_t i = lo + tid + e * EX_BLOCK;
+            v[e] = i < hi ? a.buf[i] : 0.0;
+        }
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const int64_t i = lo + tid + e * EX_BLOCK;
+            if (i < hi) __hip_atomic_store(mine + i, v[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this thread's stores have been acknowledged by memory
+    __syncthreads();
+
+    // 2. tell every rank, then wait for every rank (bounded: a rank that never arrives must not hang the GPU)
+    int failed = 0;
+    if (tid < a.world) {
+        uint32_t *theirs = (uint32_t *)a.window[tid] + (b * EX_MAX_RANKS + a.rank);
+        __hip_atomic_store(theirs, a.call, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        uint32_t *flag = (uint32_t *)a.window[a.rank] + (b * EX_MAX_RANKS + tid);
+        const long long t0 = wall_clock64();
+        while ((int32_t)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - a.call) < 0) {
+            if (wall_clock64() - t0 > a.wait_ticks) {
+                failed = 1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    failed = __syncthreads_or(failed);
+    if (failed) {
+        if (tid == 0) __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+
+    // 3. add the windows up, rank 0 first; the loads of eight ranks are in flight together (one trip over
+    // xGMI per eight ranks, not one per rank and element)
+    double acc[PER];
+#pragma unroll
+    for (int e = 0; e < PER; ++e) acc[e] = 0.0;
+    for (int r0 = 0; r0 < a.world; r0 += 8) {
+        double v[8][PER];
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const int r = r0 + rr < a.world ? r0 + rr : a.world - 1;      // beyond the last rank: a valid address, value unused
+            const double *slot = (const double *)(a.window[r] + slot_off);
+#pragma unroll
+            for (int e = 0; e < PER; ++e) {
+                const int64_t i = lo + tid + e * EX_BLOCK;
+                v[rr][e] = __hip_atomic_load(slot + (i < hi ? i : lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+            for (int e = 0; e < PER; ++e)
+                if (r0 + rr < a.world) acc[e] += v[rr][e];
+    }
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+        const int64_t i = lo + tid + e * EX_BLOCK;
+        if (i < hi) a.buf[i] = acc[e];
+    }
+}
+
+}  // namespace ba
+
+struct ba_exchange {
+    int device = 0, rank = 0, world = 1;
+    int64_t capacity = 0;
+    char *window[ba::EX_MAX_RANKS] = {};
+    bool opened[ba::EX_MAX_RANKS] = {};
+    uint32_t call = 0;
+    int *h_status = nullptr;                      // pinned, device-visible
+    double wait_seconds = 2.0;
+};
+
+extern "C" {
+
+int ba_exchange_create(int rank, int world, int64_t capacity_doubles, ba_exchange **out) {
+    BA_REQUIRE(out, "ba_exchange_create: null output");
+    *out = nullptr;
+    BA_REQUIRE(world >= 1 && world <= ba::EX_MAX_RANKS && rank >= 0 && rank < world, "ba_exchange_create: rank / world out of range (at most 16 ranks)");
+    BA_REQUIRE(capacity_doubles >= 1 && capacity_doubles <= (int64_t)ba::EX_MAX_BLOCKS * ba::EX_CHUNK,
+               "ba_exchange_create: capacity out of range (1 .. 262144 doubles)");
+    ba_exchange *x = new ba_exchange;
+    x->rank = rank;
+    x->world = world;
+    x->capacity = capacity_doubles;
+    hipError_t e = hipGetDevice(&x->device);
+    const size_t bytes = ba::EX_FLAG_BYTES + 2 * sizeof(double) * (size_t)capacity_doubles;
+    void *w = nullptr;
+    if (e == hipSuccess) e = hipExtMallocWithFlags(&w, bytes, hipDeviceMallocUncached);
+    if (e == hipSuccess) e = hipMemset(w, 0, bytes);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&x->h_status, sizeof(int), hipHostMallocMapped);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        if (w) (void)hipFree(w);
+        if (x->h_status) (void)hipHostFree(x->h_status);
+        delete x;
+        return ba::hip_fail(e, "ba_exchange_create", __FILE__, __LINE__);
+    }
+    *x->h_status = 0;
+    x->window[rank] = (char *)w;
+    *out = x;
+    return BA_OK;
+}
+
+int ba_exchange_export(ba_exchange *x, void *h_handle64) {
+    BA_REQUIRE(x && h_handle64, "ba_exchange_export: null argument");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+    hipIpcMemHandle_t h;
+    BA_HIP(hipIpcGetMemHandle(&h, x->window[x->rank]));
+    memcpy(h_handle64, &h, sizeof h);
+    return BA_OK;
+}
+
+int ba_exchange_import(ba_exchange *x, int rank, const void *h_handle64) {
+    BA_REQUIRE(x && h_handle64, "ba_exchange_import: null argument");
+    BA_REQUIRE(rank >= 0 && rank < x->world && rank != x->rank, "ba_exchange_import: rank out of range or own rank");
+    BA_REQUIRE(!x->opened[rank], "ba_exchange_import: window of this rank already mapped");
+    hipIpcMemHandle_t h;
+    memcpy(&h, h_handle64, sizeof h);
+    void *p = nullptr;
+    BA_HIP(hipSetDevice(x->device));
+    BA_HIP(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+    x->window[rank] = (char *)p;
+    x->opened[rank] = true;
+    return BA_OK;
+}
+
+int ba_exchange_sum(ba_exchange *x, double *buf, int64_t n, void *stream) {
+    BA_REQUIRE(x && buf, "ba_exchange_sum: null argument");
+    BA_REQUIRE(n >= 1 && n <= x->capacity, "ba_exchange_sum: length beyond the capacity of the windows");
+    for (int r = 0; r < x->world; ++r)
+        if (!x->window[r]) {
+            ba::set_error("ba_exchange_sum: window of rank " + std::to_string(r) + " not mapped");
+            return BA_ERR_STATE;
+        }
+    if (*x->h_status != 0) {
+        ba::set_error("ba_exchange_sum: an earlier call gave up waiting for another rank");
+        return BA_ERR_STATE;
+    }
+    ba::ExchangeArgs a;
+    for (int r = 0; r < ba::EX_MAX_RANKS; ++r) a.window[r] = x->window[r];
+    a.buf = buf;
+    a.n = n;
+    a.capacity = x->capacity;
+    a.rank = x->rank;
+    a.world = x->world;
+    a.call = ++x->call;
+    a.wait_ticks = (long long)(x->wait_seconds * 1e8);
+    a.status = x->h_status;
+    const int grid = (int)((n + ba::EX_CHUNK - 1) / ba::EX_CHUNK);
+    hipLaunchKernelGGL(ba::k_exchange_sum, dim3(grid), dim3(ba::EX_BLOCK), 0, (hipStream_t)stream, a);
+    BA_HIP(hipGetLastError());
+    return BA_OK;
+}
+
+int ba_exchange_status(ba_exchange *x) {
+    if (!x) return BA_ERR_ARG;
+    if (*x->h_status != 0) {
+        ba::set_error("ba_exchange: a call gave up waiting for another rank; sums since then are not valid");
+        return BA_ERR_STATE;
+    }
+    return BA_OK;
+}
+
+int ba_exchange_set_wait(ba_exchange *x, double seconds) {
+    BA_REQUIRE(x && seconds > 0.0 && seconds <= 30.0, "ba_exchange_set_wait: 0 < seconds <= 30");
+    x->wait_seconds = seconds;
+    return BA_OK;
+}
+
+void ba_exchange_destroy(ba_exchange *x) {
+    if (!x) return;
+    (void)hipSetDevice(x->device);
+    (void)hipDeviceSynchronize();
+    for (int r = 0; r < x->world; ++r)
+        if (r != x->rank && x->opened[r]) (void)hipIpcCloseMemHandle(x->window[r]);
+    if (x->window[x->rank]) (void)hipFree(x->window[x->rank]);
+    if (x->h_status) (void)hipHostFree(x->h_status);
+    delete x;
+}
+
+}  // extern "C"

@@ -11,7 +11,7 @@ import torch
 
 from . import _lib
 from ._lib import check, ptr, stream_ptr
-from .sharding import StreamAllReduce, allreduce_sum_
+from .sharding import NodeExchange, StreamAllReduce, allreduce_sum_
 
 F64 = torch.float64
 
@@ -109,6 +109,7 @@ class Shard:
         # one GPU) the buffers are staged through the host explicitly
         self._stage_reduce = self.distributed and torch.distributed.get_backend(group) == 'gloo'
         self._stream_allreduce = False     # not yet tried; then a StreamAllReduce or None (torch.distributed)
+        self._node_exchange = False        # not yet tried; then a NodeExchange (short sums inside one node) or None
         self._out_ptrs = [t.data_ptr() for t in (self.E_sum, self.gX, self.gC, self.gTheta, self.gphi)]
         self._E_host = C.c_double(0.0)
         # Several GPUs: the sums a deferred pass leaves for the camera step (camera-frame sums, per-tile partial
@@ -164,8 +165,18 @@ class Shard:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN, group=self.group)
         return bool(t.item() > 0.5)
 
+    # longest sum that goes through the node exchange (doubles): the camera-block sums of an iteration and of
+    # a J^T J pass at a few thousand cameras; longer ones (the Schur complement) are bandwidth-bound and stay
+    # with the collective library
+    NODE_EXCHANGE_CAPACITY = 131072
+
     def _sum_over_ranks(self, t):
-        if self._stream_allreduce is False:      # first use: every rank gets here in the same iteration
+        if self._node_exchange is False:         # first use: every rank gets here in the same iteration
+            self._node_exchange = NodeExchange.create(self.group, self.device, self.NODE_EXCHANGE_CAPACITY)
+        if self._node_exchange is not None and t.numel() <= self._node_exchange.capacity:
+            self._node_exchange(t, self.stream)
+            return
+        if self._stream_allreduce is False:
             self._stream_allreduce = None if self._stage_reduce else StreamAllReduce.create(self.group, self.device)
         if self._stream_allreduce is not None:
             self._stream_allreduce(t, self.stream)
@@ -195,6 +206,9 @@ class Shard:
         return self._table_cam is self.cam
 
     def close(self):
+        if getattr(self, '_node_exchange', None):
+            self._node_exchange.close()
+            self._node_exchange = None
         if getattr(self, 'handle', None):
             self.lib.ba_problem_destroy(self.handle)
             self.handle = None
@@ -284,11 +298,15 @@ class Shard:
         """E = sum r^2 / (2|V|) (p2w:612) of the latest `eval`, picked up from the host mailbox the
         GPU posts it to.  Does not wait for work queued after that pass."""
         check(self.lib.ba_wait_energy(self.handle, C.byref(self._E_host), self.stream))
+        if self._node_exchange:
+            self._node_exchange.check()
         return self._E_host.value / (2 * self.nV)
 
     def energy(self):
         """The same value through an 8-byte device-to-host copy that synchronises the stream."""
         check(self.lib.ba_fetch_double(self._out_ptrs[0], C.byref(self._E_host), self.stream))
+        if self._node_exchange:
+            self._node_exchange.check()
         return self._E_host.value / (2 * self.nV)
 
     def eval_kernel_ms(self):

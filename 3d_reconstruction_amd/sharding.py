@@ -144,3 +144,114 @@ class StreamAllReduce:
             return obj if float(same.item()) > 0.5 else None
         except Exception:
             return None
+
+
+class NodeExchange:
+    """Sum of a short fp64 device tensor over the ranks of ONE node by the library's own kernel
+    (`ba_exchange_sum`: every GPU publishes its vector in a window the others have mapped and adds the
+    windows up in rank order), queued on the caller's stream.  For the camera-block sum of an iteration
+    (~100 KB) a collective library is bound by its latency; this is one kernel with two trips over
+    xGMI.  `create` exchanges the window handles through torch.distributed, runs a trial sum against
+    torch.distributed's and returns None - callers stay with the collective library - whenever a
+    step fails on any rank (ranks on several nodes, no peer mapping, a wrong trial result)."""
+
+    created = 0          # exchanges set up successfully in this process
+
+    def __init__(self, lib, handle, capacity):
+        self._lib, self._handle, self.capacity = lib, handle, capacity
+
+    def __call__(self, t, stream):
+        import ctypes as C
+        from ._lib import check
+        st = stream if isinstance(stream, C.c_void_p) else C.c_void_p(stream)
+        check(self._lib.ba_exchange_sum(self._handle, C.c_void_p(t.data_ptr()), t.numel(), st))
+
+    def check(self):
+        """Raises if a call gave up waiting for another rank (read from host memory: no sync)."""
+        from ._lib import check
+        check(self._lib.ba_exchange_status(self._handle))
+
+    def close(self):
+        if self._handle is not None:
+            self._lib.ba_exchange_destroy(self._handle)
+            self._handle = None
+
+    @staticmethod
+    def _all_ok(flag, group, device, host):
+        t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64, device='cpu' if host else device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN, group=group)
+        return bool(t.item() > 0.5)
+
+    @classmethod
+    def create(cls, group, device, capacity):
+        import ctypes as C
+        import os
+        import socket
+        from ._lib import load
+        dist = torch.distributed
+        if os.environ.get('BA_NO_NODE_EXCHANGE'):
+            return None
+        host = dist.get_backend(group) == 'gloo'
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        handle, obj = C.c_void_p(), None
+        try:
+            lib = load()
+            names = [None] * world
+            dist.all_gather_object(names, socket.gethostname(), group=group)
+            ok = world <= 16 and len(set(names)) == 1
+            mine = (C.c_byte * 64)()
+            if ok:
+                with torch.cuda.device(device):
+                    ok = lib.ba_exchange_create(rank, world, int(capacity), C.byref(handle)) == 0 and \
+                        lib.ba_exchange_export(handle, mine) == 0
+            handles = [None] * world
+            dist.all_gather_object(handles, bytes(mine) if ok else None, group=group)
+            ok = ok and all(h is not None for h in handles)
+            if ok:
+                with torch.cuda.device(device):
+                    for r in range(world):
+                        if r != rank and lib.ba_exchange_import(handle, r, (C.c_byte * 64).from_buffer_copy(handles[r])) != 0:
+                            ok = False
+                            break
+            if cls._all_ok(ok, group, device, host):         # also the barrier before the first sum
+                obj = cls(lib, handle, int(capacity))
+                lib.ba_exchange_set_wait(handle, 0.5)
+                n = min(int(capacity), 3000)
+                a = torch.arange(1, n + 1, dtype=torch.float64, device=device) * (rank + 1) / 7.0
+                want = a.cpu() if host else a.clone()
+                dist.all_reduce(want, op=dist.ReduceOp.SUM, group=group)
+                # 40 calls queued back to back, as the fit loop queues them (no host sync in between: the
+                # two slots are reused under GPU-side ordering only), each checked against the collective's sum
+                outs, b = [], a
+                try:                                 # a failure of this rank must not keep it from the collectives below
+                    with torch.cuda.device(device):
+                        for k in range(40):
+                            b = a * float(k + 1)
+                            obj(b, torch.cuda.current_stream().cuda_stream)
+                            outs.append(b)
+                    torch.cuda.synchronize(device)
+                    good = lib.ba_exchange_status(handle) == 0 and len(outs) == 40
+                    for k, o in enumerate(outs):     # rank order against the collective's order: equal up to rounding
+                        good = good and bool(torch.allclose(o.cpu(), want.cpu() * float(k + 1), rtol=1e-13, atol=0.0))
+                except Exception:
+                    good = False
+                good = cls._all_ok(good, group, device, host)
+                if good:
+                    same = b.clone() if not host else b.cpu()
+                    dist.broadcast(same, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+                    good = bool(torch.equal(same.cpu(), b.cpu()))       # identical bits on every rank
+                    good = cls._all_ok(good, group, device, host)
+                if good:
+                    lib.ba_exchange_set_wait(handle, 2.0)
+                    cls.created += 1
+                    return obj
+        except Exception:
+            pass
+        if obj is not None:
+            obj.close()
+        elif handle:
+            try:
+                load().ba_exchange_destroy(handle)
+            except Exception:
+                pass
+        return None

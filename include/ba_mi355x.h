@@ -270,6 +270,23 @@ int ba_subscenes_step(int64_t P, int rule, double lr, double bc1, double bc2, do
 int ba_subscenes_transform(int64_t P, int64_t n_entries, const int32_t *entry_subscene, const double *entry_x,
                            const double *params, double *table_work, double *x_new, void *stream);
 
+/* ---- sum over the GPUs of one node (the exchange step of the sharded fit loop; the reference runs on one
+ * device and has no counterpart; p2w:654-702 are the sums that are added up).  Every rank creates an exchange
+ * (a window of its GPU's memory: flags + two slots of `capacity_doubles`), hands the 64-byte handle of its
+ * window to the other ranks of the node (any host channel) and maps theirs; after a host barrier
+ * ba_exchange_sum replaces buf[0..n) by the sum over the ranks, in rank order (identical bits on every rank),
+ * as ONE kernel on `stream`: no collective library, no second stream.  All ranks must call it the same number of
+ * times with the same n.  A rank that waits longer than the limit (default 2 s) for another gives up: its buffer
+ * stays as it was, ba_exchange_status (and every later ba_exchange_sum) returns BA_ERR_STATE. */
+typedef struct ba_exchange ba_exchange;
+int ba_exchange_create(int rank, int world, int64_t capacity_doubles, ba_exchange **out);
+int ba_exchange_export(ba_exchange *x, void *h_handle64);
+int ba_exchange_import(ba_exchange *x, int rank, const void *h_handle64);
+int ba_exchange_sum(ba_exchange *x, double *buf, int64_t n, void *stream);
+int ba_exchange_status(ba_exchange *x);
+int ba_exchange_set_wait(ba_exchange *x, double seconds);
+void ba_exchange_destroy(ba_exchange *x);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,4 +1,4 @@
-"""Two ranks on ONE GPU (gloo carries the device tensors through the host): the multi-GPU sequence
+"""Two ranks on ONE GPU (sums over the ranks by the library's node exchange, or by gloo through the host): the multi-GPU sequence
 of the first-order loop and of the LM extension with real partitioning — each rank holds a point
 range, the camera-side blocks (and, for LM, the Schur complement) are summed across the ranks.
 Results must equal the reference's trace (golden F6) resp. the one-process LM run."""
@@ -30,8 +30,47 @@ def _lm_scene(ba):
     return ba.scenes.orbit_scene(N=300, K=80, track_len=8, seed=4)
 
 
-def _worker(rank, world, port, out_dir):
+def _exchange_checks(ba, rank, world):
+    """The node exchange on its own: lengths around the workgroup chunk, many calls in a row (both slots),
+    sums in rank order with identical bits on every rank; then a rank that calls alone gives up and says so."""
+    sharding = importlib.import_module('3d_reconstruction_amd.sharding')
+    _lib = importlib.import_module('3d_reconstruction_amd._lib')
+    ex = sharding.NodeExchange.create(None, torch.device('cuda:0'), 5000)
+    assert ex is not None
+    st = torch.cuda.current_stream().cuda_stream
+    call = 0
+    for n in (1, 7, 1023, 1024, 1025, 4097, 5000):
+        for _ in range(3):
+            call += 1
+            parts = [torch.from_numpy(np.random.default_rng(1000 * call + r).normal(0, 1e3, n)) for r in range(world)]
+            want = parts[0].clone()
+            for r in range(1, world):
+                want += parts[r]
+            t = parts[rank].to('cuda:0')
+            ex(t, st)
+            assert torch.equal(t.cpu(), want), (n, call)
+    ex.check()
+    with pytest.raises(_lib.BAError):
+        ex(torch.zeros(5001, dtype=torch.float64, device='cuda:0'), st)        # beyond the capacity
+    dist.barrier()
+    if rank == 0:                       # nobody else calls: the wait runs out, the buffer stays, the status says so
+        _lib.check(ex._lib.ba_exchange_set_wait(ex._handle, 0.2))
+        t = torch.full((10,), 3.0, dtype=torch.float64, device='cuda:0')
+        ex(t, st)
+        torch.cuda.synchronize()
+        assert torch.equal(t.cpu(), torch.full((10,), 3.0, dtype=torch.float64))
+        with pytest.raises(_lib.BAError):
+            ex.check()
+        with pytest.raises(_lib.BAError):
+            ex(t, st)
+    dist.barrier()
+    ex.close()
+
+
+def _worker(rank, world, port, out_dir, exchange):
     sys.path.insert(0, ROOT)
+    if not exchange:
+        os.environ['BA_NO_NODE_EXCHANGE'] = '1'
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -45,15 +84,20 @@ def _worker(rank, world, port, out_dir):
         sc = _lm_scene(ba)
         lm = ba.fit_scene_sparse(sc['i'], sc['j'], sc['uv'], sc['N_local'], sc['K'], sc['W'], sc['H'], 1e-3, 6,
                                  sc['X_0'], sc['C_0'], sc['Theta_0'], sc['phi_x_0'], optimizer='LM', **quiet)
+        sharding = importlib.import_module('3d_reconstruction_amd.sharding')
+        assert sharding.NodeExchange.created == (2 if exchange else 0)        # one per fit
+        if exchange:
+            _exchange_checks(ba, rank, world)
         np.savez(os.path.join(out_dir, f'rank{rank}.npz'), X=X, C=C, Th=Th, phi=phi, E=E, lm_X=lm[0], lm_C=lm[1],
                  lm_Th=lm[2], lm_phi=lm[3], lm_E=lm[4])
     finally:
         dist.destroy_process_group()
 
 
-def test_two_ranks_share_one_gpu(ba, tmp_path):
+@pytest.mark.parametrize('exchange', [True, False], ids=['node exchange', 'sums through the host'])
+def test_two_ranks_share_one_gpu(ba, tmp_path, exchange):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), exchange), nprocs=world, join=True)
     r0, r1 = np.load(tmp_path / 'rank0.npz'), np.load(tmp_path / 'rank1.npz')
     for key in r0.files:       # replicated state and gathered points are identical on both ranks
         assert np.array_equal(r0[key], r1[key]), key
