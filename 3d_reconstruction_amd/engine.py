@@ -172,7 +172,7 @@ class Shard:
 
     def _sum_over_ranks(self, t):
         if self._node_exchange is False:         # first use: every rank gets here in the same iteration
-            self._node_exchange = NodeExchange.create(self.group, self.device, self.NODE_EXCHANGE_CAPACITY)
+            self._node_exchange = NodeExchange.shared(self.group, self.device, self.NODE_EXCHANGE_CAPACITY)
         if self._node_exchange is not None and t.numel() <= self._node_exchange.capacity:
             self._node_exchange(t, self.stream)
             return
@@ -206,9 +206,7 @@ class Shard:
         return self._table_cam is self.cam
 
     def close(self):
-        if getattr(self, '_node_exchange', None):
-            self._node_exchange.close()
-            self._node_exchange = None
+        self._node_exchange = None          # the exchange belongs to the process, not to the shard
         if getattr(self, 'handle', None):
             self.lib.ba_problem_destroy(self.handle)
             self.handle = None

@@ -157,14 +157,37 @@ class NodeExchange:
 
     created = 0          # exchanges set up successfully in this process
 
+    _shared = {}         # (device index, capacity) -> (process group, exchange or None)
+
     def __init__(self, lib, handle, capacity):
         self._lib, self._handle, self.capacity = lib, handle, capacity
+        self._last_stream = None
 
     def __call__(self, t, stream):
         import ctypes as C
         from ._lib import check
         st = stream if isinstance(stream, C.c_void_p) else C.c_void_p(stream)
+        if self._last_stream is not None and self._last_stream != st.value:
+            # a call starts only after the previous one has finished on this GPU: guaranteed by the stream's
+            # order as long as the stream stays the same
+            torch.cuda.synchronize(t.device)
+        self._last_stream = st.value
         check(self._lib.ba_exchange_sum(self._handle, C.c_void_p(t.data_ptr()), t.numel(), st))
+
+    @classmethod
+    def shared(cls, group, device, capacity):
+        """The exchange of this process for (group, device), set up on first use (None if that failed: not
+        tried again).  It lives until the process ends: a rank cannot know when the others have finished
+        reading its window, so the window is never freed while the group is alive.  Every rank of the group
+        must ask for it at the same point of the program."""
+        dist = torch.distributed
+        pg = group if group is not None else dist.distributed_c10d._get_default_group()
+        key = (torch.device(device).index, int(capacity))
+        hit = cls._shared.get(key)
+        if hit is None or hit[0] is not pg:
+            hit = (pg, cls.create(group, device, capacity))
+            cls._shared[key] = hit
+        return hit[1]
 
     def check(self):
         """Raises if a call gave up waiting for another rank (read from host memory: no sync)."""
@@ -172,6 +195,8 @@ class NodeExchange:
         check(self._lib.ba_exchange_status(self._handle))
 
     def close(self):
+        """Frees the window.  Only safe once every rank has finished its last sum (a barrier after a device
+        synchronisation on every rank): the others read this rank's window from inside their kernels."""
         if self._handle is not None:
             self._lib.ba_exchange_destroy(self._handle)
             self._handle = None
@@ -225,6 +250,11 @@ class NodeExchange:
                 outs, b = [], a
                 try:                                 # a failure of this rank must not keep it from the collectives below
                     with torch.cuda.device(device):
+                        first = a.clone()            # one call on its own: a rank that cannot see the others' flags
+                        obj(first, torch.cuda.current_stream().cuda_stream)       # is found out after one wait
+                        torch.cuda.synchronize(device)
+                        if lib.ba_exchange_status(handle) != 0:
+                            raise RuntimeError('no answer from the other ranks')
                         for k in range(40):
                             b = a * float(k + 1)
                             obj(b, torch.cuda.current_stream().cuda_stream)
@@ -242,7 +272,7 @@ class NodeExchange:
                     good = bool(torch.equal(same.cpu(), b.cpu()))       # identical bits on every rank
                     good = cls._all_ok(good, group, device, host)
                 if good:
-                    lib.ba_exchange_set_wait(handle, 2.0)
+                    lib.ba_exchange_set_wait(handle, 20.0)
                     cls.created += 1
                     return obj
         except Exception:
