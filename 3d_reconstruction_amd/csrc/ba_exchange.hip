@@ -179,6 +179,13 @@ int ba_exchange_import(ba_exchange *x, int rank, const void *h_handle64) {
     void *p = nullptr;
     BA_HIP(hipSetDevice(x->device));
     BA_HIP(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+    // a mapping the runtime cannot read through must not reach a kernel: probe it with a copy first
+    uint32_t probe = 0;
+    hipError_t e = hipMemcpy(&probe, p, sizeof probe, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+        (void)hipIpcCloseMemHandle(p);
+        return ba::hip_fail(e, "ba_exchange_import: probe of the mapped window", __FILE__, __LINE__);
+    }
     x->window[rank] = (char *)p;
     x->opened[rank] = true;
     return BA_OK;
