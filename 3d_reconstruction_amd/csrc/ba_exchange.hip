@@ -1,18 +1,19 @@
 // Sum of a short fp64 vector over the GPUs of one node without a collective library: every GPU
-// publishes its vector in a window of its own memory that the other GPUs have mapped (HIP IPC), a
-// flag exchange tells when all windows are filled, and every GPU adds the windows up in rank order
-// (the same order everywhere: all ranks end with bit-identical sums).  One kernel, one trip over
-// xGMI for the flags and one for the data; meant for the per-iteration camera-block sum of the fit
+// publishes its vector in a window of its own memory that the other GPUs have mapped (HIP IPC) and
+// adds up all windows in rank order (the same order everywhere: all ranks end with bit-identical
+// sums).  One kernel and one trip over xGMI; meant for the per-iteration camera-block sum of the fit
 // loop (~100 KB), where a ring or tree collective is bound by its latency.
 //
-// Window (memory allocated "uncached", so that stores go out to memory and loads of another GPU
-// never meet a stale line):
-//   flags  uint32 [EX_MAX_BLOCKS][EX_MAX_RANKS]   flag[b][r] = last call whose block b rank r has published
-//   slots  double [2][capacity]                   call e uses slot e & 1
-// A rank can overwrite slot e & 1 (in call e + 2) only after it has passed the flag exchange of call
-// e + 1, i.e. after every other rank has launched call e + 1, which its stream starts only after its
-// kernel of call e has finished reading: two slots are enough, and no second flag exchange is needed
-// at the end of a call.
+// Window: double slots[4][capacity] of "uncached" memory (stores go out to memory, loads of another
+// GPU never meet a stale line).  Call c uses slot c % 4.  There are no flags: an element that has not
+// been published yet holds EMPTY, a signalling-NaN pattern no arithmetic produces (a value with
+// exactly these bits is published as the canonical quiet NaN), and a reader polls the element itself -
+// aligned 8-byte stores arrive whole.  Slots are set back to EMPTY two calls after their use: a GPU that
+// starts call c has finished call c - 1, for which it has read every rank's elements of call c - 1; those
+// ranks had therefore finished call c - 2 (calls of one exchange run one after the other on a GPU), so
+// nobody reads the slot of call c - 2 any more and the kernel of call c clears it in the own window, over
+// the length that call had.  The slot is used again by call c + 2; a rank that looks at it then has seen this
+// GPU's call c + 1, whose kernel started after the kernel of call c - and with it the clearing - was complete.
 #include <hip/hip_runtime.h>
 
 #include <cstring>
@@ -27,15 +28,18 @@ constexpr int EX_MAX_RANKS = 16;
 constexpr int EX_MAX_BLOCKS = 256;
 constexpr int EX_BLOCK = 256;
 constexpr int EX_CHUNK = 1024;                    // doubles one workgroup publishes and sums
-constexpr size_t EX_FLAG_BYTES = sizeof(uint32_t) * EX_MAX_BLOCKS * EX_MAX_RANKS;
+constexpr int EX_SLOTS = 4;
+constexpr uint32_t EX_EMPTY_HALF = 0x7ff4a5a5u;   // both halves of EMPTY (the window is filled 32 bits at a time)
+constexpr uint64_t EX_EMPTY = ((uint64_t)EX_EMPTY_HALF << 32) | EX_EMPTY_HALF;
+constexpr uint64_t EX_QUIET_NAN = 0x7ff8000000000000ull;
 
 struct ExchangeArgs {
     char *window[EX_MAX_RANKS];                   // window[rank] is this GPU's own
     double *buf;
-    int64_t n, capacity;
+    int64_t n, n_old, capacity;                   // n_old: length of the call two calls ago (0: none)
     int rank, world;
     uint32_t call;
-    long long wait_ticks;                         // upper bound for the flag wait (wall_clock64 ticks, 100 MHz)
+    long long wait_ticks;                         // upper bound for the wait (wall_clock64 ticks, 100 MHz)
     int *status;                                  // host memory: set to 1 when a wait ran out
 };
 
@@ -43,14 +47,26 @@ __global__ void __launch_bounds__(EX_BLOCK) k_exchange_sum(ExchangeArgs a) {
     const int b = blockIdx.x, tid = threadIdx.x;
     const int64_t lo = (int64_t)b * EX_CHUNK;
     const int64_t hi = lo + EX_CHUNK < a.n ? lo + EX_CHUNK : a.n;
-    const size_t slot_off = EX_FLAG_BYTES + sizeof(double) * (size_t)(a.call & 1u) * (size_t)a.capacity;
-
-    // 1. publish this workgroup's chunk.  The window is uncached memory and every access to it is a system-scope
-    // atomic (the access goes to memory, past both cache levels), so no cache has to be written back or
-    // invalidated: a fence of system scope would write back the whole L2, which is full of the pass's point
-    // state at this moment.  Waiting for the stores' completion is all the ordering the flag needs.
+    const size_t slot_off = sizeof(double) * (size_t)(a.call % EX_SLOTS) * (size_t)a.capacity;
+    const size_t old_off = sizeof(double) * (size_t)((a.call + 2) % EX_SLOTS) * (size_t)a.capacity;
     constexpr int PER = EX_CHUNK / EX_BLOCK;                    // elements per thread
-    double *mine = (double *)(a.window[a.rank] + slot_off);
+
+    // 0. clear the slot of the call before the previous one (the grid covers the longer of the two lengths)
+    {
+        uint64_t *old_slot = (uint64_t *)(a.window[a.rank] + old_off);
+        const int64_t old_hi = lo + EX_CHUNK < a.n_old ? lo + EX_CHUNK : a.n_old;
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const int64_t i = lo + tid + e * EX_BLOCK;
+            if (i < old_hi) __hip_atomic_store(old_slot + i, EX_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    if (lo >= a.n) return;
+
+    // 1. publish.  Every access to a window is a system-scope atomic on uncached memory (it goes to memory,
+    // past both cache levels): no cache has to be written back or invalidated, and no fence is needed - a fence
+    // of system scope would write back the whole L2, which is full of the pass's point state at this moment.
+    uint64_t *mine = (uint64_t *)(a.window[a.rank] + slot_off);
     {
         double v[PER];
 #pragma unroll
@@ -61,55 +77,54 @@ __global__ void __launch_bounds__(EX_BLOCK) k_exchange_sum(ExchangeArgs a) {
 #pragma unroll
         for (int e = 0; e < PER; ++e) {
             const int64_t i = lo + tid + e * EX_BLOCK;
-            if (i < hi) __hip_atomic_store(mine + i, v[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            uint64_t bits = (uint64_t)__double_as_longlong(v[e]);
+            if (bits == EX_EMPTY) bits = EX_QUIET_NAN;
+            if (i < hi) __hip_atomic_store(mine + i, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this thread's stores have been acknowledged by memory
-    __syncthreads();
 
-    // 2. tell every rank, then wait for every rank (bounded: a rank that never arrives must not hang the GPU)
+    // 2. read every rank's elements until none is EMPTY (bounded: a rank that never arrives must not hang the
+    // GPU), eight ranks' loads in flight together, and add them up, rank 0 first
+    double acc[PER];
+#pragma unroll
+    for (int e = 0; e < PER; ++e) acc[e] = 0.0;
     int failed = 0;
-    if (tid < a.world) {
-        uint32_t *theirs = (uint32_t *)a.window[tid] + (b * EX_MAX_RANKS + a.rank);
-        __hip_atomic_store(theirs, a.call, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        uint32_t *flag = (uint32_t *)a.window[a.rank] + (b * EX_MAX_RANKS + tid);
-        const long long t0 = wall_clock64();
-        while ((int32_t)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - a.call) < 0) {
+    const long long t0 = wall_clock64();
+    for (int r0 = 0; r0 < a.world && !failed; r0 += 8) {
+        uint64_t v[8][PER];
+        for (;;) {
+            bool all = true;
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                const int r = r0 + rr < a.world ? r0 + rr : a.world - 1;      // beyond the last rank: a valid address, value unused
+                const uint64_t *slot = (const uint64_t *)(a.window[r] + slot_off);
+#pragma unroll
+                for (int e = 0; e < PER; ++e) {
+                    const int64_t i = lo + tid + e * EX_BLOCK;
+                    v[rr][e] = __hip_atomic_load(slot + (i < hi ? i : lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+                for (int e = 0; e < PER; ++e)
+                    if (r0 + rr < a.world && lo + tid + e * EX_BLOCK < hi && v[rr][e] == EX_EMPTY) all = false;
+            if (all) break;
             if (wall_clock64() - t0 > a.wait_ticks) {
                 failed = 1;
                 break;
             }
             __builtin_amdgcn_s_sleep(1);
         }
-    }
-    failed = __syncthreads_or(failed);
-    if (failed) {
-        if (tid == 0) __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        return;
-    }
-
-    // 3. add the windows up, rank 0 first; the loads of eight ranks are in flight together (one trip over
-    // xGMI per eight ranks, not one per rank and element)
-    double acc[PER];
-#pragma unroll
-    for (int e = 0; e < PER; ++e) acc[e] = 0.0;
-    for (int r0 = 0; r0 < a.world; r0 += 8) {
-        double v[8][PER];
-#pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {
-            const int r = r0 + rr < a.world ? r0 + rr : a.world - 1;      // beyond the last rank: a valid address, value unused
-            const double *slot = (const double *)(a.window[r] + slot_off);
-#pragma unroll
-            for (int e = 0; e < PER; ++e) {
-                const int64_t i = lo + tid + e * EX_BLOCK;
-                v[rr][e] = __hip_atomic_load(slot + (i < hi ? i : lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr)
 #pragma unroll
             for (int e = 0; e < PER; ++e)
-                if (r0 + rr < a.world) acc[e] += v[rr][e];
+                if (r0 + rr < a.world) acc[e] += __longlong_as_double((long long)v[rr][e]);
+    }
+    if (failed) {            // the buffer stays as it was (the exchange is dead from here on)
+        __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
     }
 #pragma unroll
     for (int e = 0; e < PER; ++e) {
@@ -126,6 +141,7 @@ struct ba_exchange {
     char *window[ba::EX_MAX_RANKS] = {};
     bool opened[ba::EX_MAX_RANKS] = {};
     uint32_t call = 0;
+    int64_t n_hist[2] = {0, 0};                   // lengths of the last call and of the one before
     int *h_status = nullptr;                      // pinned, device-visible
     double wait_seconds = 2.0;
 };
@@ -143,10 +159,10 @@ int ba_exchange_create(int rank, int world, int64_t capacity_doubles, ba_exchang
     x->world = world;
     x->capacity = capacity_doubles;
     hipError_t e = hipGetDevice(&x->device);
-    const size_t bytes = ba::EX_FLAG_BYTES + 2 * sizeof(double) * (size_t)capacity_doubles;
+    const size_t bytes = ba::EX_SLOTS * sizeof(double) * (size_t)capacity_doubles;
     void *w = nullptr;
     if (e == hipSuccess) e = hipExtMallocWithFlags(&w, bytes, hipDeviceMallocUncached);
-    if (e == hipSuccess) e = hipMemset(w, 0, bytes);
+    if (e == hipSuccess) e = hipMemsetD32((hipDeviceptr_t)w, (int)ba::EX_EMPTY_HALF, bytes / sizeof(uint32_t));
     if (e == hipSuccess) e = hipHostMalloc((void **)&x->h_status, sizeof(int), hipHostMallocMapped);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
@@ -207,13 +223,17 @@ int ba_exchange_sum(ba_exchange *x, double *buf, int64_t n, void *stream) {
     for (int r = 0; r < ba::EX_MAX_RANKS; ++r) a.window[r] = x->window[r];
     a.buf = buf;
     a.n = n;
+    a.n_old = x->n_hist[1];
+    x->n_hist[1] = x->n_hist[0];
+    x->n_hist[0] = n;
     a.capacity = x->capacity;
     a.rank = x->rank;
     a.world = x->world;
     a.call = ++x->call;
     a.wait_ticks = (long long)(x->wait_seconds * 1e8);
     a.status = x->h_status;
-    const int grid = (int)((n + ba::EX_CHUNK - 1) / ba::EX_CHUNK);
+    const int64_t covered = n > a.n_old ? n : a.n_old;
+    const int grid = (int)((covered + ba::EX_CHUNK - 1) / ba::EX_CHUNK);
     hipLaunchKernelGGL(ba::k_exchange_sum, dim3(grid), dim3(ba::EX_BLOCK), 0, (hipStream_t)stream, a);
     BA_HIP(hipGetLastError());
     return BA_OK;
