@@ -67,6 +67,7 @@ __global__ void __launch_bounds__(EX_BLOCK) k_exchange_sum(ExchangeArgs a) {
     // past both cache levels): no cache has to be written back or invalidated, and no fence is needed - a fence
     // of system scope would write back the whole L2, which is full of the pass's point state at this moment.
     uint64_t *mine = (uint64_t *)(a.window[a.rank] + slot_off);
+    uint64_t own[PER];
     {
         double v[PER];
 #pragma unroll
@@ -77,9 +78,9 @@ __global__ void __launch_bounds__(EX_BLOCK) k_exchange_sum(ExchangeArgs a) {
 #pragma unroll
         for (int e = 0; e < PER; ++e) {
             const int64_t i = lo + tid + e * EX_BLOCK;
-            uint64_t bits = (uint64_t)__double_as_longlong(v[e]);
-            if (bits == EX_EMPTY) bits = EX_QUIET_NAN;
-            if (i < hi) __hip_atomic_store(mine + i, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            own[e] = (uint64_t)__double_as_longlong(v[e]);
+            if (own[e] == EX_EMPTY) own[e] = EX_QUIET_NAN;
+            if (i < hi) __hip_atomic_store(mine + i, own[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 
@@ -102,6 +103,10 @@ __global__ void __launch_bounds__(EX_BLOCK) k_exchange_sum(ExchangeArgs a) {
                 for (int e = 0; e < PER; ++e) {
                     const int64_t i = lo + tid + e * EX_BLOCK;
                     v[rr][e] = __hip_atomic_load(slot + (i < hi ? i : lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                if (r == a.rank) {      // the own elements come from the registers: no wait for the own stores to land
+#pragma unroll
+                    for (int e = 0; e < PER; ++e) v[rr][e] = own[e];
                 }
             }
 #pragma unroll
