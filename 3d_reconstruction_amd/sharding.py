@@ -3,7 +3,9 @@
 Observations are independent and the energy is a plain sum, so the path shards by POINT
 ranges: a rank owns a contiguous block of points, all their observations, their gradients and
 optimiser moments.  Cameras and phi_x are replicated; the camera-side sums and the energy are
-the one thing exchanged (one all-reduce per evaluation, engine.Shard.eval)."""
+the one thing exchanged (one sum over the ranks per evaluation, engine.Shard.eval): inside a node
+by the library's own exchange kernel (NodeExchange), otherwise by RCCL on the caller's stream
+(StreamAllReduce) or through torch.distributed."""
 from __future__ import annotations
 
 import numpy as np
