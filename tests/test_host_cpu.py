@@ -48,6 +48,11 @@ def test_argument_errors_need_no_gpu():
     assert lib.ba_adam_step(5, None, None, None, None, 1e-3, 1.0, 0.1, 0.001, None, None) == -1
     with pytest.raises(ba_lib.BAError, match='null pointer'):
         ba_lib.check(lib.ba_sgd_step(5, None, None, 1e-3, 1.0, None, None))
+    # node exchange: limits are checked before anything touches a device
+    assert lib.ba_exchange_create(0, 17, 1000, ctypes.byref(out)) == -1 and b'16 ranks' in lib.ba_last_error()
+    assert lib.ba_exchange_create(2, 2, 1000, ctypes.byref(out)) == -1
+    assert lib.ba_exchange_create(0, 2, 262145, ctypes.byref(out)) == -1 and b'capacity' in lib.ba_last_error()
+    assert lib.ba_exchange_sum(None, None, 5, None) == -1 and lib.ba_exchange_status(None) == -1
 
 
 def test_no_cpu_fallback_in_product_package():
