@@ -8,8 +8,12 @@ by the library's own exchange kernel (NodeExchange), otherwise by RCCL on the ca
 (StreamAllReduce) or through torch.distributed."""
 from __future__ import annotations
 
+import ctypes as C
+
 import numpy as np
 import torch
+
+from ._lib import check, load
 
 
 def partition_points(obs_i, N, world):
@@ -166,8 +170,6 @@ class NodeExchange:
         self._last_stream = None
 
     def __call__(self, t, stream):
-        import ctypes as C
-        from ._lib import check
         st = stream if isinstance(stream, C.c_void_p) else C.c_void_p(stream)
         if self._last_stream is not None and self._last_stream != st.value:
             # a call starts only after the previous one has finished on this GPU: guaranteed by the stream's
@@ -193,7 +195,6 @@ class NodeExchange:
 
     def check(self):
         """Raises if a call gave up waiting for another rank (read from host memory: no sync)."""
-        from ._lib import check
         check(self._lib.ba_exchange_status(self._handle))
 
     def close(self):
@@ -211,10 +212,8 @@ class NodeExchange:
 
     @classmethod
     def create(cls, group, device, capacity):
-        import ctypes as C
         import os
         import socket
-        from ._lib import load
         dist = torch.distributed
         if os.environ.get('BA_NO_NODE_EXCHANGE'):
             return None
