@@ -188,6 +188,19 @@ class Shard:
         else:
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM, group=self.group)
 
+    @property
+    def rank_sum_path(self):
+        """How the short sums over the ranks travel (known after the first one)."""
+        if not self.distributed:
+            return 'single rank'
+        if self._node_exchange:
+            return 'node exchange kernel (xGMI windows)'
+        if self._node_exchange is False:
+            return 'not used yet'
+        if self._stream_allreduce:
+            return 'RCCL all-reduce on the compute stream'
+        return 'gloo through the host' if self._stage_reduce else 'torch.distributed all-reduce'
+
     # views of the current camera buffer
     @property
     def C(self):

@@ -149,6 +149,7 @@ def main():
                                    f'camera-block all-reduce + Adam + gauge fix), gradient-only pass',
                        'points': N_total, 'cameras': K, 'observations': nv_total,
                        'parallelism': f'point-sharded x{world}, cameras replicated',
+                       'sum_over_ranks': sh.rank_sum_path,
                        'energy_first_timed': E_first, 'energy_last_timed': E_last},
             'roofline': {'bound': 'hbm', 'kernel': 'ba::k_run_pass<ba::GradOp, ba::RecI16> (fused observation pass, gradient + point update)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

@@ -25,6 +25,6 @@ for forced, how in ((False, ''), (True, 'node exchange'), (True, 'RCCL on the st
         fit.step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 200
-    print(f'distributed sequence forced={forced} {how}: {dt*1e6:.1f} us per iteration, E={fit.E[499]:.12f}', flush=True)
+    print(f'distributed sequence forced={forced} {how}: {dt*1e6:.1f} us per iteration, E={fit.E[499]:.12f} [{sh.rank_sum_path}]', flush=True)
     sh.close()
 dist.destroy_process_group()
