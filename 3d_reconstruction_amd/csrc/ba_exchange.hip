@@ -93,27 +93,30 @@ __global__ void __launch_bounds__(EX_BLOCK) k_exchange_sum(ExchangeArgs a) {
     const long long t0 = wall_clock64();
     for (int r0 = 0; r0 < a.world && !failed; r0 += 8) {
         uint64_t v[8][PER];
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+            for (int e = 0; e < PER; ++e) {
+                const bool wanted = r0 + rr < a.world && lo + tid + e * EX_BLOCK < hi;
+                v[rr][e] = !wanted ? 0 : r0 + rr == a.rank ? own[e] : EX_EMPTY;       // the own elements come from the registers
+            }
         for (;;) {
-            bool all = true;
+            // only what is still missing is asked for again: a round of loads is a megabyte over xGMI per GPU
 #pragma unroll
             for (int rr = 0; rr < 8; ++rr) {
-                const int r = r0 + rr < a.world ? r0 + rr : a.world - 1;      // beyond the last rank: a valid address, value unused
+                const int r = r0 + rr < a.world ? r0 + rr : a.world - 1;
                 const uint64_t *slot = (const uint64_t *)(a.window[r] + slot_off);
 #pragma unroll
-                for (int e = 0; e < PER; ++e) {
-                    const int64_t i = lo + tid + e * EX_BLOCK;
-                    v[rr][e] = __hip_atomic_load(slot + (i < hi ? i : lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                }
-                if (r == a.rank) {      // the own elements come from the registers: no wait for the own stores to land
-#pragma unroll
-                    for (int e = 0; e < PER; ++e) v[rr][e] = own[e];
-                }
+                for (int e = 0; e < PER; ++e)
+                    if (v[rr][e] == EX_EMPTY)
+                        v[rr][e] = __hip_atomic_load(slot + (lo + tid + e * EX_BLOCK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
+            bool all = true;
 #pragma unroll
             for (int rr = 0; rr < 8; ++rr)
 #pragma unroll
                 for (int e = 0; e < PER; ++e)
-                    if (r0 + rr < a.world && lo + tid + e * EX_BLOCK < hi && v[rr][e] == EX_EMPTY) all = false;
+                    if (v[rr][e] == EX_EMPTY) all = false;
             if (all) break;
             if (wall_clock64() - t0 > a.wait_ticks) {
                 failed = 1;
