@@ -31,7 +31,7 @@ def measured_traffic(points_per_gpu, cameras, track_len):
     """HBM bytes per launch of the observation-pass kernel from the committed rocprofv3 PMC passes
     (FETCH_SIZE / WRITE_SIZE, corrected as profiles/summarize_pmc.py documents); only for the
     workload those passes were taken on, else None."""
-    path = os.path.join(ROOT, 'profiles', 'r01j_pmc_traffic_cfg3.json')
+    path = os.path.join(ROOT, 'profiles', 'r01m_pmc_traffic_cfg3.json')
     if (points_per_gpu, cameras, track_len) != (1_000_000, 2000, 10) or not os.path.exists(path):
         return None
     with open(path) as fh:
