@@ -130,7 +130,8 @@ __global__ void __launch_bounds__(EX_BLOCK) k_exchange_sum(ExchangeArgs a) {
             for (int e = 0; e < PER; ++e)
                 if (r0 + rr < a.world) acc[e] += __longlong_as_double((long long)v[rr][e]);
     }
-    if (failed) {            // the buffer stays as it was (the exchange is dead from here on)
+    if (failed) {            // this workgroup's chunk stays as it was, others may already hold sums: the buffer is
+                             // undefined after a failed call (the exchange is dead from here on)
         __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
     }

@@ -61,6 +61,8 @@ class Shard:
     def __init__(self, oi, oj, uv, N, K, W, H, device, n_visible_total=None, group=None, reorder=True):
         self.lib = _lib.load()
         self.device = torch.device(device)
+        if self.device.type == 'cuda' and self.device.index is None:     # 'cuda' means the current device, not GPU 0
+            self.device = torch.device('cuda', torch.cuda.current_device())
         self.N, self.K, self.W, self.H = int(N), int(K), float(W), float(H)
         oi = _dev_tensor(oi, torch.int32, self.device)
         oj = _dev_tensor(oj, torch.int32, self.device)
@@ -78,7 +80,7 @@ class Shard:
         handle = C.c_void_p()
         with torch.cuda.device(self.device):
             check(self.lib.ba_problem_create(self.N, self.K, self.nV_local, ptr(oi), ptr(oj), ptr(uv), self.W,
-                                             self.H, self.device.index or 0, C.byref(handle)))
+                                             self.H, self.device.index, C.byref(handle)))
         self.handle = handle
         K3 = 3 * self.K
         z = lambda *s: torch.zeros(*s, dtype=F64, device=self.device)

@@ -21,8 +21,13 @@ import numpy as np
 
 RHO_1, RHO_2 = 0.9, 0.999      # p2w:351-352
 
-# optimiser registry, looked up by name like the reference's gd_func_dict (p2w:362, 527, 705);
-# the values name the device update rule the shard runs.
+# optimiser registry, looked up by name like the reference's gd_func_dict (p2w:362, 527, 705).
+# A string value names the device update rule the shard runs.  A CALLABLE value is a user's update
+# rule with the reference's calling convention, `rule(x, grad, lr, **state) -> (x_new, new_state)`,
+# called once per free group in the order X, C, Theta, phi_x on host copies (p2w:704-708); as in the
+# reference (p2w:469-473) the state is {'s', 'r', 't'} under the name 'Adam' and empty under any other
+# name.  That is the slow path (parameters and gradients cross PCIe every iteration, nothing is queued
+# ahead); with several ranks the rule sees each rank's own block of X.
 gd_func_dict = {'SGD': 'ba_sgd_step', 'Adam': 'ba_adam_step'}
 
 # optimisers beyond the reference's registry, accepted by fit_scene(optimizer=...)
@@ -43,6 +48,10 @@ class SceneFit:
         if optimizer not in gd_func_dict:
             raise ValueError(f'Unkown name of the optmizer, choose one from {[key for key in gd_func_dict]}')
         self.sh = shard
+        rule = gd_func_dict[optimizer]
+        self.host_rule = rule if callable(rule) else None
+        if self.host_rule is not None:
+            speculate = fuse = False
         self.lr, self.max_iters = lr, int(max_iters)
         self.masks = (bool(X_mask), bool(C_Theta_mask), bool(phi_x_mask))
         self.optimizer = optimizer
@@ -72,7 +81,11 @@ class SceneFit:
             shard.gauge_fix()                                            # p2w:533-536
 
         self.release = shard.snapshot()                                  # p2w:463-464
-        self.adam = optimizer == 'Adam'
+        self.adam = optimizer == 'Adam' and self.host_rule is None
+        self.host_state = self.host_state_tmp = None
+        if self.host_rule is not None:                                   # p2w:466-473
+            self.host_state, self.host_state_tmp = self._host_state_init(optimizer), self._host_state_init(optimizer)
+            self._host_state_named = optimizer
         self.mom_x = self.mom_cam = self.mom_x_tmp = self.mom_cam_tmp = None
         if self.adam:                                                    # p2w:469-473
             self.mom_x, self.mom_cam = self._zero_moments()
@@ -99,15 +112,64 @@ class SceneFit:
         if self.adam:
             self.mom_x, self.mom_cam = self._zero_moments()
             self.t = 1
+        if self.host_rule is not None:
+            self.host_state = self._host_state_init(self._host_state_named)
 
     def _adam_stash_and_reset(self):
         if self.adam:
             self.mom_x_tmp, self.mom_cam_tmp, self.t_tmp = self.mom_x, self.mom_cam, self.t
-            self._adam_reset()
+        if self.host_rule is not None:
+            self.host_state_tmp = self.host_state
+        self._adam_reset()
 
     def _adam_restore(self):
         if self.adam:
             self.mom_x, self.mom_cam, self.t = self.mom_x_tmp, self.mom_cam_tmp, self.t_tmp
+        if self.host_rule is not None:
+            self.host_state = {k: {n: v.copy() for n, v in st.items()} for k, st in self.host_state_tmp.items()}
+
+    # ---- user-supplied update rule on host copies (p2w:704-708) --------------------------------
+    def _host_group_shapes(self):
+        N, K = self.sh.N, self.sh.K
+        out = []
+        if self.masks[0]:
+            out.append(('X', (N, 3)))
+        if self.masks[1]:
+            out.extend([('C', (K, 3)), ('Theta', (K, 3))])
+        if self.masks[2]:
+            out.append(('phi_x', (1,)))
+        return out
+
+    def _host_state_init(self, optimizer):
+        """Per-group state as form_params_dict makes it (p2w:466-473): moments and the step counter under
+        the name 'Adam', nothing otherwise."""
+        if optimizer != 'Adam':
+            return {name: {} for name, _ in self._host_group_shapes()}
+        return {name: {'s': np.zeros(shape), 'r': np.zeros(shape), 't': np.array([1])}
+                for name, shape in self._host_group_shapes()}
+
+    def _host_update(self):
+        """One step of the registered callable on every free group, then the gauge fix on the device."""
+        import torch
+        sh = self.sh
+        K3, inv = 3 * sh.K, 1.0 / sh.nV
+        cam = sh.cam.cpu().numpy().copy()
+        red = sh.red.cpu().numpy() * inv
+        main = {'C': cam[:K3].reshape(-1, 3), 'Theta': cam[K3:2 * K3].reshape(-1, 3), 'phi_x': cam[2 * K3:2 * K3 + 1]}
+        grad = {'C': red[:K3].reshape(-1, 3), 'Theta': red[K3:2 * K3].reshape(-1, 3), 'phi_x': red[2 * K3:2 * K3 + 1]}
+        if self.masks[0]:
+            main['X'] = sh.points_to_caller(sh.X).cpu().numpy().copy()
+            grad['X'] = sh.points_to_caller(sh.gX).cpu().numpy() * inv
+        for name, shape in self._host_group_shapes():
+            new, new_state = self.host_rule(main[name], grad[name], self.lr, **self.host_state[name])
+            main[name][:] = np.asarray(new, dtype=np.float64).reshape(shape)
+            for key, val in self.host_state[name].items():
+                val[:] = new_state[key]
+        X_new = sh.points_to_engine(main['X']) if self.masks[0] else sh.X
+        sh.adopt(X_new, torch.from_numpy(cam).to(sh.cam.device))
+        sh.invalidate_table()
+        if self.gauge:
+            sh.gauge_fix()                                               # p2w:710-712
 
     def _evaluate(self):
         timed = self.timed_every > 0 and self._passes % self.timed_every == 0
@@ -203,6 +265,10 @@ class SceneFit:
         if it % self.print_step == 0:
             self.print(f'{it} : {self.E_min}')
 
+        if self.host_rule is not None:
+            self._host_update()
+            self.iters += 1
+            return True
         if queued is None or self._intervened:
             if queued is not None:
                 self.dropped += 1

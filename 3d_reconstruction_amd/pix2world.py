@@ -18,7 +18,7 @@ import torch
 from . import engine
 from .fit_loop import SceneFit, extra_optimizers, gd_func_dict  # noqa: F401  (gd_func_dict re-exported)
 from .lm import LMFit
-from .sharding import partition_points, connected_components_count
+from .sharding import all_ranks_ok, checked_partition, connected_components_count
 
 __all__ = ['fit_scene', 'fit_scene_sparse', 'transform', 'error', 'validate_scene_parameters', 'gd_func_dict',
            'get_X_from_C_Theta', 'get_C_Theta_from_X', 'get_H_diff_matrix']
@@ -143,7 +143,16 @@ def _pack_results(fit, shard, masks, gather_X=None):
         if X_mask:
             back = (lambda h: h) if shard.perm is None else \
                 (lambda h, inv=torch.argsort(shard.perm).cpu().numpy(): h[inv])
-            out.append(np.array([back(h.reshape(-1, 3)) for h in hist[g]]))
+            snaps = []
+            for h in hist[g]:
+                if h is not None:
+                    h = back(h.reshape(-1, 3))
+                    if gather_X is not None:       # several ranks: every snapshot holds this rank's points only
+                        t = torch.from_numpy(np.ascontiguousarray(h))
+                        dev = getattr(shard, 'device', None)
+                        h = gather_X(t if dev is None else t.to(dev)).cpu().numpy()
+                snaps.append(h)
+            out.append(np.array(snaps))
             g += 1
         if C_Theta_mask:
             out.append(np.array([h[:K3].reshape(-1, 3) for h in hist[g]]))
@@ -187,12 +196,21 @@ def fit_scene_sparse(i, j, uv, N, K, W, H, lr, max_iters, X_0, C_0, Theta_0, phi
     gather_X = None
     if world > 1:
         rank = torch.distributed.get_rank()
-        bounds, obs_bounds = partition_points(i_t.cpu().numpy(), N, world)
+        i_host = i_t.cpu().numpy()
+        bounds, obs_bounds = checked_partition(i_host, N, world)      # same verdict on every rank
         p0, p1 = bounds[rank], bounds[rank + 1]
         e0, e1 = obs_bounds[rank], obs_bounds[rank + 1]
         i_loc = (i_t[e0:e1].to(torch.int64) - p0).to(torch.int32)
-        shard = engine.Shard(i_loc, j_t[e0:e1], uv_t[e0:e1], p1 - p0, K, W, H, dev, n_visible_total=nV)
-        shard.set_params(X_0[p0:p1], C_0, Theta_0, phi_x_0)
+        shard, failure = None, None
+        try:
+            shard = engine.Shard(i_loc, j_t[e0:e1], uv_t[e0:e1], p1 - p0, K, W, H, dev, n_visible_total=nV)
+            shard.set_params(X_0[p0:p1], C_0, Theta_0, phi_x_0)
+        except Exception as e:        # the other ranks are about to enter collectives: tell them first
+            failure = e
+        if not all_ranks_ok(failure is None, dev):
+            if shard is not None:
+                shard.close()
+            raise failure if failure is not None else RuntimeError('another rank could not set up its shard')
 
         def gather_X(x_local):
             from .sharding import all_gather_rows

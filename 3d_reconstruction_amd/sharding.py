@@ -3,9 +3,9 @@
 Observations are independent and the energy is a plain sum, so the path shards by POINT
 ranges: a rank owns a contiguous block of points, all their observations, their gradients and
 optimiser moments.  Cameras and phi_x are replicated; the camera-side sums and the energy are
-the one thing exchanged (one sum over the ranks per evaluation, engine.Shard.eval): inside a node
-by the library's own exchange kernel (NodeExchange), otherwise by RCCL on the caller's stream
-(StreamAllReduce) or through torch.distributed."""
+the one thing exchanged (one sum over the ranks per evaluation, engine.Shard.eval): by RCCL on the
+caller's stream (StreamAllReduce; torch.distributed's own call if that cannot be set up), or, when
+BA_NODE_EXCHANGE=1 asks for it, inside a node by the library's own exchange kernel (NodeExchange)."""
 from __future__ import annotations
 
 import ctypes as C
@@ -39,6 +39,34 @@ def partition_points(obs_i, N, world):
     point_bounds.append(N)
     obs_bounds.append(nV)
     return point_bounds, obs_bounds
+
+
+def checked_partition(obs_i, N, world):
+    """partition_points for a fit over `world` ranks, with the checks that have to give the same verdict on
+    every rank before any of them builds its shard (a rank that raised alone would leave the others waiting
+    in their first collective): observations sorted by point, and no rank left without points or
+    observations.  Every rank evaluates all ranks' ranges from the same input, so all raise or none does."""
+    obs_i = np.asarray(obs_i)
+    if obs_i.size > 1 and bool((obs_i[1:] < obs_i[:-1]).any()):
+        raise ValueError('observations must be sorted by point index')
+    point_bounds, obs_bounds = partition_points(obs_i, N, world)
+    for r in range(world):
+        if point_bounds[r + 1] <= point_bounds[r] or obs_bounds[r + 1] <= obs_bounds[r]:
+            raise ValueError(f'Unable to split {N} points with {obs_i.size} observations over {world} ranks: rank {r} '
+                             'would hold no observations; use fewer ranks')
+    return point_bounds, obs_bounds
+
+
+def all_ranks_ok(flag, device=None, group=None):
+    """True if `flag` is true on every rank of the group (one MIN all-reduce; no group: the flag itself)."""
+    dist = torch.distributed
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return bool(flag)
+    t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64)
+    if dist.get_backend(group) != 'gloo' and device is not None:
+        t = t.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(t.item() > 0.5)
 
 
 def connected_components_count(i, j, N, K):
@@ -185,7 +213,8 @@ class NodeExchange:
         reading its window, so the window is never freed while the group is alive.  Every rank of the group
         must ask for it at the same point of the program."""
         import os
-        if os.environ.get('BA_NO_NODE_EXCHANGE'):
+        # opt-in: the default path for the sums over the ranks is RCCL on the compute stream (StreamAllReduce)
+        if os.environ.get('BA_NODE_EXCHANGE') != '1' or os.environ.get('BA_NO_NODE_EXCHANGE'):
             return None
         dist = torch.distributed
         pg = group if group is not None else dist.distributed_c10d._get_default_group()

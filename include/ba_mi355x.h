@@ -277,8 +277,9 @@ int ba_subscenes_transform(int64_t P, int64_t n_entries, const int32_t *entry_su
  * ba_exchange_sum replaces buf[0..n) by the sum over the ranks, in rank order (identical bits on every rank),
  * as ONE kernel on `stream`: no collective library, no second stream.  All ranks must call it the same number of
  * times with the same n.  A value with the bit pattern 0x7ff4a5a57ff4a5a5 (a signalling NaN, the windows' mark for
- * "not yet published") is summed as a quiet NaN.  A rank that waits longer than the limit (default 2 s) for another gives up: its buffer
- * stays as it was, ba_exchange_status (and every later ba_exchange_sum) returns BA_ERR_STATE
+ * "not yet published") is summed as a quiet NaN.  A rank that waits longer than the limit (default 2 s) for another gives up: the
+ * contents of its buffer are then UNDEFINED (the chunks of workgroups that had finished their wait already hold
+ * sums, the others the rank's own values), ba_exchange_status (and every later ba_exchange_sum) returns BA_ERR_STATE
  * (ba_exchange_set_wait changes the limit, at most 30 s).  Calls of one exchange must not overlap on a GPU: queue
  * them on one stream.  ba_exchange_destroy frees the window the other ranks read from inside their kernels: call
  * it only after every rank has finished its last sum (device synchronisation, then a host barrier). */

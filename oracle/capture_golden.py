@@ -458,6 +458,36 @@ def capture_f9(out):
     save_npz(os.path.join(out, 'f9_h_diff.npz'), **arrays)
 
 
+def capture_f10(out):
+    """The three early exits of the loop (p2w:625-638) on the F3 scene: a run that ends on `stop_value`, two
+    that end on `stop_diff` after learning-rate events (the iteration counter has gone down by then, so the
+    window E[:iters - 2 * patience] is taken at a decremented counter), and one that reaches lr == 0.0 (an
+    infinite factor: the first decrease divides the rate to zero; the parameters returned are the rolled-back
+    ones)."""
+    import warnings
+    sc = make_scene(50, 12, seed=7, vis_frac=1.0)
+    arrays = {k: sc[k] for k in ('X_pix', 'X_0', 'C_0', 'Theta_0')}
+    arrays['W'], arrays['H'], arrays['phi_x_0'] = sc['W'], sc['H'], sc['phi_x_0']
+    base = run_reference(sc, lr=1e-3, max_iters=200, patience=20)
+    stop_value = 0.5 * (base['E'][61] + base['E'][62])
+    runs = dict(stop_value=dict(lr=1e-3, max_iters=200, patience=20, stop_value=float(stop_value)),
+                stop_diff_a=dict(lr=1e-3, max_iters=200, patience=3, stop_diff=10.0),
+                stop_diff_b=dict(lr=1e-3, max_iters=200, patience=2, stop_diff=20.0),
+                stop_diff_sgd=dict(lr=1e-7, max_iters=200, patience=2, stop_diff=50.0, optimizer='SGD'),
+                lr_zero=dict(lr=1.0, max_iters=50, patience=20, factor=float('inf')))
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for tag, kw in runs.items():
+            r = run_reference(sc, **kw)
+            print(tag, r['log'], r['E'].shape)
+            for k, v in kw.items():
+                arrays[f'{tag}__arg_{k}'] = v
+            for k, v in r.items():
+                arrays[f'{tag}__{k}'] = np.array(v) if k == 'log' else v
+    arrays['runs'] = np.array(list(runs))
+    save_npz(os.path.join(out, 'f10_early_stops.npz'), **arrays)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden'))
@@ -465,7 +495,7 @@ def main():
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     todo = dict(f1=capture_f1, f2=capture_f2, f3=capture_f3, f4=capture_f4, f5=capture_f5,
-                f6=capture_f6, f7=capture_f7, f8=capture_f8, f9=capture_f9)
+                f6=capture_f6, f7=capture_f7, f8=capture_f8, f9=capture_f9, f10=capture_f10)
     for name, fn in todo.items():
         if a.only and name not in a.only.split(','):
             continue

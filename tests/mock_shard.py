@@ -51,6 +51,9 @@ class MockShard:
     def points_to_caller(self, t):
         return t
 
+    def points_to_engine(self, a):
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64))
+
     def invalidate_table(self):
         pass
 

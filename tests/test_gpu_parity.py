@@ -267,6 +267,41 @@ def test_fit_scene_lr_events(ba, golden):
     assert rel_err(out[-1][:100], g['E'][:100]) < 1e-8
 
 
+def test_fit_scene_early_stops(ba, golden):
+    """The early exits of the loop (p2w:625-638) through the dense drop-in: every printed line, the length of
+    E and the returned parameters as the reference gave them (stop_value; stop_diff after rollbacks, Adam
+    and SGD; lr == 0.0, which returns the rolled-back parameters)."""
+    from test_oracle_golden import _f10_kwargs
+    g = golden('f10_early_stops.npz')
+    for tag in g['runs'].tolist():
+        kw = _f10_kwargs(g, tag)
+        lr, max_iters = kw.pop('lr'), int(kw.pop('max_iters'))
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            out = ba.fit_scene(g['X_pix'], int(g['W']), int(g['H']), lr, max_iters, g['X_0'], g['C_0'], g['Theta_0'],
+                               float(g['phi_x_0']), **kw)
+        assert logs_match(buf.getvalue().splitlines(), g[f'{tag}__log'].tolist()), (tag, buf.getvalue())
+        assert out[-1].shape == g[f'{tag}__E'].shape, tag
+        assert rel_err(out[-1], g[f'{tag}__E']) < 1e-8, tag
+        for n, v in zip(('X', 'C', 'Theta', 'phi_x'), out):
+            assert np.abs(np.asarray(v) - g[f'{tag}__final_{n}']).max() < 1e-8, (tag, n)
+
+
+def test_registered_callable_optimizers(ba, golden):
+    """Callables in gd_func_dict (the reference's extension point, p2w:362, 705) drive the GPU loop."""
+    from test_host_cpu import check_registered_callables
+
+    def run(g, optimizer, lr, max_iters, m, **kw):
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            out = ba.fit_scene(g['X_pix'], int(g['W']), int(g['H']), lr, max_iters, g['X_0'], g['C_0'], g['Theta_0'],
+                               float(g['phi_x_0']), X_mask=m[0], C_Theta_mask=m[1], phi_x_mask=m[2],
+                               optimizer=optimizer, **kw)
+        names = (['X'] if m[0] else []) + (['C', 'Theta'] if m[1] else []) + (['phi_x'] if m[2] else [])
+        return out[len(names)], dict(zip(names, out)), buf.getvalue().splitlines()
+    check_registered_callables(golden, run)
+
+
 def test_queued_updates_do_not_change_the_trajectory(ba, golden):
     """The loop queues each update before it knows the energy and drops it when the LR schedule
     intervenes; it must walk the same trajectory as the run that waits every time (up to the

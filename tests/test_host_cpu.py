@@ -124,6 +124,26 @@ def test_loop_control_reproduces_lr_events(golden):
     assert sh.evals == g['manager_calls'].shape[0] + rollbacks
 
 
+def test_loop_control_early_stops(golden):
+    """SceneFit leaves the loop where the reference does (p2w:625-638) with the same printed line, the
+    same number of energies and the same returned state (after lr == 0.0: the rolled-back parameters)."""
+    from test_oracle_golden import _f10_kwargs
+    g = golden('f10_early_stops.npz')
+    i, j, uv = orc.visibility_coo(g['X_pix'])
+    N, K = g['X_pix'].shape[:2]
+    for tag in g['runs'].tolist():
+        kw = _f10_kwargs(g, tag)
+        lr, max_iters = kw.pop('lr'), int(kw.pop('max_iters'))
+        sh, fit, lines = _run_mock(g, i, j, uv, N, K, lr, max_iters, **kw)
+        assert logs_match(lines, g[f'{tag}__log'].tolist()), (tag, lines)
+        assert fit.energies().shape == g[f'{tag}__E'].shape
+        assert rel_err(fit.energies(), g[f'{tag}__E']) < 1e-8
+        assert np.abs(sh.X.numpy() - g[f'{tag}__final_X']).max() < 1e-8
+        assert np.abs(sh.C.numpy() - g[f'{tag}__final_C']).max() < 1e-8
+        assert np.abs(sh.Theta.numpy() - g[f'{tag}__final_Theta']).max() < 1e-8
+        assert abs(float(sh.phi[0]) - float(g[f'{tag}__final_phi_x'])) < 1e-8
+
+
 @pytest.mark.parametrize('opt', ['Adam', 'SGD'])
 def test_loop_control_all_masks(golden, opt):
     g = golden('f1_tiny_masks.npz')
@@ -144,6 +164,81 @@ def test_loop_control_all_masks(golden, opt):
         if m[2]:
             assert abs(float(sh.phi[0]) - float(g[f'{tag}__final_phi_x'])) < 1e-9
         assert logs_match(lines, g[f'{tag}__log'].tolist()), tag
+
+
+def _numpy_adam(x, grad_x, lr, s, r, t):
+    """Adam as the reference states it (p2w:344-360), written here as a user of the registry would."""
+    s_new = 0.9 * s + 0.1 * grad_x
+    r_new = 0.999 * r + 0.001 * grad_x ** 2
+    x_new = x - lr * (s_new / (1.0 - 0.9 ** t)) / (1e-12 + np.sqrt(r_new / (1.0 - 0.999 ** t)))
+    return x_new, {'s': s_new, 'r': r_new, 't': t + 1}
+
+
+def check_registered_callables(golden, run):
+    """A callable placed in gd_func_dict is what the loop calls, with the reference's convention
+    (p2w:362, 705): under a new name it gets no state, under the name 'Adam' it gets s, r, t.
+    `run(optimizer, lr, max_iters, masks, **kw)` -> (energies, {group: final}, printed lines)."""
+    g1 = golden('f1_tiny_masks.npz')
+    reg = p2w.gd_func_dict
+    seen = []
+
+    def my_sgd(x, grad_x, lr):
+        seen.append(grad_x.shape)
+        return x - lr * grad_x, {}
+
+    recorded = []
+
+    def recording_adam(x, grad_x, lr, **state):
+        recorded.append((x.copy(), grad_x.copy()))
+        return _numpy_adam(x, grad_x, lr, **state)
+
+    saved = dict(reg)
+    try:
+        reg['plain descent'] = my_sgd
+        for m in g1['combos']:
+            m = tuple(bool(t) for t in m)
+            tag = 'SGD_' + ''.join('1' if t else '0' for t in m)
+            E, final, lines = run(g1, 'plain descent', 1e-7, 5, m)
+            assert rel_err(E, g1[f'{tag}__E']) < 1e-9, tag
+            for n, v in final.items():
+                assert np.abs(v - g1[f'{tag}__final_{n}']).max() < 1e-9, (tag, n)
+        assert (60, 3) in seen and (15, 3) in seen and (1,) in seen
+        # the capture hook of the golden files works on the drop-in too: wrap the entry 'Adam'
+        reg['Adam'] = recording_adam
+        E, final, lines = run(g1, 'Adam', 1e-3, 5, (True, True, True))
+        assert rel_err(E, g1['Adam_111__E']) < 1e-9
+        assert len(recorded) == 4 * 4
+        for step in range(4):
+            for k, n in enumerate(('X', 'C', 'Theta', 'phi_x')):
+                x, grad = recorded[4 * step + k]
+                assert np.abs(x.reshape(g1[f'Adam_111__step_{n}'][step].shape) - g1[f'Adam_111__step_{n}'][step]).max() < 1e-9
+                assert rel_err(grad, g1[f'Adam_111__grad_{n}'][step]) < 1e-9, (step, n)
+        # ... and through learning-rate events (stash / reset / restore of the callable's state)
+        g3 = golden('f3_lr_events.npz')
+        E, final, lines = run(g3, 'Adam', 1e-3, 200, (True, True, True), patience=20)
+        events = lambda ls: [ln for ln in ls if 'LR' in ln or 'Reached' in ln]
+        assert events(lines) == events(g3['log'].tolist())
+        assert rel_err(E[:100], g3['E'][:100]) < 1e-8
+    finally:
+        reg.clear()
+        reg.update(saved)
+
+
+def test_registered_callable_optimizers(golden):
+    def run(g, optimizer, lr, max_iters, m, **kw):
+        i, j, uv = orc.visibility_coo(g['X_pix'])
+        N, K = g['X_pix'].shape[:2]
+        sh, fit, lines = _run_mock(g, i, j, uv, N, K, lr, max_iters, X_mask=m[0], C_Theta_mask=m[1],
+                                   phi_x_mask=m[2], optimizer=optimizer, **kw)
+        final = {}
+        if m[0]:
+            final['X'] = sh.X.numpy()
+        if m[1]:
+            final['C'], final['Theta'] = sh.C.numpy(), sh.Theta.numpy()
+        if m[2]:
+            final['phi_x'] = sh.phi.numpy()[0]
+        return fit.energies(), final, lines
+    check_registered_callables(golden, run)
 
 
 def test_unknown_optimizer_message():

@@ -219,6 +219,39 @@ def test_f3_lr_events(golden):
         assert rel_err(gT, g['grad_Theta'][s]) < TOL and rel_err(gp, g['grad_phi_x'][s]) < TOL
 
 
+def _f10_kwargs(g, tag):
+    kw = {}
+    for key in g.files:
+        if key.startswith(tag + '__arg_'):
+            v = g[key]
+            kw[key[len(tag) + 6:]] = str(v) if v.dtype.kind == 'U' else (int(v) if v.dtype.kind == 'i' else float(v))
+    return kw
+
+
+def test_f10_early_stops(golden):
+    """The three early exits of the loop (p2w:625-638): stop_value, stop_diff after learning-rate events
+    (iteration counter already decremented), lr == 0.0 - printed line, length of E, returned parameters."""
+    g = golden('f10_early_stops.npz')
+    X_pix = g['X_pix']
+    N, K = X_pix.shape[:2]
+    i, j, uv = _coo(X_pix)
+    seen = set()
+    for tag in g['runs'].tolist():
+        kw = _f10_kwargs(g, tag)
+        lr, max_iters = kw.pop('lr'), int(kw.pop('max_iters'))
+        log = []
+        out = orc.fit_scene(i, j, uv, N, K, int(g['W']), int(g['H']), lr, max_iters, g['X_0'], g['C_0'], g['Theta_0'],
+                            float(g['phi_x_0']), log=log, **kw)
+        want = [ln for ln in g[f'{tag}__log'].tolist() if ('LR' in ln or 'Reached' in ln)]
+        assert logs_match(log, want), (tag, log, want)
+        seen.add(want[-1].split(' : ')[1].split(':')[0].split(' <')[0])
+        assert out[-1].shape == g[f'{tag}__E'].shape, tag
+        assert rel_err(out[-1], g[f'{tag}__E']) < 1e-8, tag
+        for n, v in zip(('X', 'C', 'Theta', 'phi_x'), out):
+            assert np.abs(np.asarray(v) - g[f'{tag}__final_{n}']).max() < 1e-8, (tag, n)
+    assert seen == {'Reached stopping value', 'Reached stopping difference', 'Reached lr = 0.0'}
+
+
 def test_f6_medium_scene(golden):
     g = golden('f6_medium.npz')
     i, j = g['obs_i'], g['obs_j']
