@@ -59,6 +59,10 @@ SIGNATURES = {
     'ba_set_sum_buffer': (_int, [_p, _p, _i64]),
     'ba_points_step': (_int, [_i64] + [_p] * 7 + [_int, _dbl, _dbl, _dbl, _dbl, _p, _p]),
     'ba_gauge_fix': (_int, [_i64, _i64, _p, _p, _p, _p, _p, _p]),
+    'ba_rotation_matrices': (_int, [_i64, _p, _p, _p]),
+    'ba_rotation_angles': (_int, [_i64, _p, _p, _p]),
+    'ba_align_scene': (_int, [_i64, _i64] + [_p] * 10),
+    'ba_normalize_scene': (_int, [_i64, _i64, _p, _p, _i64, _i64, _dbl, _p, _p, _p, _p]),
     'ba_project': (_int, [_i64, _i64, _i64, _p, _p, _p, _p, _p, _dbl, _dbl, _dbl, _int, _int, _p, _p]),
     'ba_reprojection_error': (_int, [_i64, _p, _p, _p, _p]),
     'ba_homography_diff_matrix': (_int, [_i64, _p, _p, _p, _dbl, _dbl, _int, _int, _p, _p]),

@@ -495,6 +495,66 @@ class Shard:
         return 0
 
 
+def rotation_matrices(Theta, device='cuda:0'):
+    """ryxz (p2w:138-140) on the device: (K, 3, 3)."""
+    lib = _lib.load()
+    dev = torch.device(device)
+    Td = _dev_tensor(Theta, F64, dev).view(-1, 3)
+    K = int(Td.shape[0])
+    R = torch.empty((K, 3, 3), dtype=F64, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.ba_rotation_matrices(K, ptr(Td), ptr(R), stream_ptr()))
+    return R
+
+
+def rotation_angles(R, device='cuda:0'):
+    """get_rotations (p2w:254-267) on the device: (K, 3)."""
+    lib = _lib.load()
+    dev = torch.device(device)
+    Rd = _dev_tensor(R, F64, dev).view(-1, 9)
+    K = int(Rd.shape[0])
+    Theta = torch.empty((K, 3), dtype=F64, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.ba_rotation_angles(K, ptr(Rd), ptr(Theta), stream_ptr()))
+    return Theta
+
+
+def align_scene(X, C_, Theta=None, R=None, device='cuda:0'):
+    """align_scene (p2w:270-303) on the device: (X_new, C_new, Theta_new, R_new)."""
+    lib = _lib.load()
+    dev = torch.device(device)
+    Xd, Cd = _dev_tensor(X, F64, dev).view(-1, 3), _dev_tensor(C_, F64, dev).view(-1, 3)
+    Td = None if Theta is None else _dev_tensor(Theta, F64, dev).view(-1, 3)
+    Rd = None if R is None else _dev_tensor(R, F64, dev).view(-1, 9)
+    N, K = int(Xd.shape[0]), int(Cd.shape[0])
+    X_new, C_new = torch.empty_like(Xd), torch.empty_like(Cd)
+    T_new = torch.empty((K, 3), dtype=F64, device=dev)
+    R_new = torch.empty((K, 3, 3), dtype=F64, device=dev)
+    work = torch.empty(12, dtype=F64, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.ba_align_scene(N, K, ptr(Xd), ptr(Cd), ptr(Td), ptr(Rd), ptr(X_new), ptr(C_new), ptr(T_new), ptr(R_new),
+                                 ptr(work), stream_ptr()))
+    return X_new, C_new, T_new, R_new
+
+
+def normalize_scene(X, C_, main_indexes=None, dist_scale=1.0, device='cuda:0'):
+    """normalize_scene (p2w:306-333) on the device: (X_new, C_new, j1)."""
+    lib = _lib.load()
+    dev = torch.device(device)
+    Xd, Cd = _dev_tensor(X, F64, dev).view(-1, 3), _dev_tensor(C_, F64, dev).view(-1, 3)
+    N, K = int(Xd.shape[0]), int(Cd.shape[0])
+    j0, j1 = (0, -1) if main_indexes is None else (int(main_indexes[0]), int(main_indexes[1]))
+    if main_indexes is not None:
+        j0, j1 = j0 % K, j1 % K              # numpy's negative indices
+    X_new, C_new = torch.empty_like(Xd), torch.empty_like(Cd)
+    work = torch.empty(2, dtype=F64, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.ba_normalize_scene(N, K, ptr(Xd), ptr(Cd), j0, j1, float(dist_scale), ptr(X_new), ptr(C_new), ptr(work),
+                                     stream_ptr()))
+    j_used = int(work[1].item())
+    return X_new, C_new, (np.int64(j_used) if main_indexes is None else main_indexes[1])
+
+
 def project(X, C_, Theta, phi_x, W, H, i=None, j=None, delete_back_points=True, delete_boundary_points=False,
             device='cuda:0'):
     """Model pixels for a list of (i, j) pairs, or for the dense N x K grid when i is None."""

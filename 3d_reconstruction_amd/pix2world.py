@@ -21,7 +21,8 @@ from .lm import LMFit
 from .sharding import all_ranks_ok, checked_partition, connected_components_count
 
 __all__ = ['fit_scene', 'fit_scene_sparse', 'transform', 'error', 'validate_scene_parameters', 'gd_func_dict',
-           'get_X_from_C_Theta', 'get_C_Theta_from_X', 'get_H_diff_matrix']
+           'get_X_from_C_Theta', 'get_C_Theta_from_X', 'get_H_diff_matrix', 'ryxz', 'get_rotations', 'align_scene',
+           'normalize_scene']
 
 
 # --------------------------------------------------------------------------------------------- #
@@ -247,6 +248,57 @@ def fit_scene(X_pix, W, H, lr, max_iters, X_0, C_0, Theta_0, phi_x_0, X_mask=Tru
     return fit_scene_sparse(oi, oj, uv, N, K, W, H, lr, max_iters, X_0, C_0, Theta_0, phi_x_0, X_mask,
                             C_Theta_mask, phi_x_mask, optimizer, patience, factor, stop_value, stop_diff,
                             print_step, ret_all_iters, device=dev, _validate=False)
+
+
+# --------------------------------------------------------------------------------------------- #
+# rotation and gauge helpers (p2w:138-140, 254-333)
+# --------------------------------------------------------------------------------------------- #
+def ryxz(Theta, _validate=True, device=None):
+    """Rotation matrices Ry(theta_y) @ Rx(theta_x) @ Rz(theta_z), shape (K, 3, 3) (p2w:138-140)."""
+    if _validate:
+        validate_scene_parameters(Theta=Theta)
+    dev = torch.device(device) if device is not None else _default_device()
+    return engine.rotation_matrices(Theta, dev).cpu().numpy()
+
+
+def get_rotations(R, _validate=True, device=None):
+    """Euler angles (K, 3) of rotation matrices, the inverse of ryxz with theta_x in [-pi/2, pi/2]
+    (p2w:254-267)."""
+    if _validate:
+        validate_scene_parameters(R=R)
+    dev = torch.device(device) if device is not None else _default_device()
+    return engine.rotation_angles(R, dev).cpu().numpy()
+
+
+def align_scene(X, C, Theta=None, R=None, ret_R=False, _validate=True, device=None):
+    """The scene in the frame of camera 0 (its centre at the origin, its rotation the identity):
+    returns X_new, C_new, Theta_new and, with ret_R, the new rotation matrices (p2w:270-303)."""
+    if Theta is None and R is None:
+        raise ValueError('Expected Theta or R to be passed')
+    elif Theta is not None and R is not None:
+        raise ValueError('Expected only Theta or R to be passed, not both')
+    if _validate:
+        validate_scene_parameters(X=X, C=C, Theta=Theta, R=R)
+    dev = torch.device(device) if device is not None else _default_device()
+    out = engine.align_scene(X, C, Theta, R, dev)
+    out = [t.cpu().numpy() for t in out]
+    return tuple(out) if ret_R else tuple(out[:3])
+
+
+def normalize_scene(X, C, main_indexes=None, dist_scale=1.0, ret_j=False, _validate=True, device=None):
+    """X and C scaled so that the distance between cameras main_indexes = (j0, j1) becomes dist_scale;
+    by default camera 0 and the camera farthest from it.  Returns [X_new, C_new] and, with ret_j, j1
+    (p2w:306-333)."""
+    if _validate:
+        validate_scene_parameters(X=X, C=C)
+        if main_indexes is not None and len(main_indexes) != 2:
+            raise ValueError(f'Expected main_indexes to have length 2, got {len(main_indexes)}')
+    dev = torch.device(device) if device is not None else _default_device()
+    X_new, C_new, j1 = engine.normalize_scene(X, C, main_indexes, dist_scale, dev)
+    returns = [X_new.cpu().numpy(), C_new.cpu().numpy()]
+    if ret_j:
+        returns.append(j1)
+    return returns
 
 
 def transform(X, C, Theta, phi_x, W, H, delete_back_points=True, delete_boundary_points=False, _validate=True,

@@ -136,6 +136,23 @@ int ba_sgd_step(int64_t n, double *x, const double *g, double lr, double gscale,
 int ba_gauge_fix(int64_t N, int64_t K, double *X, double *C, double *Theta, double *R_out,
                  double *gauge_out, void *stream);
 
+/* ---- the rotation and gauge helpers as calls of their own (the fit loop uses the fused steps below).
+ * ba_rotation_matrices: ryxz (p2w:138-140), R_out[K][9] row-major = Ry(theta_y) Rx(theta_x) Rz(theta_z).
+ * ba_rotation_angles:   get_rotations (p2w:254-267), Theta_out[K][3] with theta_x in [-pi/2, pi/2].
+ * ba_align_scene:       align_scene (p2w:270-303): camera 0 to the origin with identity rotation.  Exactly one of
+ *   Theta_in[K][3], R_in[K][9]; X_out = (X - C0) @ R0, C_out likewise, R_out (optional) = R0^T R, Theta_out its
+ *   angles.  Outputs may alias the inputs.  frame_work: 12 doubles of scratch.
+ * ba_normalize_scene:   normalize_scene (p2w:306-333): X_out = X * f, C_out = C * f, f = dist_scale / |C[j1] - C[j0]|;
+ *   j1 < 0 selects j0 = 0 and the camera farthest from camera 0 (the first among equals, as numpy.argmax).
+ *   scale_work[2] receives f and the j1 used. */
+int ba_rotation_matrices(int64_t K, const double *Theta, double *R_out, void *stream);
+int ba_rotation_angles(int64_t K, const double *R, double *Theta_out, void *stream);
+int ba_align_scene(int64_t N, int64_t K, const double *X_in, const double *C_in, const double *Theta_in,
+                   const double *R_in, double *X_out, double *C_out, double *Theta_out, double *R_out,
+                   double *frame_work, void *stream);
+int ba_normalize_scene(int64_t N, int64_t K, const double *X_in, const double *C_in, int64_t j0, int64_t j1,
+                       double dist_scale, double *X_out, double *C_out, double *scale_work, void *stream);
+
 /* ---- one optimiser step, fused (p2w:704-712): the same arithmetic as ba_adam_step / ba_sgd_step
  * followed by ba_gauge_fix, in two launches and one pass over each array.  Parameters and moments
  * have an input and an output pointer each: the same buffer (in place) or disjoint ones.  With

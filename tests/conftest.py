@@ -39,6 +39,17 @@ def rel_err(a, b):
     return np.abs(a - b).max() / scale
 
 
+def row_err(a, b, floor=1e-4):
+    """Worst per-row relative error of a (rows, components) array: every point's / camera's vector is
+    compared with its own magnitude, bounded below by `floor` times the array's largest entry (a row that
+    is small because its terms cancel carries the rounding of those terms)."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    a, b = a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)
+    top = max(np.abs(b).max(), 1e-300)
+    scale = np.maximum(np.abs(b).max(axis=1), floor * top)
+    return (np.abs(a - b).max(axis=1) / scale).max()
+
+
 def logs_match(got, want, rtol=1e-8):
     """Printed lines agree: same text, every number within `rtol` (the reference prints energies
     with full repr precision, so the last digits depend on summation order)."""
