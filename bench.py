@@ -5,17 +5,28 @@
 
 One "step" is one full iteration of the fit_scene loop on a synthetic video-orbit scene that is
 already resident in HBM: fused observation pass (projection, residual, analytic Jacobian,
-gradient), cross-GPU sum of the camera-side block, the 8-byte energy read-back the LR schedule
-branches on, Adam update of X, C, Theta, phi_x, gauge fix.  Per GPU: 1 M points, 2 k cameras,
-~10 M observations (weak scaling: N GPUs hold N shards of that size of one scene sharing the
-2 k cameras).  For N > 1 launch with torch.distributed.run, one rank per GPU.
+gradient), sum of the camera-side block over the GPUs, the 8-byte energy read-back the LR schedule
+branches on, Adam update of X, C, Theta, phi_x, gauge fix.
 
-Prints ONE JSON line on rank 0 (metric/value/unit/... plus `roofline` for the observation-pass
-kernel and `cpu_baseline`, the C restatement of the reference's iteration on this box's host)."""
+Workloads
+  N = 1 : 1 M points, 2 k cameras, 10 M observations on one MI355X.
+  N > 1 : 10 M points, 2 k cameras, 100 M observations IN TOTAL, split over the N GPUs by point ranges
+          (strong scaling; 12.5 M observations per GPU at N = 8), cameras replicated, one sum over the
+          ranks per iteration.  The same scene is then timed on ONE GPU (rank 0 builds all shards), so
+          that the line carries the 1 -> N speed-up on an identical workload.
+
+With N > 1 and no launcher environment (WORLD_SIZE unset) the script starts its N ranks itself, as
+child processes, before it touches the GPU; under torch.distributed.run it is a rank.
+
+Prints ONE JSON line on rank 0: metric/value/unit/... plus `roofline` (gradient pass, the kernel of the
+timed loop), `roofline_jtj` (the pass with the J^T J blocks, timed stand-alone) and, at N = 1,
+`cpu_baseline` (the C restatement of the reference's iteration on this box's host cores)."""
 import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,20 +36,35 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak
+TRAFFIC_FILE = os.path.join('profiles', 'r02_pmc_traffic_cfg3.json')
 
 
-def measured_traffic(points_per_gpu, cameras, track_len):
-    """HBM bytes per launch of the observation-pass kernel from the committed rocprofv3 PMC passes
-    (FETCH_SIZE / WRITE_SIZE, corrected as profiles/summarize_pmc.py documents); only for the
-    workload those passes were taken on, else None."""
-    path = os.path.join(ROOT, 'profiles', 'r01m_pmc_traffic_cfg3.json')
+def measured_traffic(kernel_key, points_per_gpu, cameras, track_len):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE of
+    this script's own command, corrected as profiles/summarize_pmc.py documents).  The counters cannot be read
+    from inside a run: the figure is a constant of the committed profile, and only for the workload the passes
+    were taken on (else None)."""
+    path = os.path.join(ROOT, TRAFFIC_FILE)
     if (points_per_gpu, cameras, track_len) != (1_000_000, 2000, 10) or not os.path.exists(path):
         return None
     with open(path) as fh:
         for kernel, row in json.load(fh).items():
-            if 'k_run_pass<ba::GradOp' in kernel:
+            if kernel_key in kernel:
                 return row.get('hbm_bytes_per_launch')
     return None
+
+
+def host_cpu():
+    model = '?'
+    try:
+        with open('/proc/cpuinfo') as fh:
+            for line in fh:
+                if line.startswith('model name'):
+                    model = line.split(':', 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return model, os.cpu_count()
 
 
 def cpu_baseline(sc, budget_s=15.0):
@@ -58,9 +84,127 @@ def cpu_baseline(sc, budget_s=15.0):
         dt = time.perf_counter() - t0
         if dt > budget_s or n >= 200:
             break
+    model, ncpu = host_cpu()
     return {'value': cut * n / dt, 'unit': 'observations/s', 'cores': 1, 'kind': 'port',
+            'host_cpu_model': model, 'host_cpus': ncpu,
             'sample': f'{n} full iterations (evaluate + Adam + gauge fix) of oracle/ba_oracle.c on the first '
-                      f'{pts} points / {cut} observations of the workload, K={sc["K"]} cameras, 1 thread'}
+                      f'{pts} points / {cut} observations of the workload, K={sc["K"]} cameras, 1 thread of the '
+                      f'{ncpu} the host shows'}
+
+
+def grad_pass_bytes(nv, n_pts, K):
+    """Algorithmic bytes of the gradient pass: 24 B per observation record (i32, i32, f64, f64), X in, gX out,
+    cameras in and out."""
+    return 24 * nv + 24 * n_pts + 24 * n_pts + 48 * K + 48 * K
+
+
+def jtj_pass_bytes(nv, n_pts, K):
+    """... of the pass with the J^T J blocks: the same plus V (6 doubles per point) and B, bphi (27 per camera)."""
+    return grad_pass_bytes(nv, n_pts, K) + 48 * n_pts + 216 * K
+
+
+def roofline_block(kernel, algo_bytes, kern_ms, traffic, extra=None):
+    avg_ms = float(np.mean(kern_ms)) if len(kern_ms) else float('nan')
+    achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
+    out = {'bound': 'hbm', 'kernel': kernel, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+           'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+           'traffic_source': (f'{TRAFFIC_FILE}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, '
+                              'committed; a constant of that profile, not collected by this run') if traffic else None,
+           'achieved_traffic': (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None,
+           'algorithmic_bytes_per_launch': algo_bytes, 'avg_kernel_ms': avg_ms, 'launches_timed': len(kern_ms)}
+    if extra:
+        out.update(extra)
+    return out
+
+
+def time_jtj_pass(ba, sc, dev, nv_total, launches=24):
+    """Kernel time of the pass with the J^T J blocks (stand-alone, HIP events handed to the dispatch) on a
+    shard of its own holding the scene `sc`."""
+    import torch
+    sh = ba.engine.Shard(sc['i'], sc['j'], sc['uv'], sc['N_local'], sc['K'], sc['W'], sc['H'], dev,
+                         n_visible_total=nv_total)
+    try:
+        sh.distributed = False          # the kernel alone: no sum over ranks behind it
+        sh.set_params(sc['X_0'], sc['C_0'], sc['Theta_0'], sc['phi_x_0'])
+        for _ in range(6):
+            sh.eval_jtj()
+        torch.cuda.synchronize()
+        sh.eval_kernel_ms()
+        for _ in range(launches):
+            sh.eval_jtj(timed=True)
+        torch.cuda.synchronize()
+        return sh.eval_kernel_ms()
+    finally:
+        sh.close()
+
+
+def run_loop(ba, sh, sc, steps, warmup, sync, timed=True):
+    """`warmup` untimed and `steps` timed full iterations; returns (fit, seconds)."""
+    sh.set_params(sc['X_0'], sc['C_0'], sc['Theta_0'], sc['phi_x_0'])
+    total = steps + warmup
+    fit = ba.SceneFit(sh, lr=1e-3, max_iters=total + 8, patience=1000, print_step=10 ** 9, printer=lambda *a: None)
+    # HIP events on every 16th launch of the observation-pass kernel (handed to the dispatch itself, so they
+    # hold the kernel's own begin and end), at least three samples in short runs
+    fit.timed_every = max(1, min(16, steps // 3)) if timed else 0
+    for _ in range(warmup):
+        if not fit.step():
+            raise RuntimeError('the fit stopped during the warm-up')
+    sh.eval_kernel_ms()          # drop warm-up timings
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        if not fit.step():
+            raise RuntimeError('the fit stopped inside the timed region: the iterations counted would not all be full ones')
+    sync()
+    return fit, time.perf_counter() - t0
+
+
+# ------------------------------------------------------------------------------------------------- #
+def launch_ranks(args, argv):
+    """N > 1 without a launcher: start the N ranks as child processes (this process never touches the GPU)."""
+    import torch
+    share = os.environ.get('BA_BENCH_SHARE_GPU') == '1'
+    have = torch.cuda.device_count()         # counting devices does not initialise the GPU
+    if have < args.gpus and not share:
+        print(f'bench.py: --gpus {args.gpus} but this machine shows {have} GPU(s); nothing was run '
+              f'(BA_BENCH_SHARE_GPU=1 rehearses the ranks on one GPU)', file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+def exchange_trial(args, rank, world, local_rank):
+    """The same distributed loop with the sums over the ranks carried by the library's node exchange instead of
+    RCCL, in CHILD processes of the ranks (a group of their own on another port): whatever happens to them, the
+    measurement already taken stands.  Returns the child's report on rank 0 (a dict) or an error string."""
+    port = int(os.environ.get('MASTER_PORT', '29500')) + 23
+    env = dict(os.environ, MASTER_PORT=str(port), BA_NODE_EXCHANGE='1', RANK=str(rank), LOCAL_RANK=str(local_rank),
+               WORLD_SIZE=str(world))
+    cmd = [sys.executable, os.path.abspath(__file__), '--gpus', str(world), '--steps', str(args.steps), '--warmup',
+           str(args.warmup), '--cameras', str(args.cameras), '--track-len', str(args.track_len), '--total-points',
+           str(args.total_points), '--exchange-child']
+    try:
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    except subprocess.TimeoutExpired:
+        return 'no result within 240 s'
+    if res.returncode != 0:
+        tail = (res.stderr or '').strip().splitlines()[-1:] or ['']
+        return f'exit status {res.returncode}: {tail[0][:200]}'
+    for line in res.stdout.splitlines():
+        if line.startswith('{'):
+            return json.loads(line)
+    return 'no report' if rank == 0 else None
 
 
 def main():
@@ -68,12 +212,22 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=300)
     ap.add_argument('--warmup', type=int, default=300,
-                    help='the first few hundred iterations of a process run 5-10 %% slower than the steady state')
-    ap.add_argument('--points-per-gpu', type=int, default=1_000_000)
+                    help='the first few hundred iterations of a process run slower than the steady state')
+    ap.add_argument('--points-per-gpu', type=int, default=1_000_000, help='N = 1: points of the scene')
+    ap.add_argument('--total-points', type=int, default=10_000_000, help='N > 1: points of the scene, split over the GPUs')
     ap.add_argument('--cameras', type=int, default=2000)
     ap.add_argument('--track-len', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-jtj', action='store_true', help='skip the stand-alone timing of the J^T J pass')
+    ap.add_argument('--no-one-gpu-reference', action='store_true',
+                    help='N > 1: skip the timing of the whole scene on one GPU')
+    ap.add_argument('--no-exchange-trial', action='store_true',
+                    help='N > 1: skip the second measurement with the node exchange kernel')
+    ap.add_argument('--exchange-child', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -81,22 +235,27 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run')
+        print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}', file=sys.stderr)
+        sys.exit(2)
+    share = os.environ.get('BA_BENCH_SHARE_GPU') == '1'       # rehearsal: every rank on GPU 0, sums through gloo
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
-        dist.init_process_group('nccl', device_id=dev)
+        if share:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)
 
     ba = importlib.import_module('3d_reconstruction_amd')
-    N_total = args.points_per_gpu * world
+    N_total = args.points_per_gpu if world == 1 else args.total_points
     sc = ba.scenes.orbit_scene(N=N_total, K=args.cameras, track_len=args.track_len, seed=0, part=rank, parts=world)
     nv_local = int(sc['i'].size)
-    nv_t = torch.tensor([nv_local], dtype=torch.int64, device=dev)
+    nv_t = torch.tensor([nv_local], dtype=torch.int64, device='cpu' if share else dev)
     if world > 1:
         dist.all_reduce(nv_t)
     nv_total = int(nv_t.item())
-
-    total = args.steps + args.warmup
 
     def sync():
         torch.cuda.synchronize()
@@ -104,81 +263,124 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def measure():
-        sh = ba.engine.Shard(sc['i'], sc['j'], sc['uv'], sc['N_local'], sc['K'], sc['W'], sc['H'], dev,
-                             n_visible_total=nv_total)
-        try:
-            sh.set_params(sc['X_0'], sc['C_0'], sc['Theta_0'], sc['phi_x_0'])
-            fit = ba.SceneFit(sh, lr=1e-3, max_iters=total + 8, patience=1000, print_step=10 ** 9,
-                              printer=lambda *a: None)
-            # HIP events on every 16th launch of the observation-pass kernel (handed to the dispatch itself, so they
-            # hold the kernel's own begin and end), at least three samples in short runs
-            fit.timed_every = max(1, min(16, args.steps // 3))
-            for _ in range(args.warmup):
-                assert fit.step()
-            sh.eval_kernel_ms()          # drop warm-up timings
-            sync()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                fit.step()
-            sync()
-            return sh, fit, time.perf_counter() - t0
-        except Exception:
-            sh.close()
-            raise
+    def max_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64, device='cpu' if share else dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
-    try:
-        sh, fit, dt = measure()
-    except importlib.import_module('3d_reconstruction_amd._lib').BAError as e:
-        # several GPUs only: the node exchange gave up waiting for a rank (every rank ends up here, the
-        # others after their own wait has run out); measure again with the sums over ranks left to RCCL
-        if world == 1 or os.environ.get('BA_NO_NODE_EXCHANGE'):
-            raise
-        print(f'[bench] rank {rank}: {e}; measuring again without the node exchange', file=sys.stderr, flush=True)
-        os.environ['BA_NO_NODE_EXCHANGE'] = '1'
-        sh, fit, dt = measure()
-    dt_t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
-    dt = float(dt_t.item())
-
+    sh = ba.engine.Shard(sc['i'], sc['j'], sc['uv'], sc['N_local'], sc['K'], sc['W'], sc['H'], dev,
+                         n_visible_total=nv_total)
+    fit, dt = run_loop(ba, sh, sc, args.steps, args.warmup, sync)
+    dt = max_over_ranks(dt)
     kern_ms = sh.eval_kernel_ms()
+    total = args.steps + args.warmup
     E_first, E_last = float(fit.E[args.warmup]), float(fit.E[total - 1])
+    path = sh.rank_sum_path
+    fused = bool(fit.fuse)
 
+    if args.exchange_child:
+        if rank == 0:
+            print(json.dumps({'ms_per_step': dt / args.steps * 1e3, 'sum_over_ranks': path,
+                              'energy_last_timed': E_last}), flush=True)
+        sh.close()
+        sync()
+        dist.destroy_process_group()
+        return
+
+    N_loc, K = sc['N_local'], sc['K']
+    out = None
     if rank == 0:
-        N_loc, K = sc['N_local'], sc['K']
-        # gradient pass: 24 B per observation record, X in, gX out, cameras in and out
-        algo_bytes = 24 * nv_local + 24 * N_loc + 24 * N_loc + 48 * K + 48 * K
-        # the launch also carries the Adam update of the points (moments in, X and moments out,
-        # no gX round trip): bytes on top of the figure above, not counted in `achieved`
-        update_bytes = (48 + 72 - 24) * N_loc if fit.fuse else 0
-        avg_ms = float(np.mean(kern_ms)) if kern_ms else float('nan')
-        achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
+        if world == 1:
+            workload = (f'synthetic video-orbit scene, {N_total} points, K={K} cameras, track length {args.track_len}: '
+                        f'|V|={nv_total} observations on one GPU; full fit_scene iteration (fused observation pass + '
+                        f'Adam + gauge fix), gradient-only pass')
+        else:
+            workload = (f'synthetic video-orbit scene, {N_total} points, K={K} cameras, track length {args.track_len}: '
+                        f'|V|={nv_total} observations in total, split by point ranges over {world} GPUs '
+                        f'({nv_local} on rank 0), cameras replicated; full fit_scene iteration (fused observation '
+                        f'pass + sum of the camera block over the ranks + Adam + gauge fix), gradient-only pass')
         out = {
             'metric': 'BA observations/sec per iteration', 'value': nv_total * args.steps / dt,
             'unit': 'observations/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
+            'scaling': 'weak' if world == 1 else 'strong',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': f'synthetic video-orbit scene, {args.points_per_gpu} points per GPU, '
-                                   f'K={K} cameras, track length {args.track_len}: |V|={nv_total} observations '
-                                   f'({nv_local} on rank 0); full fit_scene iteration (fused observation pass + '
-                                   f'camera-block all-reduce + Adam + gauge fix), gradient-only pass',
-                       'points': N_total, 'cameras': K, 'observations': nv_total,
+            'config': {'workload': workload, 'points': N_total, 'cameras': K, 'observations': nv_total,
                        'parallelism': f'point-sharded x{world}, cameras replicated',
-                       'sum_over_ranks': sh.rank_sum_path,
-                       'energy_first_timed': E_first, 'energy_last_timed': E_last},
-            'roofline': {'bound': 'hbm', 'kernel': 'ba::k_run_pass<ba::GradOp, ba::RecI16> (fused observation pass, gradient + point update)',
-                         'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': measured_traffic(args.points_per_gpu, args.cameras, args.track_len),
-                         'algorithmic_bytes_per_launch': algo_bytes, 'avg_kernel_ms': avg_ms,
-                         'launches_timed': len(kern_ms), 'fused_point_update_bytes_per_launch': update_bytes,
-                         'achieved_with_point_update': (algo_bytes + update_bytes) / (avg_ms * 1e-3) / 1e9},
+                       'sum_over_ranks': path, 'energy_first_timed': E_first, 'energy_last_timed': E_last},
+            'roofline': roofline_block(
+                'ba::k_run_pass<ba::GradOp, ba::RecI16> (fused observation pass: gradient + point update)',
+                grad_pass_bytes(nv_local, N_loc, K), kern_ms,
+                measured_traffic('k_run_pass<ba::GradOp', N_loc, K, args.track_len) if fused else None,
+                {'observations_per_launch': nv_local,
+                 'note': 'achieved = algorithmic bytes (24 B per observation record + X in + gX out + cameras in '
+                         'and out) / kernel time; the kernel streams 8-byte records and carries the fused point '
+                         'update, so the bytes it really moves are `traffic`'}),
         }
+    sh.close()
+    del sh, fit
+
+    # ---- the pass with the J^T J blocks, stand-alone, on this rank's shard (and, at N = 1, on the 12.5 M-observation
+    # share a GPU holds when 100 M observations are split eight ways)
+    if not args.no_jtj:
+        jt = time_jtj_pass(ba, sc, dev, nv_total)
+        if rank == 0:
+            out['roofline_jtj'] = roofline_block(
+                'ba::k_run_pass<ba::JtjOp, ba::RecI16> (fused pass: residual + Jacobian + gradient + J^T J blocks)',
+                jtj_pass_bytes(nv_local, N_loc, K), jt,
+                measured_traffic('k_run_pass<ba::JtjOp', N_loc, K, args.track_len),
+                {'observations_per_launch': nv_local, 'timed': 'stand-alone launches, outside the timed loop',
+                 'parity': 'second-order extension without a counterpart in the reference: pinned by dense normal '
+                           'equations, not by reference outputs'})
+        if world == 1:
+            sc8 = ba.scenes.orbit_scene(N=args.total_points, K=args.cameras, track_len=args.track_len, seed=0, part=0,
+                                        parts=8)
+            jt8 = time_jtj_pass(ba, sc8, dev, int(sc8['i'].size))
+            out['roofline_jtj']['at_one_eighth_of_100M'] = {
+                'observations_per_launch': int(sc8['i'].size),
+                'avg_kernel_ms': float(np.mean(jt8)),
+                'frac': jtj_pass_bytes(int(sc8['i'].size), sc8['N_local'], K) / (float(np.mean(jt8)) * 1e-3) / 1e9
+                / HBM_PEAK_GBS}
+            del sc8
+
+    # ---- N > 1: the same scene on ONE GPU (rank 0 builds every rank's shard), for the 1 -> N speed-up
+    if world > 1 and not args.no_one_gpu_reference:
+        if rank == 0:
+            # rank 0 builds the other ranks' shards of the scene itself (seconds each; the others wait at the barrier)
+            parts = [sc] + [ba.scenes.orbit_scene(N=N_total, K=args.cameras, track_len=args.track_len, seed=0, part=r,
+                                                  parts=world) for r in range(1, world)]
+            offs = np.cumsum([0] + [g['N_local'] for g in parts])
+            whole = dict(sc, i=np.concatenate([(g['i'].astype(np.int64) + offs[r]).astype(np.int32)
+                                               for r, g in enumerate(parts)]),
+                         j=np.concatenate([g['j'] for g in parts]), uv=np.concatenate([g['uv'] for g in parts]),
+                         X_0=np.concatenate([g['X_0'] for g in parts]), N_local=int(offs[-1]))
+            del parts
+            one = ba.engine.Shard(whole['i'], whole['j'], whole['uv'], whole['N_local'], K, sc['W'], sc['H'], dev)
+            one.distributed = False
+            steps1 = max(10, min(args.steps, 100))
+            fit1, dt1 = run_loop(ba, one, whole, steps1, min(args.warmup, 100), torch.cuda.synchronize, timed=False)
+            out['strong_scaling'] = {
+                'one_gpu_ms_per_step': dt1 / steps1 * 1e3, 'one_gpu_value': nv_total * steps1 / dt1,
+                'speedup': (dt1 / steps1) / (dt / args.steps),
+                'note': f'the identical scene ({nv_total} observations) timed on rank 0 alone, {steps1} iterations'}
+            one.close()
+            del one, whole, fit1
+        dist.barrier()
+
+    # ---- N > 1: the node exchange kernel as the carrier of the sums, measured by child processes
+    if world > 1 and not args.no_exchange_trial:
+        rep = exchange_trial(args, rank, world, local_rank)
+        if rank == 0:
+            out['config']['transports'] = {
+                path: {'ms_per_step': out['ms_per_step']},
+                'node exchange kernel (opt-in, BA_NODE_EXCHANGE=1)': rep if isinstance(rep, dict) else {'error': rep}}
+        dist.barrier()
+
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(sc)
         print(json.dumps(out), flush=True)
-    sh.close()
     if world > 1:
         dist.destroy_process_group()
 
