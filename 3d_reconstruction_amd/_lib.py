@@ -64,6 +64,7 @@ SIGNATURES = {
     'ba_align_scene': (_int, [_i64, _i64] + [_p] * 10),
     'ba_normalize_scene': (_int, [_i64, _i64, _p, _p, _i64, _i64, _dbl, _p, _p, _p, _p]),
     'ba_project': (_int, [_i64, _i64, _i64, _p, _p, _p, _p, _p, _dbl, _dbl, _dbl, _int, _int, _p, _p]),
+    'ba_project_noalloc': (_int, [_i64, _i64, _i64, _p, _p, _p, _p, _p, _dbl, _dbl, _dbl, _int, _int, _p, _p]),
     'ba_reprojection_error': (_int, [_i64, _p, _p, _p, _p]),
     'ba_homography_diff_matrix': (_int, [_i64, _p, _p, _p, _dbl, _dbl, _int, _int, _p, _p]),
     'ba_subscenes_eval': (_int, [_i64, _i64] + [_p] * 7),

@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <mutex>
 #include "ba_device.h"
 
 #include <hip/hip_ext.h>
@@ -2908,6 +2909,59 @@ int ba_project(int64_t N, int64_t K, int64_t n, const int32_t *i, const int32_t 
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     hipFree(T);
     BA_HIP(e);
+    return BA_OK;
+}
+
+}  // extern "C"
+
+// ---- ba_project for callers that cannot allocate (HIP graph capture, serving loops): the camera table, which
+// ba_project keeps in a buffer it allocates and frees per call, lives in a fixed array of the code object.
+// Every GPU holds its own copy at its own address; host code reaches it through the pointer
+// hipGetSymbolAddress returns for the current device, never through the array's name.
+constexpr int64_t NOALLOC_MAX_CAMERAS = 16384;                       // 2 MiB of table per GPU
+constexpr int NOALLOC_MAX_DEVICES = 64;
+static __device__ __align__(256) double scratch[NOALLOC_MAX_CAMERAS * CAM_ROW];
+static double *g_scratch_ptr[NOALLOC_MAX_DEVICES] = {};
+static std::mutex g_scratch_mutex;
+
+// Device address of `scratch` on the current GPU (looked up once per GPU).
+static int noalloc_scratch(double **out) {
+    int dev = -1;
+    BA_HIP(hipGetDevice(&dev));
+    BA_REQUIRE(dev >= 0 && dev < NOALLOC_MAX_DEVICES, "ba_project_noalloc: device index out of range");
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        double *ptr = nullptr;
+        BA_HIP(hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)));
+        BA_REQUIRE(ptr != nullptr, "ba_project_noalloc: no address for the scratch array on this device");
+        g_scratch_ptr[dev] = ptr;
+    }
+    *out = g_scratch_ptr[dev];
+    return BA_OK;
+}
+
+extern "C" {
+
+int ba_project_noalloc(int64_t N, int64_t K, int64_t n, const int32_t *i, const int32_t *j, const double *X,
+                       const double *C, const double *Theta, double phi, double W, double H, int delete_back_points,
+                       int delete_boundary_points, double *out, void *stream) {
+    BA_REQUIRE(X && C && Theta && out, "ba_project_noalloc: null pointer");
+    BA_REQUIRE((i == nullptr) == (j == nullptr), "ba_project_noalloc: i and j must both be given or both be null");
+    BA_REQUIRE(i || n == N * K, "ba_project_noalloc: dense form needs n == N*K");
+    BA_REQUIRE(K >= 1 && K <= NOALLOC_MAX_CAMERAS,
+               "ba_project_noalloc: more than 16384 cameras do not fit the fixed camera table; use ba_project");
+    if (n == 0) return BA_OK;
+    hipStream_t st = (hipStream_t)stream;
+    double *T = nullptr;
+    const int rc = noalloc_scratch(&T);
+    if (rc != BA_OK) return rc;
+    // every row a call reads is written by the same call first: nothing of an earlier call's table is used
+    hipLaunchKernelGGL(k_camera_table, dim3(cdiv(K, 256)), dim3(256), 0, st, K, C, Theta, (const double *)nullptr, W, H,
+                       T, (double *)nullptr);
+    const double w_over_tan = W / tan(phi / 2.0);
+    hipLaunchKernelGGL(k_project, dim3(cdiv(n, 256)), dim3(256), 0, st, K, n, i, j, X, (const double *)T, w_over_tan, W,
+                       H, delete_back_points, delete_boundary_points, (double2 *)out);
+    BA_HIP(hipGetLastError());
     return BA_OK;
 }
 
