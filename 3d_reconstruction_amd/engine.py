@@ -469,11 +469,12 @@ class Shard:
             self._sum_over_ranks(self.red)
             self._sum_over_ranks(self.jred)
 
-    def lm_step(self, lam):
+    def lm_step(self, lam, on_system=None):
         """Solve the damped normal equations (J^T J + lam diag) d = -J^T r by Schur complement and
         dense Cholesky; leaves dX and dcam = [dC | dTheta | dphi].  Returns the pivot info (0 = ok).
         With several GPUs every rank adds its points' part of S and rhs, the sums go over the
-        ranks, and every rank factorises the (identical) reduced system itself."""
+        ranks, and every rank factorises the (identical) reduced system itself.
+        on_system(S, rhs), if given, sees the reduced system before it is factorised in place."""
         info = C.c_int(0)
         X = self.X
         first = 1
@@ -485,6 +486,8 @@ class Shard:
         if self.distributed:
             self._sum_over_ranks(self.S)
             self._sum_over_ranks(self.rhs)
+        if on_system is not None:
+            on_system(self.S, self.rhs)
         status = self.lib.ba_cholesky_solve(self.n_red, self.ld_red, ptr(self.S), ptr(self.rhs), C.byref(info),
                                             self.stream)
         if status == -4:

@@ -197,3 +197,107 @@ def test_fit_scene_lm_converges_like_dense_lm(ba):
     with pytest.raises(ValueError, match="optimizer='LM' needs"):
         ba.fit_scene_sparse(sc['i'], sc['j'], sc['uv'], sc['N_local'], sc['K'], sc['W'], sc['H'], 1e-3, 5, sc['X_0'],
                             sc['C_0'], sc['Theta_0'], sc['phi_x_0'], optimizer='LM', phi_x_mask=False)
+
+
+def test_twenty_thousand_cameras_lm_step_at_full_size(ba):
+    """The large-K configuration at its full size (K = 20 000 cameras, 1 M points, 10 M observations: reduced
+    system of 120 001 unknowns, S = 115 GB in HBM) through size-independent properties of ONE damped
+    Gauss-Newton step: the factorisation succeeds; S d = rhs holds on block rows of S saved before the in-place
+    factorisation (first, middle and last rows: element offsets beyond 2^32); six rows of S of a late camera equal
+    the Schur complement formed from per-observation Jacobians of the CPU restatement; the back-substituted
+    point steps satisfy the point rows of the normal equations; the energy decreases."""
+    K, N, lam = 20000, 1_000_000, 1e-3
+    sc = ba.scenes.orbit_scene(N=N, K=K, track_len=10, seed=0)
+    i, j, uv, W, H = sc['i'], sc['j'], sc['uv'], sc['W'], sc['H']
+    sh = ba.engine.Shard(i, j, uv, N, K, W, H, DEV)
+    sh.set_params(sc['X_0'], sc['C_0'], sc['Theta_0'], sc['phi_x_0'])
+    sh.gauge_fix()
+    sh.eval_jtj()
+    E0 = sh.energy()
+    n, ld = sh.n_red, sh.ld_red
+    assert n == 6 * K + 1 and ld * ld * 8 > 100e9
+    j_star = K - 7                                       # a late camera: rows 6 j* .. 6 j* + 5
+    starts = [0, (3 * K // 64) * 64, (6 * j_star // 64) * 64, ld - 64]
+    saved = {}
+
+    def keep(S, rhs):
+        saved['rhs'] = rhs.clone()
+        for r0 in starts:
+            saved[r0] = (S[r0:r0 + 64, :].clone(), S[:, r0:r0 + 64].clone())
+
+    assert sh.lm_step(lam, on_system=keep) == 0
+    d = sh.rhs.clone()                                    # the solution, reduced-system order
+    assert bool(torch.isfinite(d).all())
+    worst = 0.0
+    for r0 in starts:
+        rows, cols = saved[r0]
+        for k in range(64):
+            r = r0 + k
+            lhs = torch.dot(rows[k, :r + 1], d[:r + 1]) + torch.dot(cols[r + 1:, k], d[r + 1:])
+            scale = torch.dot(rows[k, :r + 1].abs(), d[:r + 1].abs()) + torch.dot(cols[r + 1:, k].abs(), d[r + 1:].abs())
+            worst = max(worst, float((lhs - saved['rhs'][r]).abs() / (scale + saved['rhs'][r].abs() + 1e-300)))
+    assert worst < 1e-9, worst
+
+    # current parameters in the caller's order, and the per-observation Jacobians of the restatement
+    X = sh.points_to_caller(sh.X).cpu().numpy()
+    C, Th, phi = sh.C.cpu().numpy(), sh.Theta.cpu().numpy(), float(sh.phi.item())
+    factors = orc.camera_rotation_tables(Theta=Th)
+    R = factors[1] @ factors[0] @ factors[2]
+    f = W / 2.0 / np.tan(phi / 2.0)
+
+    def blocks(sel):
+        r, J_X, J_T, J_p = orc.jacobian_blocks(X, C, R, *factors, f, phi, W, H, i[sel], j[sel], uv[sel])
+        return r, J_X, np.concatenate([-J_X, J_T], axis=2), J_p          # J_cam = [dr/dC | dr/dTheta] (2 x 6)
+
+    # (a) rows of S of camera j*: D' - sum_i W_ij*^T V'_i^-1 W_ij' over the cameras j' <= j*
+    pts = np.unique(i[j == j_star])
+    sel = np.isin(i, pts)
+    r_o, J_X, J_c, J_p = blocks(sel)
+    io, jo = i[sel], j[sel]
+    want = np.zeros((6, n))
+    mine = jo == j_star
+    B = np.einsum('vab,vac->bc', J_c[mine], J_c[mine])
+    want[:, 6 * j_star:6 * j_star + 6] = B + lam * np.diag(np.diag(B))
+    for pt in pts:
+        o = np.nonzero(io == pt)[0]
+        V = np.einsum('vab,vac->bc', J_X[o], J_X[o])
+        Vi = np.linalg.inv(V + lam * np.diag(np.diag(V)))
+        a = o[jo[o] == j_star][0]
+        Wa = J_X[a].T @ J_c[a]                                               # 3 x 6
+        for b in o:
+            want[:, 6 * jo[b]:6 * jo[b] + 6] -= Wa.T @ Vi @ (J_X[b].T @ J_c[b])
+    r0 = (6 * j_star // 64) * 64
+    got = saved[r0][0][6 * j_star - r0:6 * j_star - r0 + 6, :n].cpu().numpy()
+    lower = np.arange(n)[None, :] <= (6 * j_star + np.arange(6))[:, None]    # the valid (lower) triangle
+    assert np.abs(np.where(lower, got - want, 0.0)).max() < 1e-9 * np.abs(want).max()
+    assert np.count_nonzero(np.where(lower, want, 0.0)) > 36                # other cameras' blocks were compared
+
+    # (b) point rows of the damped normal equations for a sample of points
+    dX = sh.points_to_caller(sh.dX).cpu().numpy()
+    dcam = sh.dcam.cpu().numpy()
+    dC, dT, dphi = dcam[:3 * K].reshape(K, 3), dcam[3 * K:6 * K].reshape(K, 3), dcam[6 * K]
+    sample = np.random.default_rng(0).choice(N, 300, replace=False)
+    sel = np.isin(i, sample)
+    r_o, J_X, J_c, J_p = blocks(sel)
+    io, jo = i[sel], j[sel]
+    dcam_o = np.concatenate([dC[jo], dT[jo]], axis=1)
+    lin = np.einsum('vab,vb->va', J_c, dcam_o) + J_p * dphi + r_o           # residual change the camera side causes
+    worst = 0.0
+    for pt in sample:
+        o = io == pt
+        if not o.any():
+            continue
+        V = np.einsum('vab,vac->bc', J_X[o], J_X[o])
+        lhs = (V + lam * np.diag(np.diag(V))) @ dX[pt] + np.einsum('vab,va->b', J_X[o], lin[o])
+        worst = max(worst, np.abs(lhs).max() / (np.abs(V).max() * np.abs(dX[pt]).max() + 1e-300))
+    assert worst < 1e-8, worst
+
+    # (c) the step lowers the energy
+    sh.X.add_(sh.dX)
+    sh.cam.add_(sh.dcam)
+    sh.invalidate_table()
+    sh.gauge_fix()
+    sh.eval()
+    E1 = sh.energy()
+    assert E1 < 0.5 * E0, (E0, E1)
+    sh.close()
