@@ -746,6 +746,10 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_tile_fill(const int32_t *__restr
 // ---- gradient pass on camera runs (see ba_runpass.h) --------------------------------------------
 struct GradOp {
     static constexpr int NCV = 6, NPV = 3, NPART = 2, NOUT = 1, WAVES_PER_EU = 4, WAVES_PER_EU_COMPACT = 4;
+#ifndef BA_MOMENT_PREFETCH
+#define BA_MOMENT_PREFETCH 5
+#endif
+    static constexpr int MOMENT_PREFETCH = BA_MOMENT_PREFETCH;
     __host__ __device__ static constexpr int out_width(int) { return 3; }
     __host__ __device__ static constexpr int out_offset(int) { return 0; }
     __host__ __device__ static constexpr bool cv_used(int) { return true; }
@@ -867,7 +871,7 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_run_fill(const uint32_t *__restr
             const int plane = ((q % RUN_LEN) - c) & (RUN_LEN - 1);
             const int64_t idx = rb * RUN_LEN + (int64_t)plane * nruns + run;
             // the point's position in the LDS record array (pt_swz), so that the pass needs no index arithmetic
-            const uint32_t word = ((uint32_t)pt_swz((int)(pk >> 16), pt_stride) << 16) | ((uint32_t)(rho & 15) << RUN_SLOT_BITS) | (uint32_t)c;
+            const uint32_t word = ((uint32_t)run_pt_swz((int)(pk >> 16), pt_stride) << 16) | ((uint32_t)(rho & 15) << RUN_SLOT_BITS) | (uint32_t)c;
             const double2 uv = ouv[tm.e0 + e];
             if ((q % RUN_LEN) == 0) first_word = word;
             if (rrec) {
@@ -2085,7 +2089,7 @@ static int build_runs(ba_problem *p) {
         BA_HIP(hipMalloc(&p->rpack, sizeof(uint32_t) * n_rec));
         BA_HIP(hipMalloc(&p->ruv, sizeof(double2) * n_rec));
     }
-    p->run_pt_stride = (p->pt_cap + 7) / 8;
+    p->run_pt_stride = (p->pt_cap + RUN_LEN - 1) / RUN_LEN;
     while ((p->run_pt_stride & 3) != 2) ++p->run_pt_stride;   // 2 * odd, see pt_swz
     hipLaunchKernelGGL(k_run_fill, dim3(nt), dim3(TILE_BLOCK), fill_lds, 0, p->opack, p->ouv,
                        (const TileMeta *)p->tile_meta, p->run_ptr, p->cam_cap, p->run_pt_stride, p->rpack, p->ruv, p->rrec);

@@ -248,6 +248,7 @@ constexpr int CAMV_C = 28;
 struct JtjOp {
     // register budget: three waves per SIMD with the 8-byte records, two with the long ones
     static constexpr int NCV = CAMV_C, NPV = PTV, NPART = 3, NOUT = 2, WAVES_PER_EU = 2, WAVES_PER_EU_COMPACT = 3;
+    static constexpr int MOMENT_PREFETCH = 0;      // this pass never carries the point update
     // per-point sums: gradient (3) -> gX, V upper triangle (6) -> V
     __host__ __device__ static constexpr int out_width(int o) { return o == 1 ? 6 : 3; }
     __host__ __device__ static constexpr int out_offset(int o) { return o == 0 ? 0 : 3; }

@@ -39,7 +39,16 @@
 
 namespace ba {
 
-constexpr int RUN_LEN = 8;
+#ifndef BA_RUN_LEN
+#define BA_RUN_LEN 8
+#endif
+constexpr int RUN_LEN = BA_RUN_LEN;  // observations of a run (8 or 16)
+#ifndef BA_RUN_PF
+#define BA_RUN_PF 4
+#endif
+constexpr int RUN_PF = BA_RUN_PF;    // records a thread holds ahead of the one it works on (4 observation bodies of three
+                                     // interleaved waves cover the latency of HBM; 8 cost eight more registers)
+static_assert(RUN_LEN == 8 || RUN_LEN == 16, "runs of 8 or 16 observations");
 constexpr int RUN_SLOT_BITS = 12;    // record: pt_swz(point in tile) << 16 | (round & 15) << 12 | camera slot
 constexpr int RUN_MAX_CAMS = 1 << RUN_SLOT_BITS;
 
@@ -53,7 +62,15 @@ struct RecF64 {
         uint32_t pack;
         double2 uv;
     };
-    static __device__ __forceinline__ raw_t load(const RunArgs &a, int64_t idx);
+    // A tile's records as buffer resources (scalar registers): a load names the plane by a scalar offset and the
+    // run by a 32-bit per-lane offset, so no plane costs a 64-bit address register pair per lane; reads beyond the
+    // tile's records return zeros instead of faulting.
+    struct stream_t {
+        __amdgpu_buffer_rsrc_t pack, uv;
+    };
+    static __device__ __forceinline__ stream_t stream(const RunArgs &a, int64_t first, int count);
+    // record `lane` of the plane that starts `plane0` records into the tile (plane0: the same for the whole wave)
+    static __device__ __forceinline__ raw_t load(const stream_t &s, int plane0, uint32_t lane);
     static __device__ __forceinline__ uint32_t pack(const raw_t &r) { return r.pack; }
     static __device__ __forceinline__ bool valid(const raw_t &r) { return r.uv.x == r.uv.x; }
     static __device__ __forceinline__ double2 uv(const raw_t &r) { return r.uv; }
@@ -64,7 +81,11 @@ struct RecF64 {
 };
 struct RecI16 {
     typedef uint2 raw_t;    // x: pack, y: pixel x (low half) and y (high half) as int16
-    static __device__ __forceinline__ raw_t load(const RunArgs &a, int64_t idx);
+    struct stream_t {
+        __amdgpu_buffer_rsrc_t rec;
+    };
+    static __device__ __forceinline__ stream_t stream(const RunArgs &a, int64_t first, int count);
+    static __device__ __forceinline__ raw_t load(const stream_t &s, int plane0, uint32_t lane);
     static __device__ __forceinline__ uint32_t pack(const raw_t &r) { return r.x; }
     static __device__ __forceinline__ bool valid(const raw_t &r) { return (r.y & 0xffffu) != 0x8000u; }
     static __device__ __forceinline__ double2 uv(const raw_t &r) {
@@ -104,22 +125,42 @@ struct RunArgs {
     double *partials = nullptr;         // Op::NPART per tile
 };
 
-__device__ __forceinline__ RecF64::raw_t RecF64::load(const RunArgs &a, int64_t idx) {
+constexpr int BUFFER_RSRC_WORD3 = 0x00020000;      // raw buffer of 32-bit data on gfx950
+__device__ __forceinline__ RecF64::stream_t RecF64::stream(const RunArgs &a, int64_t first, int count) {
+    stream_t s;
+    s.pack = __builtin_amdgcn_make_buffer_rsrc((void *)(a.rpack + first), 0, count * 4, BUFFER_RSRC_WORD3);
+    s.uv = __builtin_amdgcn_make_buffer_rsrc((void *)(a.ruv + first), 0, count * 16, BUFFER_RSRC_WORD3);
+    return s;
+}
+__device__ __forceinline__ RecF64::raw_t RecF64::load(const stream_t &s, int plane0, uint32_t lane) {
     raw_t r;
-    r.pack = a.rpack[idx];
-    r.uv = a.ruv[idx];
+    r.pack = __builtin_amdgcn_raw_buffer_load_b32(s.pack, lane * 4u, plane0 * 4, 0);
+    const auto v = __builtin_amdgcn_raw_buffer_load_b128(s.uv, lane * 16u, plane0 * 16, 0);
+    r.uv = make_double2(__hiloint2double((int)v[1], (int)v[0]), __hiloint2double((int)v[3], (int)v[2]));
     return r;
 }
-__device__ __forceinline__ RecI16::raw_t RecI16::load(const RunArgs &a, int64_t idx) { return a.rrec[idx]; }
+__device__ __forceinline__ RecI16::stream_t RecI16::stream(const RunArgs &a, int64_t first, int count) {
+    stream_t s;
+    s.rec = __builtin_amdgcn_make_buffer_rsrc((void *)(a.rrec + first), 0, count * 8, BUFFER_RSRC_WORD3);
+    return s;
+}
+__device__ __forceinline__ RecI16::raw_t RecI16::load(const stream_t &s, int plane0, uint32_t lane) {
+    const auto v = __builtin_amdgcn_raw_buffer_load_b64(s.rec, lane * 8u, plane0 * 8, 0);
+    return make_uint2(v[0], v[1]);
+}
 
 __device__ __forceinline__ int pt_swz(int p, int S) { return (p & 7) * S + (p >> 3); }
+// the same for the run pass: RUN_LEN rows of S records (the 16 lanes the LDS serves together hold RUN_LEN-periodic
+// point numbers of two consecutive rounds: row = p mod RUN_LEN differs inside a round, p / RUN_LEN between the
+// rounds, and with S = 2 * odd and an odd record length the two sets fall on bank pairs of different parity)
+__host__ __device__ __forceinline__ int run_pt_swz(int p, int S) { return (p & (RUN_LEN - 1)) * S + p / RUN_LEN; }
 
 // doubles of a point's LDS record: x (3), the per-point sums, padded to an odd count
 __host__ __device__ constexpr int pt_record_doubles(int npv) { return (3 + npv) | 1; }
 
 // LDS doubles a workgroup of the pass needs
 __host__ __device__ inline size_t run_pass_lds_doubles(int ncv, int npv, int cam_cap, int pt_stride, int cacc_slots) {
-    return (size_t)cam_cap * ROW_LDS + (size_t)cacc_slots * ncv + (size_t)pt_record_doubles(npv) * 8 * pt_stride;
+    return (size_t)cam_cap * ROW_LDS + (size_t)cacc_slots * ncv + (size_t)pt_record_doubles(npv) * RUN_LEN * pt_stride;
 }
 template <class Op>
 __host__ __device__ inline size_t run_pass_lds_doubles(int cam_cap, int pt_stride, int cacc_slots) {
@@ -132,6 +173,7 @@ __host__ __device__ inline size_t run_pass_lds_doubles(int cam_cap, int pt_strid
 //   cv_lds(k) / cv_from_lds(c) (position of sum k among the used ones and back; the LDS accumulators hold only
 //   those: with 160 KB of LDS per CU in granules of 1280 bytes, three workgroups fit if each stays within 53 760
 //   bytes, and the J^T J pass at ~380 points and up to 20 cameras per tile is within a few hundred bytes of that), NCV, NPV, NPART, NOUT, out_width(o), out_offset(o) (slices of the per-point sums),
+//   MOMENT_PREFETCH (rounds of the fused point update whose moments are loaded ahead of the main loop; 0 where the registers do not allow it),
 //   obs(valid, x[3], rw[6], uv, cv[NCV] (+=), pv[NPV] (=), part[NPART] (+=)); everything it adds is zero when !valid
 template <class Op, class Rec>
 __global__ void __launch_bounds__(TILE_BLOCK, sizeof(typename Rec::raw_t) <= 8 ? Op::WAVES_PER_EU_COMPACT : Op::WAVES_PER_EU)
@@ -151,12 +193,27 @@ __global__ void __launch_bounds__(TILE_BLOCK, sizeof(typename Rec::raw_t) <= 8 ?
         return;
     }
     // this thread's first run: issue the record loads before anything else
-    typename Rec::raw_t rec[RUN_LEN];
+    const typename Rec::stream_t rs = Rec::stream(a, rb * RUN_LEN, nruns * RUN_LEN);
+    typename Rec::raw_t rec[RUN_PF];
     {
-        const int r = tid < nruns ? tid : nruns - 1;
-        const int64_t base = rb * RUN_LEN + r;
+        const uint32_t r = tid < nruns ? tid : nruns - 1;
 #pragma unroll
-        for (int k = 0; k < RUN_LEN; ++k) rec[k] = Rec::load(a, base + (int64_t)k * nruns);
+        for (int k = 0; k < RUN_PF; ++k) rec[k] = Rec::load(rs, k * nruns, r);
+    }
+
+    // the fused point update's moments of this thread's first MPF components: requested now, used after the main loop
+    constexpr int MPF = sizeof(typename Rec::raw_t) <= 8 ? Op::MOMENT_PREFETCH : 0;     // the long records leave no registers for it
+    const int n_comp = 3 * (tm.whi - tm.wlo);
+    const int64_t g0 = 3 * (int64_t)tm.wlo;
+    double spf[MPF > 0 ? MPF : 1], rpf[MPF > 0 ? MPF : 1];
+#pragma unroll
+    for (int m = 0; m < MPF; ++m) {
+        const int li = tid + m * TILE_BLOCK;
+        spf[m] = rpf[m] = 0.0;
+        if (a.upd.mode == 2 && li < n_comp) {
+            spf[m] = a.s_in[g0 + li];
+            rpf[m] = a.r_in[g0 + li];
+        }
     }
 
     constexpr int PREC = pt_record_doubles(NPV);                // doubles of a point's LDS record
@@ -182,7 +239,7 @@ __global__ void __launch_bounds__(TILE_BLOCK, sizeof(typename Rec::raw_t) <= 8 ?
         }
         for (int pt = tid; pt < np; pt += TILE_BLOCK) {
             const double *x = a.X + 3 * (int64_t)(p0 + pt);
-            double *rec_pt = pts + pt_swz(pt, S) * PREC;
+            double *rec_pt = pts + run_pt_swz(pt, S) * PREC;
             if (G) {
                 const double d0 = x[0] - g[9], d1 = x[1] - g[10], d2 = x[2] - g[11];
 #pragma unroll
@@ -205,7 +262,7 @@ __global__ void __launch_bounds__(TILE_BLOCK, sizeof(typename Rec::raw_t) <= 8 ?
 
     for (int r = tid; r < nruns; r += TILE_BLOCK) {
         const bool more = r + TILE_BLOCK < nruns;
-        const int64_t base_next = rb * RUN_LEN + (more ? r + TILE_BLOCK : r);
+        const uint32_t r_next = more ? r + TILE_BLOCK : r;
         const int slot = (int)(Rec::pack(rec[0]) & (RUN_MAX_CAMS - 1));   // one camera per run
         const int round = (int)(Rec::pack(rec[0]) >> RUN_SLOT_BITS) & 15;
         double2 rw[6];
@@ -223,11 +280,14 @@ __global__ void __launch_bounds__(TILE_BLOCK, sizeof(typename Rec::raw_t) <= 8 ?
         for (int k = 0; k < RUN_LEN; ++k) {
             double *pt_cur = pt_next;
             const double x[3] = {xn[0], xn[1], xn[2]};
-            const bool valid = Rec::valid(rec[k]);
-            const double2 uv = Rec::pix(rec[k]);
-            const uint32_t next_pack = k + 1 < RUN_LEN ? Rec::pack(rec[k + 1]) : 0u;
-            // this slot of the thread's next run (of this run again after the last one: no branch)
-            rec[k] = Rec::load(a, base_next + (int64_t)k * nruns);
+            const bool valid = Rec::valid(rec[k % RUN_PF]);
+            const double2 uv = Rec::pix(rec[k % RUN_PF]);
+            const uint32_t next_pack = k + 1 < RUN_LEN ? Rec::pack(rec[(k + 1) % RUN_PF]) : 0u;
+            // the record RUN_PF positions ahead in this thread's stream: a later one of this run, or one of the
+            // thread's next run (of this run again after the last one: no branch)
+            rec[k % RUN_PF] = k + RUN_PF < RUN_LEN
+                                  ? Rec::load(rs, (k + RUN_PF) * nruns, (uint32_t)r)
+                                  : Rec::load(rs, (k + RUN_PF - RUN_LEN) * nruns, r_next);
             double pv[NPV];
             op.obs(valid, x, rw, uv, cv, pv, part);
             if (k + 1 < RUN_LEN) {
@@ -265,15 +325,15 @@ __global__ void __launch_bounds__(TILE_BLOCK, sizeof(typename Rec::raw_t) <= 8 ?
     // next tile's first point (zeros)
     const int lo = tm.wlo - p0, hi = tm.whi - p0;
     if (a.upd.mode) {
-        // component li of the tile's write range (32-bit index arithmetic: the loop runs 3 x points / 256 times)
-        const int n_comp = 3 * (tm.whi - tm.wlo);
-        const int64_t g0 = 3 * (int64_t)tm.wlo;
-        for (int li = tid; li < n_comp; li += TILE_BLOCK) {
+        // component li of the tile's write range (32-bit index arithmetic: the loop runs 3 x points / 256 times).
+        // The first MPF rounds are unrolled: their moments were requested before the main loop, and their LDS
+        // reads are issued together (each would otherwise wait in turn behind the other workgroups' atomics).
+        auto fetch = [&](int li, double &x, double &g) {
             const int lpt = li / 3, comp = li - 3 * lpt, pt = lpt + lo;
             const int64_t gi = g0 + li;
-            double x, g = 0.0;
+            g = 0.0;
             if (pt >= 0 && pt < np) {
-                const double *rec_pt = pts + pt_swz(pt, S) * PREC;
+                const double *rec_pt = pts + run_pt_swz(pt, S) * PREC;
                 x = rec_pt[comp];
                 g = rec_pt[3 + comp];     // the gradient is the first slice of the per-point sums
             } else if (a.X_gauge) {   // a point nobody observes: only the stored value changes frame
@@ -282,16 +342,36 @@ __global__ void __launch_bounds__(TILE_BLOCK, sizeof(typename Rec::raw_t) <= 8 ?
             } else {
                 x = a.X[gi];
             }
-            double sv = 0.0, rv = 0.0;
-            if (a.upd.mode == 2) {
-                sv = a.s_in[gi];
-                rv = a.r_in[gi];
-            }
+        };
+        auto store = [&](int li, double x, double g, double sv, double rv) {
+            const int64_t gi = g0 + li;
             a.X_out[gi] = apply_rule(a.upd, x, g, &sv, &rv);
             if (a.upd.mode == 2) {
                 a.s_out[gi] = sv;
                 a.r_out[gi] = rv;
             }
+        };
+        if (MPF > 0) {
+            double xs[MPF > 0 ? MPF : 1], gs[MPF > 0 ? MPF : 1];
+#pragma unroll
+            for (int m = 0; m < MPF; ++m) {
+                const int li = tid + m * TILE_BLOCK;
+                if (li < n_comp) fetch(li, xs[m], gs[m]);
+            }
+#pragma unroll
+            for (int m = 0; m < MPF; ++m) {
+                const int li = tid + m * TILE_BLOCK;
+                if (li < n_comp) store(li, xs[m], gs[m], spf[m], rpf[m]);
+            }
+        }
+        for (int li = tid + MPF * TILE_BLOCK; li < n_comp; li += TILE_BLOCK) {
+            double x, g, sv = 0.0, rv = 0.0;
+            fetch(li, x, g);
+            if (a.upd.mode == 2) {
+                sv = a.s_in[g0 + li];
+                rv = a.r_in[g0 + li];
+            }
+            store(li, x, g, sv, rv);
         }
     }
 #pragma unroll
@@ -299,9 +379,21 @@ __global__ void __launch_bounds__(TILE_BLOCK, sizeof(typename Rec::raw_t) <= 8 ?
         double *dst = a.out[o];
         if (!dst) continue;
         const int w = Op::out_width(o), off = Op::out_offset(o);
-        for (int idx = w * lo + tid; idx < w * hi; idx += TILE_BLOCK) {
-            const int pt = idx >= 0 ? idx / w : -1, k = idx - w * pt;
-            dst[(int64_t)w * p0 + idx] = (idx >= 0 && pt < np) ? pts[pt_swz(pt, S) * PREC + 3 + off + k] : 0.0;
+        // four values per thread and trip, their LDS reads in flight together
+        constexpr int UNR = 4;
+        for (int base = w * lo + tid; base < w * hi; base += UNR * TILE_BLOCK) {
+            double v[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int idx = base + u * TILE_BLOCK;
+                const int pt = idx >= 0 ? idx / w : -1, k = idx - w * pt;
+                v[u] = (idx < w * hi && idx >= 0 && pt < np) ? pts[run_pt_swz(pt, S) * PREC + 3 + off + k] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int idx = base + u * TILE_BLOCK;
+                if (idx < w * hi) dst[(int64_t)w * p0 + idx] = v[u];
+            }
         }
     }
     for (int idx = tid; idx < NCVL * nc; idx += TILE_BLOCK) {
