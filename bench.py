@@ -138,14 +138,33 @@ def time_jtj_pass(ba, sc, dev, nv_total, launches=24):
         sh.close()
 
 
+PREHEAT_ITERATIONS = 700
+
+
+def preheat(ba, sh, sc, iterations=PREHEAT_ITERATIONS):
+    """Keeps the GPU busy with iterations of a throw-away fit (a fixed number: every rank walks the same sequence
+    of sums over the ranks; about 50 ms at 10 M observations) before anything is measured: after an
+    idle spell the chip raises its clock over the first 20-30 ms of load (measured: the same fit's pass kernel takes
+    53 us right after 2 s of idling and 49 us a few hundred iterations later, whatever its iteration number), and
+    a short run (W = 5, K = 20 is 2 ms) would otherwise be timed entirely inside that ramp."""
+    import torch
+    sh.set_params(sc['X_0'], sc['C_0'], sc['Theta_0'], sc['phi_x_0'])
+    fit = ba.SceneFit(sh, lr=1e-3, max_iters=iterations + 8, patience=10 ** 7, print_step=10 ** 9, printer=lambda *a: None)
+    for _ in range(iterations):
+        fit.step()
+    torch.cuda.synchronize()
+
+
 def run_loop(ba, sh, sc, steps, warmup, sync, timed=True):
     """`warmup` untimed and `steps` timed full iterations; returns (fit, seconds)."""
+    preheat(ba, sh, sc)
     sh.set_params(sc['X_0'], sc['C_0'], sc['Theta_0'], sc['phi_x_0'])
     total = steps + warmup
     fit = ba.SceneFit(sh, lr=1e-3, max_iters=total + 8, patience=1000, print_step=10 ** 9, printer=lambda *a: None)
-    # HIP events on every 16th launch of the observation-pass kernel (handed to the dispatch itself, so they
-    # hold the kernel's own begin and end), at least three samples in short runs
-    fit.timed_every = max(1, min(16, steps // 3)) if timed else 0
+    # HIP events on about ten launches of the observation-pass kernel spread over the timed region (handed to the
+    # dispatch itself, so they hold the kernel's own begin and end; such a launch costs the host about 30 us more than
+    # a plain one, which is why not every launch carries them), at least three samples in short runs
+    fit.timed_every = max(1, steps // 10 if steps >= 90 else -(-steps // 3)) if timed else 0
     for _ in range(warmup):
         if not fit.step():
             raise RuntimeError('the fit stopped during the warm-up')
@@ -211,8 +230,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=300)
-    ap.add_argument('--warmup', type=int, default=300,
-                    help='the first few hundred iterations of a process run slower than the steady state')
+    ap.add_argument('--warmup', type=int, default=300)
     ap.add_argument('--points-per-gpu', type=int, default=1_000_000, help='N = 1: points of the scene')
     ap.add_argument('--total-points', type=int, default=10_000_000, help='N > 1: points of the scene, split over the GPUs')
     ap.add_argument('--cameras', type=int, default=2000)
@@ -307,6 +325,7 @@ def main():
             'scaling': 'weak' if world == 1 else 'strong',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': workload, 'points': N_total, 'cameras': K, 'observations': nv_total,
+                       'preheat_iterations': PREHEAT_ITERATIONS,
                        'parallelism': f'point-sharded x{world}, cameras replicated',
                        'sum_over_ranks': path, 'energy_first_timed': E_first, 'energy_last_timed': E_last},
             'roofline': roofline_block(
