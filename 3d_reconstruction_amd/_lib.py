@@ -44,6 +44,8 @@ SIGNATURES = {
     'ba_backsubstitute': (_int, [_p, _p, _dbl, _p, _p, _p, _p, _p, _p, _p]),
     'ba_can_fuse_update': (_int, [_p]),
     'ba_eval_update': (_int, [_p] * 6 + [_int] + [_p] * 5 + [_int, _dbl, _dbl, _dbl, _dbl] + [_p] * 6),
+    'ba_eval_update_arm': (_int, [_p] * 6 + [_int] + [_p] * 5 + [_int, _dbl, _dbl, _dbl, _dbl] + [_p] * 6),
+    'ba_wait_energy_fire': (_int, [_p, C.POINTER(_dbl), _dbl, _dbl, _dbl, _dbl, C.POINTER(_int), _p]),
     'ba_gauge_points': (_int, [_i64, _p, _p, _p, _p]),
     'ba_fetch_double': (_int, [_p, C.POINTER(_dbl), _p]),
     'ba_post_energy': (_int, [_p, _p, _p]),

@@ -114,6 +114,17 @@ struct ba_problem {
     // timing ring
     std::vector<hipEvent_t> ev_begin, ev_end;
     int ev_count = 0;
+    // a pass armed by ba_eval_update_arm: launched by ba_wait_energy_fire the moment the awaited energy allows it
+    struct ArmedUpdate {
+        bool armed = false;
+        const double *X = nullptr, *X_gauge = nullptr, *C = nullptr, *Theta = nullptr, *phi = nullptr;
+        int flags = 0;
+        double *E_sum = nullptr, *gX = nullptr, *gC = nullptr, *gTheta = nullptr, *gphi = nullptr;
+        int rule = 0;
+        double lr = 0, gscale = 0, bc1 = 1, bc2 = 1;
+        const double *s_in = nullptr, *r_in = nullptr;
+        double *s_out = nullptr, *r_out = nullptr, *X_out = nullptr, *X_out_alt = nullptr;
+    } armed_update;
 };
 
 namespace ba {

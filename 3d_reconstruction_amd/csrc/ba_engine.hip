@@ -2693,6 +2693,46 @@ int ba_wait_energy(ba_problem *p, double *h_E_sum, void *stream) {
     return BA_OK;
 }
 
+int ba_eval_update_arm(ba_problem *p, const double *X, const double *X_gauge, const double *C, const double *Theta,
+                       const double *phi, int flags, double *E_sum, double *gX, double *gC, double *gTheta, double *gphi,
+                       int rule, double lr, double gscale, double bc1, double bc2, const double *s_in, double *s_out,
+                       const double *r_in, double *r_out, double *X_out, double *X_out_alt) {
+    BA_REQUIRE(p, "ba_eval_update_arm: null problem");
+    BA_REQUIRE(rule == 1 || rule == 2, "ba_eval_update_arm: rule must be 1 (SGD) or 2 (Adam)");
+    BA_REQUIRE(X && C && Theta && phi && X_out && (rule != 2 || (s_in && s_out && r_in && r_out)),
+               "ba_eval_update_arm: null pointer");
+    BA_REQUIRE(ba_can_fuse_update(p), "ba_eval_update_arm: needs the camera-run layout of the observation pass");
+    ba_problem::ArmedUpdate &a = p->armed_update;
+    a.X = X, a.X_gauge = X_gauge, a.C = C, a.Theta = Theta, a.phi = phi, a.flags = flags;
+    a.E_sum = E_sum, a.gX = gX, a.gC = gC, a.gTheta = gTheta, a.gphi = gphi;
+    a.rule = rule, a.lr = lr, a.gscale = gscale, a.bc1 = bc1, a.bc2 = bc2;
+    a.s_in = s_in, a.s_out = s_out, a.r_in = r_in, a.r_out = r_out, a.X_out = X_out, a.X_out_alt = X_out_alt;
+    a.armed = true;
+    return BA_OK;
+}
+
+int ba_wait_energy_fire(ba_problem *p, double *h_E_sum, double divisor, double lo, double hi, double alt_lo,
+                        int *h_fired, void *stream) {
+    BA_REQUIRE(p && h_E_sum && h_fired, "ba_wait_energy_fire: null pointer");
+    *h_fired = 0;
+    ba_problem::ArmedUpdate a = p->armed_update;
+    p->armed_update.armed = false;
+    const int rc = ba_wait_energy(p, h_E_sum, stream);
+    if (rc != BA_OK) return rc;
+    const double e = *h_E_sum / divisor;      // the caller's own arithmetic: its schedule sees exactly this value
+    if (!a.armed || !(e >= lo)) return BA_OK;                 // a NaN energy fails every comparison
+    int which = 0;
+    if (e < hi) which = 1;
+    else if (a.X_out_alt && e >= alt_lo) which = 2;
+    if (!which) return BA_OK;
+    const int rl = ba_eval_update(p, a.X, a.X_gauge, a.C, a.Theta, a.phi, a.flags, a.E_sum, a.gX, a.gC, a.gTheta, a.gphi,
+                                  a.rule, a.lr, a.gscale, a.bc1, a.bc2, a.s_in, a.s_out, a.r_in, a.r_out,
+                                  which == 1 ? a.X_out : a.X_out_alt, stream);
+    if (rl != BA_OK) return rl;
+    *h_fired = which;
+    return BA_OK;
+}
+
 int ba_eval_timing(ba_problem *p, float *h_ms, int capacity, int *h_count) {
     BA_REQUIRE(p && h_count, "ba_eval_timing: null pointer");
     int n = p->ev_count < capacity ? p->ev_count : capacity;

@@ -315,6 +315,46 @@ class Shard:
             self._node_exchange.check()
         return self._E_host.value / (2 * self.nV)
 
+    def arm_eval_update(self, rule, lr, bc1, bc2, X_in, X_gauge, cam_in, mom_x_in, outs, grad_cam=True, grad_phi=True,
+                        timed=False):
+        """Prepares the NEXT fused pass (eval_update with defer_finalize) on tensors that are not current yet - the
+        results of the step queued last - into the given output tensors (X_out, s_out, r_out, X_out_alt: the points go
+        to X_out if the awaited energy is an improvement, to X_out_alt (may be None) if it is not); nothing is
+        launched.  wait_energy_fire launches it the moment the awaited energy allows it."""
+        flags = (_lib.EVAL_GRAD_CAM if grad_cam else 0) | (_lib.EVAL_GRAD_PHI if grad_phi else 0) | \
+                (_lib.EVAL_TIMED if timed else 0) | (_lib.EVAL_REUSE_TABLE if self._table_cam is cam_in else 0) | \
+                _lib.EVAL_DEFER_FINALIZE
+        if self.distributed:
+            self._shared_sum_buffer()
+        X_out, s_out, r_out, X_alt = outs
+        if mom_x_in is not None:
+            mp = (mom_x_in[0].data_ptr(), s_out.data_ptr(), mom_x_in[1].data_ptr(), r_out.data_ptr())
+        else:
+            mp = (None, None, None, None)
+        c = cam_in.data_ptr()
+        K24 = 24 * self.K
+        o = self._out_ptrs
+        check(self.lib.ba_eval_update_arm(self.handle, X_in.data_ptr(), None if X_gauge is None else X_gauge.data_ptr(),
+                                          c, c + K24, c + 2 * K24, flags, o[0], None, o[2], o[3], o[4], rule, float(lr),
+                                          1.0 / self.nV, float(bc1), float(bc2), *mp, X_out.data_ptr(),
+                                          None if X_alt is None else X_alt.data_ptr()))
+        self._armed_cam = cam_in
+
+    def wait_energy_fire(self, lo, hi, alt_lo):
+        """wait_energy that launches the armed pass if lo <= E < hi (returns fired = 1) or, into the alternative
+        buffer, if E >= hi and E >= alt_lo (fired = 2); returns (E, fired).  A fired pass is followed at once by the
+        sum of its raw sums over the ranks, as eval_update(defer_finalize=True) does."""
+        fired = C.c_int(0)
+        check(self.lib.ba_wait_energy_fire(self.handle, C.byref(self._E_host), float(2 * self.nV), float(lo), float(hi),
+                                           float(alt_lo), C.byref(fired), self.stream))
+        if fired.value:
+            self._table_cam = self._armed_cam
+            if self.distributed:
+                self._sum_over_ranks(self.raw)
+        if self._node_exchange:
+            self._node_exchange.check()
+        return self._E_host.value / (2 * self.nV), int(fired.value)
+
     def energy(self):
         """The same value through an 8-byte device-to-host copy that synchronises the stream."""
         check(self.lib.ba_fetch_double(self._out_ptrs[0], C.byref(self._E_host), self.stream))

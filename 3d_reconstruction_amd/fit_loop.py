@@ -100,6 +100,9 @@ class SceneFit:
         self.iters = 0
         self.finished = False
         self._intervened = False    # the schedule changed lr / moments / parameters in this pass
+        self._ahead = None          # results of a step whose pass was launched from inside the previous wait
+        self.launch_ahead = True    # let the wait for the energy launch the next pass (see _arm_next)
+        self.fired = 0              # passes launched that way
 
     # ---- optimiser state moves (p2w:411-414, 439-446) -----------------------------------------
     def _zero_moments(self):
@@ -238,14 +241,23 @@ class SceneFit:
         if self.finished or not (self.iters < self.max_iters):
             self.finished = True
             return False
+        armed = None
         if self.fuse:
-            queued = self._queue_fused()
+            queued, self._ahead = (self._ahead, None) if self._ahead is not None else (self._queue_fused(), None)
+            armed = self._arm_next(queued)
         else:
             self._evaluate()
             queued = self._queue_update() if self.speculate else None
-        self.E[self.iters] = self.sh.wait_energy()
+        fired = 0
+        if armed is not None:
+            self.E[self.iters], fired = self.sh.wait_energy_fire(*armed['window'])
+        else:
+            self.E[self.iters] = self.sh.wait_energy()
+        old_release, old_iters = self.release, self.iters
         self._intervened = False
         self._manage()
+        if fired and (self._intervened or self.iters != old_iters or (self.release is old_release) != (fired == 2)):
+            raise RuntimeError('a pass was launched ahead for an energy the schedule did not accept')
 
         it = self.iters
         if self.lr == 0.0:
@@ -280,7 +292,66 @@ class SceneFit:
         if self.adam:
             self.t += 1
         self.iters += 1
+        if fired:
+            self._ahead = self._finish_ahead(armed, fired)
         return True
+
+    def _arm_next(self, queued):
+        """Prepares the pass of the NEXT iteration so that the wait for this iteration's energy can launch it
+        itself (Shard.wait_energy_fire): the host then is not on the path between two passes.  It fires only for an
+        energy at which the schedule does not intervene: an improvement that neither raises the learning rate nor
+        meets a stopping rule (the schedule moves its snapshot forward), or no improvement while patience is left
+        (it counts down).  The buffers for the fired pass's results are the ones that are dead in the respective
+        case - the moments this iteration's pass read; the old snapshot's points after an improvement, the points
+        this iteration's pass read otherwise - i.e. the rotation of buffers the allocator would produce, decided
+        before the energy is known.  Returns None when the iteration does not qualify."""
+        sh = self.sh
+        if not self.launch_ahead or not hasattr(sh, 'arm_eval_update') or self.ret_all_iters or self.iters == 0 \
+                or self.iters >= self.max_iters - 1 or self.cam_range is None or not self.gauge:
+            return None
+        X_q, cam_q, mom_x_q, mom_cam_q, rec_q = queued
+        X_cur, X_old = sh._X_buf, self.release[0]
+        if X_old is X_cur or X_old is X_q or X_cur is X_q or X_old.shape != X_q.shape:
+            return None
+        s_out = r_out = None
+        if self.adam:
+            if self.mom_x is None or self.mom_x_tmp is None or self.mom_x[0] is self.mom_x_tmp[0] \
+                    or self.mom_x[0] is mom_x_q[0]:
+                return None
+            s_out, r_out = self.mom_x
+        inf = float('inf')
+        prev_min = self.E[:self.iters - 2 * self.patience].min() \
+            if self.stop_diff > 0.0 and self.iters > 2 * self.patience else None
+        # an improvement: not if it would raise the learning rate, nor into the window of the stopping difference
+        hi = self.E_min if self.success_timer > 0 else -inf
+        if prev_min is not None:
+            hi = min(hi, prev_min - self.stop_diff - 1e-12 * abs(prev_min))
+        # no improvement: only while patience is left, and not if the stopping difference is met as things stand
+        alt_ok = self.patience_timer > 0 and not self.increased and \
+            not (prev_min is not None and 0.0 < prev_min - self.E_min < self.stop_diff)
+        if hi == -inf and not alt_ok:
+            return None
+        bc1 = bc2 = 1.0
+        if self.adam:
+            bc1, bc2 = 1.0 - RHO_1 ** (self.t + 1), 1.0 - RHO_2 ** (self.t + 1)
+        timed = self.timed_every > 0 and self._passes % self.timed_every == 0
+        outs = (X_old, s_out, r_out, X_cur if alt_ok else None)
+        sh.arm_eval_update(2 if self.adam else 1, self.lr, bc1, bc2, X_q, rec_q, cam_q, mom_x_q, outs,
+                           grad_cam=self.masks[1], grad_phi=True, timed=timed)
+        return {'window': (self.stop_value, hi, self.E_min if alt_ok else inf), 'outs': outs}
+
+    def _finish_ahead(self, armed, fired):
+        """The camera-side step that follows a pass launched ahead (the state it reads is current by now)."""
+        self.fired += 1
+        self._passes += 1
+        self._grad_x_valid = False
+        bc1 = bc2 = 1.0
+        if self.adam:
+            bc1, bc2 = 1.0 - RHO_1 ** self.t, 1.0 - RHO_2 ** self.t
+        X_old, s_out, r_out, X_alt = armed['outs']
+        cam, mom_cam, rec = self.sh.camera_update(2 if self.adam else 1, self.lr, bc1, bc2, self.cam_range, self.mom_cam,
+                                                  self.gauge, finalize=True)
+        return (X_old if fired == 1 else X_alt), cam, ((s_out, r_out) if self.adam else None), mom_cam, rec
 
     def _queue_update(self):
         """Update rule on every free group and gauge fix (p2w:704-712) from the current state into

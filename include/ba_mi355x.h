@@ -113,6 +113,23 @@ int ba_fetch_double(const double *src, double *h_out, void *stream);
 int ba_post_energy(ba_problem *p, const double *E_sum, void *stream);
 int ba_wait_energy(ba_problem *p, double *h_E_sum, void *stream);
 
+/* The same wait with a pass launched from inside it: ba_eval_update_arm stores the arguments of a ba_eval_update call
+ * (nothing is launched, nothing is read or written yet); ba_wait_energy_fire waits for the latest post like
+ * ba_wait_energy, forms e = *h_E_sum / divisor (divisor: 2 |V|, the caller's normalisation, so that the comparisons
+ * see the very number the caller's schedule will see) and launches the armed pass at once
+ *   with X_out      if lo <= e < hi          (*h_fired = 1: an energy that only moves the schedule's snapshot forward),
+ *   with X_out_alt  if hi <= e, alt_lo <= e  (*h_fired = 2: no improvement, patience left; X_out_alt may be NULL),
+ * otherwise not at all (*h_fired = 0) - in the fired cases the caller's LR schedule (p2w:365-454) would not have
+ * intervened, so the next pass starts without the round trip through the host interpreter.  Arming is consumed by
+ * the wait either way.  The caller guarantees that the output buffers are free in the case they are used in (each
+ * may still be referenced by state that the other outcomes keep alive). */
+int ba_eval_update_arm(ba_problem *p, const double *X, const double *X_gauge, const double *C, const double *Theta,
+                       const double *phi, int flags, double *E_sum, double *gX, double *gC, double *gTheta,
+                       double *gphi, int rule, double lr, double gscale, double bc1, double bc2, const double *s_in,
+                       double *s_out, const double *r_in, double *r_out, double *X_out, double *X_out_alt);
+int ba_wait_energy_fire(ba_problem *p, double *h_E_sum, double divisor, double lo, double hi, double alt_lo,
+                        int *h_fired, void *stream);
+
 /* Durations in milliseconds of the observation-pass kernel of the ba_eval calls made with
  * BA_EVAL_TIMED since the last call of this function (at most 256 are kept), measured with HIP
  * events recorded on the launch stream around that kernel.  Synchronises on the events. */

@@ -694,6 +694,7 @@ def test_table_consumers_after_a_merged_camera_step(ba, golden):
     sh = ba.engine.Shard(g['obs_i'], g['obs_j'], g['obs_xy'] + 0.5, N, K, int(g['W']), int(g['H']), DEV)
     sh.set_params(g['X_0'], g['C_0'], g['Theta_0'], float(g['phi_x_0']))
     fit = ba.SceneFit(sh, 1e-3, 50, printer=lambda *a: None)
+    fit.launch_ahead = False       # the test looks at the shard between two steps: nothing may be queued beyond them
     assert fit.fuse
     for _ in range(3):
         fit.step()
