@@ -43,10 +43,11 @@ SIGNATURES = {
     'ba_cholesky_solve': (_int, [_i64, _i64, _p, _p, C.POINTER(_int), _p]),
     'ba_backsubstitute': (_int, [_p, _p, _dbl, _p, _p, _p, _p, _p, _p, _p]),
     'ba_can_fuse_update': (_int, [_p]),
-    'ba_eval_update': (_int, [_p] * 6 + [_int] + [_p] * 5 + [_int, _dbl, _dbl, _dbl, _dbl] + [_p] * 6),
-    'ba_eval_update_arm': (_int, [_p] * 6 + [_int] + [_p] * 5 + [_int, _dbl, _dbl, _dbl, _dbl] + [_p] * 6),
+    'ba_eval_update': (_int, [_p] * 7 + [_int] + [_p] * 5 + [_int, _dbl, _dbl, _dbl, _dbl] + [_p] * 6),
+    'ba_eval_update_arm': (_int, [_p] * 7 + [_int] + [_p] * 5 + [_int, _dbl, _dbl, _dbl, _dbl] + [_p] * 6),
     'ba_wait_energy_fire': (_int, [_p, C.POINTER(_dbl), _dbl, _dbl, _dbl, _dbl, C.POINTER(_int), _p]),
     'ba_gauge_points': (_int, [_i64, _p, _p, _p, _p]),
+    'ba_scale_centres': (_int, [_i64, _p, _p, _p, _p]),
     'ba_fetch_double': (_int, [_p, C.POINTER(_dbl), _p]),
     'ba_post_energy': (_int, [_p, _p, _p]),
     'ba_wait_energy': (_int, [_p, C.POINTER(_dbl), _p]),
@@ -54,7 +55,7 @@ SIGNATURES = {
     'ba_adam_step': (_int, [_i64, _p, _p, _p, _p, _dbl, _dbl, _dbl, _dbl, _p, _p]),
     'ba_sgd_step': (_int, [_i64, _p, _p, _dbl, _dbl, _p, _p]),
     'ba_camera_step': (_int, [_p] * 8 + [_i64, _i64, _int, _dbl, _dbl, _dbl, _dbl, _int, _p, _p, _p]),
-    'ba_camera_step_finalize': (_int, [_p, _p, _p, _p, _int] + [_p] * 4 + [_i64, _i64, _int, _dbl, _dbl, _dbl, _dbl, _p, _p, _p]),
+    'ba_camera_step_finalize': (_int, [_p, _p, _p, _p, _p, _int] + [_p] * 4 + [_i64, _i64, _int, _dbl, _dbl, _dbl, _dbl, _p, _p, _p, _p]),
     'ba_triangulate': (_int, [_i64, _i64, _p, _p, _p, _p, _p, _dbl, _dbl, _dbl, _int, _i64, _p, _p, _p]),
     'ba_resect': (_int, [_i64, _i64, _p, _p, _p, _p, _dbl, _dbl, _dbl, _int, _i64, _p, _p, _p]),
     'ba_sum_buffer_size': (_int, [_p, _p]),

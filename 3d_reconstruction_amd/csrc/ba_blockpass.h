@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(256, Op::WAVES_PER_EU) k_block_pass(BlockArgs 
 
     for (int row = tid; row < nc; row += nthr) {
         const int j = tm.j0 >= 0 ? tm.j0 + row : a.cam_list[cb + row];
-        stage_camera_row_rt(a.T + (int64_t)j * CAM_ROW, a.C + 3 * (int64_t)j, rows + row * ROW_LDS);
+        stage_camera_row_rt(a.T + (int64_t)j * CAM_ROW, a.C + 3 * (int64_t)j, 1.0, rows + row * ROW_LDS);
     }
     // every point slot of the tile's chunks: x (zero past the tile's last point: such slots only
     // meet zero-weight records, which need finite coordinates) and zeroed sums

@@ -27,6 +27,8 @@ constexpr int SC_F = 0, SC_CX = 1, SC_CY = 2, SC_DPHI = 3, SC_COUNT = 8;
 
 constexpr int EVAL_BLOCK = 1024;          // threads per workgroup of the observation pass
 constexpr int EVAL_WAVES = EVAL_BLOCK / 64;
+constexpr int ESUM_SLOTS = 64;            // pairs of energy accumulators of a deferred pass
+constexpr int SUM_EXTRA = 2 * ESUM_SLOTS + 12;   // doubles behind the camera-frame sums: those pairs, camera 0's sums twice
 constexpr int TIMING_RING = 256;          // event pairs kept for ba_eval_timing
 
 void set_error(const std::string &msg);
@@ -94,9 +96,17 @@ struct ba_problem {
                                   // pass (which takes the centres from C itself) may reuse the table as it is
     double *sum_block = nullptr;  // owned: [cam_sums | partials]
     double *cam_sums = nullptr;   // 6 x K camera-frame sums (SoA: component-major), zero between passes
-    double *partials = nullptr;   // 2 per wave / tile, directly behind cam_sums
+    double *esum = nullptr;       // ESUM_SLOTS pairs of accumulators {sum r^2, sum m.r} of a pass whose finalisation is
+                                  // deferred: tile t adds to pair t mod ESUM_SLOTS atomically (one pair for all tiles
+                                  // serialises at the memory side), the camera step that finishes the pass zeroes them
+    double *cam0_sums = nullptr;  // camera 0's six camera-frame sums of a deferred pass, twice: the pass adds to the copy
+                                  // of its parity, the camera step reads that copy and zeroes the other one (every
+                                  // workgroup of the step reads camera 0's sums, so none of them can zero them)
+    int cam0_parity = 0;          // parity of the latest deferred pass
+    double *cam_table_alt = nullptr;   // second camera table: the ticket-free camera step reads one and writes the other
+    double *partials = nullptr;   // 2 per wave / tile (passes finished by k_finalize)
     int64_t partials_cap = 0;     // partial-sum pairs this problem may write
-    int64_t ext_partials_cap = 0; // > 0: cam_sums / partials live in a caller's buffer (ba_set_sum_buffer) with this many pairs
+    int64_t ext_partials_cap = 0; // > 0: cam_sums and esum live in a caller's buffer (ba_set_sum_buffer)
     double *scalars = nullptr;    // SC_COUNT
     int *flag = nullptr;          // 4 ints: validation flags, tile maxima
     int *step_counter = nullptr;  // arrival counter of the multi-workgroup camera step (kept at 0)
@@ -117,7 +127,7 @@ struct ba_problem {
     // a pass armed by ba_eval_update_arm: launched by ba_wait_energy_fire the moment the awaited energy allows it
     struct ArmedUpdate {
         bool armed = false;
-        const double *X = nullptr, *X_gauge = nullptr, *C = nullptr, *Theta = nullptr, *phi = nullptr;
+        const double *X = nullptr, *X_gauge = nullptr, *C = nullptr, *C_gauge = nullptr, *Theta = nullptr, *phi = nullptr;
         int flags = 0;
         double *E_sum = nullptr, *gX = nullptr, *gC = nullptr, *gTheta = nullptr, *gphi = nullptr;
         int rule = 0;

@@ -65,6 +65,14 @@ __device__ __forceinline__ void rotation_yxz(double tx, double ty, double tz, do
     *sz_out = sz;
 }
 
+// Scale factor of a gauge record (16 doubles: R0 (9), C0 (3), [12] factor, [13] j1, [14] squared longest baseline,
+// [15] flag).  The single-launch camera steps know the longest baseline when they end and store the factor; the
+// ticket-free step only collects the maximum ([14], by atomic max on the bit pattern) and leaves the division to
+// the readers ([15] != 0).  Same expression as those kernels evaluate, so the same bits.
+__device__ __forceinline__ double gauge_factor(const double *__restrict__ G) {
+    return G[15] != 0.0 ? 1.0 / sqrt(G[14]) : G[12];
+}
+
 // update rules (p2w:336-360)
 struct UpdateRule {
     int mode;  // 0 = leave unchanged, 1 = SGD (p2w:336-342), 2 = Adam (p2w:344-360)
@@ -109,13 +117,14 @@ constexpr int ROW_LDS = 12;  // doubles of a camera row kept in LDS: R (9), C (3
 // q = R^T (x - C) as R^T x + t: three instructions fewer per observation (one thread per row)
 // (the centre comes from the parameter vector, not from the row: the merged camera step leaves the rows' centres
 // to whoever needs them, see ba_problem::table_centres_stale)
+// `cscale`: what the stored centre still has to be multiplied by (1 unless a scale of the gauge fix is pending)
 __device__ __forceinline__ void stage_camera_row_rt(const double *__restrict__ src, const double *__restrict__ centre,
-                                                    double *__restrict__ dst) {
+                                                    double cscale, double *__restrict__ dst) {
     const double2 *s2 = (const double2 *)src;
     double2 v[6];
 #pragma unroll
     for (int k = 0; k < 5; ++k) v[k] = s2[k];
-    const double c0 = centre[0], c1 = centre[1], c2 = centre[2];
+    const double c0 = centre[0] * cscale, c1 = centre[1] * cscale, c2 = centre[2] * cscale;
     const double t0 = -(v[0].x * c0 + v[1].y * c1 + v[3].x * c2);   // column 0 of R: R00, R10, R20
     const double t1 = -(v[0].y * c0 + v[2].x * c1 + v[3].y * c2);
     const double t2 = -(v[1].x * c0 + v[2].y * c1 + v[4].x * c2);

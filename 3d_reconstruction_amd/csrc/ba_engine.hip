@@ -1071,7 +1071,7 @@ __global__ void __launch_bounds__(PS_POINTS) k_points_step(int64_t N, const doub
     }
     if (!gauge) return;
     __syncthreads();
-    const double c0 = gauge[9], c1 = gauge[10], c2 = gauge[11], factor = gauge[12];
+    const double c0 = gauge[9], c1 = gauge[10], c2 = gauge[11], factor = gauge_factor(gauge);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const int l = k * PS_POINTS + threadIdx.x;
@@ -1972,6 +1972,236 @@ __global__ void __launch_bounds__(256) k_camera_step_quad(CameraStep a, CameraSt
     }
 }
 
+// --------------------------------------------------------------------------------------------
+// The same step without any hand-over between workgroups (k_camera_step_free): the form the fused loop uses.
+// In k_camera_step_quad every workgroup drains its stores, draws a ticket, and the last one reduces the workgroups'
+// maxima, scales every centre and writes camera 0's staged results: 8 of that kernel's 15.5 us at 2 000 cameras
+// (store drain, returning atomic, a dependent trip for the tail).  Here nothing waits for anything:
+//   * the longest baseline is collected by an atomic max on the bit pattern of its square (non-negative doubles
+//     order like unsigned integers) in word 14 of the gauge record, which the PREVIOUS step (or the host, for the
+//     first one) left at zero; the readers of the record divide (gauge_factor);
+//   * the centres are written unscaled: the scale stays pending on them exactly as the rigid motion stays pending on
+//     the points, and the same record carries both (the next pass multiplies while it stages the camera rows, the
+//     next step while it loads the centres: the products are the ones the scaled store would have held);
+//   * camera 0, whose old values every workgroup reads, is written by workgroup 0 alone: the step writes new buffers
+//     (inputs and outputs must not overlap), the rotations come from one camera table and go to the other, and
+//     camera 0's camera-frame sums live in two copies used alternately (the step reads one and zeroes the other).
+// It always finishes a pass (energy accumulators -> energy, d E / d phi_x; camera-frame sums -> d E / d C,
+// d E / d Theta; energy mailbox).
+// --------------------------------------------------------------------------------------------
+struct FreeStep {
+    const double *T_in = nullptr;       // camera table the pass used (rotations of cam_in)
+    double *T_out = nullptr;            // table of the new parameters (rotations and cos/sin theta_z; centres unwritten)
+    const double *cam0_in = nullptr;    // camera 0's six camera-frame sums of the pass
+    double *cam0_zero = nullptr;        // the other copy: zeroed for the pass after this step
+    const double *in_scale = nullptr;   // gauge record whose scale is still pending on cam_in's centres, or null
+    double *next_gauge = nullptr;       // record the NEXT step will use: its word 14 is zeroed here (may be null)
+};
+
+__global__ void __launch_bounds__(256) k_camera_step_free(CameraStep a, FinalizeArgs fz, FreeStep fs) {
+    __shared__ double sR0[9], sC0[3];
+    __shared__ double red_e[2];
+    const int64_t K = a.K;
+    const int tid = threadIdx.x;
+    const int quad = tid >> 2, comp = tid & 3;
+    const bool is_c0 = quad == 63;
+    const int64_t j = is_c0 ? 0 : 1 + (int64_t)blockIdx.x * 63 + quad;
+    const bool live = j < K && comp < 3;
+    const bool own = live && !is_c0;                          // writes its results
+    const bool own0 = live && is_c0 && blockIdx.x == 0;       // camera 0: workgroup 0 writes
+    const bool writes = own || own0;
+    const int64_t jj = j < K ? j : 0;
+    const int cc = comp < 3 ? comp : 0;
+
+    // ---- everything this lane reads, requested at once
+    double in_sums[6], in_row[8];
+    {
+        const double *row = fs.T_in + jj * CAM_ROW;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) in_sums[k] = is_c0 ? fs.cam0_in[k] : fz.cam_sums[k * K + jj];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            in_row[k] = row[3 * cc + k];
+            in_row[3 + k] = row[3 + k];
+        }
+        in_row[6] = row[12];
+        in_row[7] = row[13];
+    }
+    const double in_factor = fs.in_scale ? gauge_factor(fs.in_scale) : 1.0;
+    double in_x[2], in_s[2] = {0.0, 0.0}, in_r[2] = {0.0, 0.0};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int64_t t = (h == 0 ? 0 : 3 * K) + 3 * jj + cc;
+        in_x[h] = a.cam_in[t];
+        if (a.rule.mode == 2 && t >= a.lo && t < a.hi) {
+            in_s[h] = a.s_in[t];
+            in_r[h] = a.r_in[t];
+        }
+    }
+    in_x[0] *= in_factor;
+
+    // ---- workgroup 0: the pass's energy accumulators -> energy and d E / d phi_x, mailbox, phi_x and its scalars
+    if (blockIdx.x == 0) {
+        const double dphi_old = a.scalars[SC_DPHI];
+        if (tid < 64) {
+            const double2 v = tid < fz.n_partials ? ((const double2 *)fz.partials)[tid] : make_double2(0.0, 0.0);
+            if (tid < fz.n_partials) ((double2 *)fz.partials)[tid] = make_double2(0.0, 0.0);
+            const double e = wave_sum(v.x), ps = wave_sum(v.y);
+            if (tid == 0) {
+                red_e[0] = e;
+                red_e[1] = ps;
+                fz.g_out[6 * K + 1] = e;
+                fz.g_out[6 * K] = dphi_old * ps;
+                if (fz.mailbox) {
+                    fz.mailbox[0] = e;
+                    __threadfence_system();
+                    fz.mailbox[1] = fz.seq;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 64) {
+            const int64_t t = 6 * K;
+            double ph = a.cam_in[t];
+            if (a.rule.mode && t >= a.lo && t < a.hi) {
+                double sv = 0.0, rv = 0.0;
+                if (a.rule.mode == 2) {
+                    sv = a.s_in[t];
+                    rv = a.r_in[t];
+                }
+                ph = apply_rule(a.rule, ph, dphi_old * red_e[1], &sv, &rv);
+                if (a.rule.mode == 2) {
+                    a.s[t] = sv;
+                    a.r[t] = rv;
+                }
+            } else if (a.rule.mode == 2) {
+                a.s[t] = a.s_in[t];
+                a.r[t] = a.r_in[t];
+            }
+            a.cam[t] = ph;
+            const double f = a.W / 2.0 / tan(ph / 2.0);
+            a.scalars[SC_F] = f;
+            a.scalars[SC_CX] = a.W / 2.0;
+            a.scalars[SC_CY] = a.H / 2.0;
+            a.scalars[SC_DPHI] = -f / sin(ph);
+        }
+        if (tid == 65 && fs.next_gauge) fs.next_gauge[14] = 0.0;
+        if (tid >= 66 && tid < 72) fs.cam0_zero[tid - 66] = 0.0;
+    }
+
+    // ---- un-normalised gradient of C[comp], Theta[comp] of this quad's camera
+    const double s0 = in_sums[0], s1 = in_sums[1], s2 = in_sums[2], w0 = in_sums[3], w1 = in_sums[4], w2 = in_sums[5];
+    const double gc = -(in_row[0] * s0 + in_row[1] * s1 + in_row[2] * s2);
+    const double gt = cc == 0 ? -(in_row[6] * w0 - in_row[7] * w1) : (cc == 1 ? -(in_row[3] * w0 + in_row[4] * w1 + in_row[5] * w2) : -w2);
+    if (writes) {
+        fz.g_out[3 * jj + cc] = gc;
+        fz.g_out[3 * K + 3 * jj + cc] = gt;
+    }
+    if (own) {      // the sums are consumed: leave them at zero for the next pass
+        fz.cam_sums[cc * K + jj] = 0.0;
+        fz.cam_sums[(3 + cc) * K + jj] = 0.0;
+    }
+
+    // ---- update rule (p2w:704-708) on the two parameters of this lane
+    double pnew[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int64_t t = (h == 0 ? 0 : 3 * K) + 3 * jj + cc;
+        double xn = in_x[h], sn_ = in_s[h], rn_ = in_r[h];
+        const bool free_t = a.rule.mode && t >= a.lo && t < a.hi;
+        if (free_t) xn = apply_rule(a.rule, in_x[h], h == 0 ? gc : gt, &sn_, &rn_);
+        if (writes && a.rule.mode == 2) {
+            if (free_t) {
+                a.s[t] = sn_;
+                a.r[t] = rn_;
+            } else {        // outside the free slice the moments are carried over
+                a.s[t] = a.s_in[t];
+                a.r[t] = a.r_in[t];
+            }
+        }
+        pnew[h] = xn;
+    }
+    double sn, cs;
+    sincos(pnew[1], &sn, &cs);
+    const double sx = quad_bcast<0>(sn), cx = quad_bcast<0>(cs), sy = quad_bcast<1>(sn), cy = quad_bcast<1>(cs),
+                 sz = quad_bcast<2>(sn), cz = quad_bcast<2>(cs);
+    const double c0v = quad_bcast<0>(pnew[0]), c1v = quad_bcast<1>(pnew[0]), c2v = quad_bcast<2>(pnew[0]);
+    double R[9];   // Ry Rx Rz (p2w:114-140)
+    {
+        const double sysx = sy * sx, cysx = cy * sx;
+        R[0] = cy * cz + sysx * sz;
+        R[1] = -cy * sz + sysx * cz;
+        R[2] = sy * cx;
+        R[3] = cx * sz;
+        R[4] = cx * cz;
+        R[5] = -sx;
+        R[6] = -sy * cz + cysx * sz;
+        R[7] = sy * sz + cysx * cz;
+        R[8] = cy * cx;
+    }
+    if (is_c0 && comp == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) sR0[k] = R[k];
+        sC0[0] = c0v;
+        sC0[1] = c1v;
+        sC0[2] = c2v;
+    }
+    __syncthreads();
+    double R0[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R0[k] = sR0[k];
+    const double c00 = sC0[0], c01 = sC0[1], c02 = sC0[2];
+
+    // ---- gauge fix of this camera (p2w:270-333): centre (C - C0) @ R0, rotation R0^T R
+    const double d0 = c0v - c00, d1 = c1v - c01, d2 = c2v - c02;
+    const double n0 = d0 * R0[0] + d1 * R0[3] + d2 * R0[6];
+    const double n1 = d0 * R0[1] + d1 * R0[4] + d2 * R0[7];
+    const double n2 = d0 * R0[2] + d1 * R0[5] + d2 * R0[8];
+    double Rn[9];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) Rn[3 * p + q] = R0[p] * R[q] + R0[3 + p] * R[3 + q] + R0[6 + p] * R[6 + q];
+    const double Cx = sqrt(Rn[3] * Rn[3] + Rn[4] * Rn[4]);   // get_rotations (p2w:260-266)
+    const double ay = cc == 0 ? -Rn[5] : (cc == 1 ? Rn[2] / Cx : Rn[3] / Cx);
+    const double ax = cc == 0 ? Cx : (cc == 1 ? Rn[8] / Cx : Rn[4] / Cx);
+    const double th_g = atan2(ay, ax);
+    const double n_own = cc == 0 ? n0 : (cc == 1 ? n1 : n2);
+    if (writes) {
+        a.cam[3 * jj + cc] = is_c0 ? 0.0 : n_own;      // the scale of the record below stays pending on the centres
+        a.cam[3 * K + 3 * jj + cc] = th_g;
+        if (a.R_out) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) a.R_out[9 * jj + 3 * cc + k] = Rn[3 * cc + k];
+        }
+        double *row = fs.T_out + jj * CAM_ROW;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) row[3 * cc + k] = Rn[3 * cc + k];
+        if (cc == 0) {
+            row[12] = Rn[4] / Cx;  // cos(theta_z), p2w:674
+            row[13] = Rn[3] / Cx;  // sin(theta_z), p2w:675
+        }
+    }
+    if (own0 && cc == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) a.gauge[k] = R0[k];
+        a.gauge[9] = c00;
+        a.gauge[10] = c01;
+        a.gauge[11] = c02;
+        a.gauge[12] = 0.0;
+        a.gauge[13] = -1.0;     // the camera at the far end of the longest baseline is not tracked here
+        a.gauge[15] = 1.0;      // the factor is 1 / sqrt(word 14)
+    }
+
+    // ---- longest baseline from camera 0 (p2w:322-326): maximum of the squared lengths, one atomic per wave
+    double best = (own && cc == 0) ? n0 * n0 + n1 * n1 + n2 * n2 : 0.0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) best = fmax(best, __shfl_xor(best, off));
+    if ((tid & 63) == 0)
+        __hip_atomic_fetch_max((unsigned long long *)(a.gauge + 14), (unsigned long long)__double_as_longlong(best),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Scale of the camera centres by the factor of a gauge record, for camera counts at which one workgroup (the
 // tail of k_camera_step_quad) would spend tens of microseconds on it: cam[3 .. 3K) and, if T is given, the rows'
 // centres.
@@ -1979,7 +2209,7 @@ __global__ void __launch_bounds__(256) k_scale_centres(int64_t K, double *__rest
                                                        const double *__restrict__ gauge) {
     const int64_t idx = 3 + (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= 3 * K) return;
-    const double c = cam[idx] * gauge[12];
+    const double c = cam[idx] * gauge_factor(gauge);
     cam[idx] = c;
     if (T) {
         const int64_t jc = idx / 3;
@@ -1987,12 +2217,21 @@ __global__ void __launch_bounds__(256) k_scale_centres(int64_t K, double *__rest
     }
 }
 
+// out = in with the centres (entries 3 .. 3K) multiplied by the record's factor; the rest is copied
+__global__ void __launch_bounds__(256) k_scale_centres_copy(int64_t K, const double *__restrict__ in,
+                                                            const double *__restrict__ gauge, double *__restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx > 6 * K) return;
+    const double v = in[idx];
+    out[idx] = (idx >= 3 && idx < 3 * K) ? v * gauge_factor(gauge) : v;
+}
+
 // X_out = ((X - C0) @ R0) * factor; X_out may be X
 __global__ void k_gauge_points(int64_t N, const double *X, double *X_out, const double *__restrict__ gauge) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     const double d0 = X[3 * i + 0] - gauge[9], d1 = X[3 * i + 1] - gauge[10], d2 = X[3 * i + 2] - gauge[11];
-    const double factor = gauge[12];
+    const double factor = gauge_factor(gauge);
     X_out[3 * i + 0] = (d0 * gauge[0] + d1 * gauge[3] + d2 * gauge[6]) * factor;
     X_out[3 * i + 1] = (d0 * gauge[1] + d1 * gauge[4] + d2 * gauge[7]) * factor;
     X_out[3 * i + 2] = (d0 * gauge[2] + d1 * gauge[5] + d2 * gauge[8]) * factor;
@@ -2321,6 +2560,7 @@ int ba_problem_destroy(ba_problem *p) {
     hipFree(p->buv);
     hipFree(p->blk_ptr);
     hipFree(p->cam_table);
+    hipFree(p->cam_table_alt);
     hipFree(p->sum_block);
     hipFree(p->scalars);
     hipFree(p->step_counter);
@@ -2423,16 +2663,20 @@ int ba_problem_create(int64_t N, int64_t K, int64_t nV, const int32_t *i, const 
     if (int rc_tiles = build_tiles(p)) return fail(rc_tiles);
 
     BA_TRY(hipMalloc(&p->cam_table, sizeof(double) * K * CAM_ROW));
+    BA_TRY(hipMalloc(&p->cam_table_alt, sizeof(double) * K * CAM_ROW));
+    BA_TRY(hipMemset(p->cam_table_alt, 0, sizeof(double) * K * CAM_ROW));
     {
         // camera-frame sums (kept at zero between passes by the finalisation) and per-tile partial sums in one
         // block, so that several GPUs can add both up with one collective
         size_t n_part = (size_t)p->grid * EVAL_WAVES;
         if ((size_t)p->n_tiles > n_part) n_part = p->n_tiles;
         p->partials_cap = (int64_t)n_part;
-        BA_TRY(hipMalloc(&p->sum_block, sizeof(double) * (K * 6 + 2 * n_part)));
-        BA_TRY(hipMemset(p->sum_block, 0, sizeof(double) * (K * 6 + 2 * n_part)));
+        BA_TRY(hipMalloc(&p->sum_block, sizeof(double) * (K * 6 + SUM_EXTRA + 2 * n_part)));
+        BA_TRY(hipMemset(p->sum_block, 0, sizeof(double) * (K * 6 + SUM_EXTRA + 2 * n_part)));
         p->cam_sums = p->sum_block;
-        p->partials = p->sum_block + K * 6;
+        p->esum = p->sum_block + K * 6;
+        p->cam0_sums = p->esum + 2 * ESUM_SLOTS;
+        p->partials = p->sum_block + K * 6 + SUM_EXTRA;
     }
     {
         void *host = nullptr, *dev = nullptr;
@@ -2471,6 +2715,7 @@ static UpdateRule make_rule(int mode, double lr, double gscale, double bc1, doub
 // optional extras of the camera-run pass: pending gauge of X and the fused point update
 struct FusedUpdate {
     const double *X_gauge = nullptr;
+    const double *C_scale = nullptr;    // gauge record whose scale is pending on the centres in C
     UpdateRule rule = {0, 0.0, 0.0, 1.0, 1.0};
     const double *s_in = nullptr, *r_in = nullptr;
     double *X_out = nullptr, *s_out = nullptr, *r_out = nullptr;
@@ -2490,6 +2735,9 @@ static int eval_impl(ba_problem *p, const double *X, const double *C, const doub
     // a table whose rows lack the centres (merged camera step) serves the run pass only
     const bool runs_expected = p->tiled && p->tiles_worth && p->run_ptr && ((flags >> 6) & 7) == 0 &&
                                !(flags & (BA_EVAL_CAM_ATOMICS | BA_EVAL_UNTILED | BA_EVAL_POINT_MAJOR));
+    if (fu && fu->C_scale)
+        BA_REQUIRE(runs_expected && (flags & BA_EVAL_REUSE_TABLE),
+                   "ba_eval_update: centres with a pending scale need the camera-run pass and the table their camera step left");
     if (!(flags & BA_EVAL_REUSE_TABLE) || (p->table_centres_stale && !runs_expected))
         if (int rc = camera_table(p, C, Theta, phi, st)) return rc;
     const bool want_gx = (flags & BA_EVAL_GRAD_X) != 0;
@@ -2558,6 +2806,12 @@ static int eval_impl(ba_problem *p, const double *X, const double *C, const doub
         ra.out[1] = ra.out[2] = nullptr;
         ra.cam_sums = p->cam_sums;
         ra.partials = p->partials;
+        if (flags & BA_EVAL_DEFER_FINALIZE) {     // the camera step that finishes the pass reads these
+            ra.esum = p->esum;
+            p->cam0_parity ^= 1;
+            ra.cam0 = p->cam0_sums + 6 * p->cam0_parity;
+        }
+        ra.C_scale = fu ? fu->C_scale : nullptr;
         n_partials = p->n_tiles;
         const size_t lds = sizeof(double) * run_pass_lds_doubles<GradOp>(p->cam_cap, p->run_pt_stride, p->run_slots_grad);
         const void *fn = p->compact ? (const void *)k_run_pass<GradOp, RecI16> : (const void *)k_run_pass<GradOp, RecF64>;
@@ -2598,7 +2852,8 @@ static int eval_impl(ba_problem *p, const double *X, const double *C, const doub
     const bool want_cam = (flags & BA_EVAL_GRAD_CAM) != 0;
     if (flags & BA_EVAL_DEFER_FINALIZE) {   // ba_camera_step_finalize finishes the pass
         BA_REQUIRE(want_cam && (flags & BA_EVAL_GRAD_PHI), "ba_eval: BA_EVAL_DEFER_FINALIZE needs the camera and phi gradients");
-        p->pending_partials = n_partials;
+        BA_REQUIRE(use_runs, "ba_eval: BA_EVAL_DEFER_FINALIZE needs the camera-run layout of the observation pass");
+        p->pending_partials = ESUM_SLOTS;        // the pairs of energy accumulators
         return BA_OK;
     }
     double *mailbox = nullptr;
@@ -2623,10 +2878,10 @@ int ba_eval(ba_problem *p, const double *X, const double *C, const double *Theta
 
 int ba_can_fuse_update(const ba_problem *p) { return p && p->tiled && p->tiles_worth && p->run_ptr ? 1 : 0; }
 
-int ba_eval_update(ba_problem *p, const double *X, const double *X_gauge, const double *C, const double *Theta,
-                   const double *phi, int flags, double *E_sum, double *gX, double *gC, double *gTheta, double *gphi,
-                   int rule, double lr, double gscale, double bc1, double bc2, const double *s_in, double *s_out,
-                   const double *r_in, double *r_out, double *X_out, void *stream) {
+int ba_eval_update(ba_problem *p, const double *X, const double *X_gauge, const double *C, const double *C_gauge,
+                   const double *Theta, const double *phi, int flags, double *E_sum, double *gX, double *gC,
+                   double *gTheta, double *gphi, int rule, double lr, double gscale, double bc1, double bc2,
+                   const double *s_in, double *s_out, const double *r_in, double *r_out, double *X_out, void *stream) {
     BA_REQUIRE(p, "ba_eval_update: null problem");
     BA_REQUIRE(rule == 1 || rule == 2, "ba_eval_update: rule must be 1 (SGD) or 2 (Adam)");
     BA_REQUIRE(X_out && (rule != 2 || (s_in && s_out && r_in && r_out)), "ba_eval_update: null pointer");
@@ -2635,6 +2890,7 @@ int ba_eval_update(ba_problem *p, const double *X, const double *X_gauge, const 
                "ba_eval_update: only the camera-run pass can fuse the update");
     FusedUpdate fu;
     fu.X_gauge = X_gauge;
+    fu.C_scale = C_gauge;
     fu.rule = make_rule(rule, lr, gscale, bc1, bc2);
     fu.s_in = s_in;
     fu.r_in = r_in;
@@ -2693,17 +2949,18 @@ int ba_wait_energy(ba_problem *p, double *h_E_sum, void *stream) {
     return BA_OK;
 }
 
-int ba_eval_update_arm(ba_problem *p, const double *X, const double *X_gauge, const double *C, const double *Theta,
-                       const double *phi, int flags, double *E_sum, double *gX, double *gC, double *gTheta, double *gphi,
-                       int rule, double lr, double gscale, double bc1, double bc2, const double *s_in, double *s_out,
-                       const double *r_in, double *r_out, double *X_out, double *X_out_alt) {
+int ba_eval_update_arm(ba_problem *p, const double *X, const double *X_gauge, const double *C, const double *C_gauge,
+                       const double *Theta, const double *phi, int flags, double *E_sum, double *gX, double *gC,
+                       double *gTheta, double *gphi, int rule, double lr, double gscale, double bc1, double bc2,
+                       const double *s_in, double *s_out, const double *r_in, double *r_out, double *X_out,
+                       double *X_out_alt) {
     BA_REQUIRE(p, "ba_eval_update_arm: null problem");
     BA_REQUIRE(rule == 1 || rule == 2, "ba_eval_update_arm: rule must be 1 (SGD) or 2 (Adam)");
     BA_REQUIRE(X && C && Theta && phi && X_out && (rule != 2 || (s_in && s_out && r_in && r_out)),
                "ba_eval_update_arm: null pointer");
     BA_REQUIRE(ba_can_fuse_update(p), "ba_eval_update_arm: needs the camera-run layout of the observation pass");
     ba_problem::ArmedUpdate &a = p->armed_update;
-    a.X = X, a.X_gauge = X_gauge, a.C = C, a.Theta = Theta, a.phi = phi, a.flags = flags;
+    a.X = X, a.X_gauge = X_gauge, a.C = C, a.C_gauge = C_gauge, a.Theta = Theta, a.phi = phi, a.flags = flags;
     a.E_sum = E_sum, a.gX = gX, a.gC = gC, a.gTheta = gTheta, a.gphi = gphi;
     a.rule = rule, a.lr = lr, a.gscale = gscale, a.bc1 = bc1, a.bc2 = bc2;
     a.s_in = s_in, a.s_out = s_out, a.r_in = r_in, a.r_out = r_out, a.X_out = X_out, a.X_out_alt = X_out_alt;
@@ -2725,7 +2982,7 @@ int ba_wait_energy_fire(ba_problem *p, double *h_E_sum, double divisor, double l
     if (e < hi) which = 1;
     else if (a.X_out_alt && e >= alt_lo) which = 2;
     if (!which) return BA_OK;
-    const int rl = ba_eval_update(p, a.X, a.X_gauge, a.C, a.Theta, a.phi, a.flags, a.E_sum, a.gX, a.gC, a.gTheta, a.gphi,
+    const int rl = ba_eval_update(p, a.X, a.X_gauge, a.C, a.C_gauge, a.Theta, a.phi, a.flags, a.E_sum, a.gX, a.gC, a.gTheta, a.gphi,
                                   a.rule, a.lr, a.gscale, a.bc1, a.bc2, a.s_in, a.s_out, a.r_in, a.r_out,
                                   which == 1 ? a.X_out : a.X_out_alt, stream);
     if (rl != BA_OK) return rl;
@@ -2879,29 +3136,88 @@ int ba_camera_step(ba_problem *p, const double *cam_in, double *cam_out, const d
                             bc1, bc2, gauge, R_out, gauge_out, stream);
 }
 
-int ba_camera_step_finalize(ba_problem *p, const double *cam_in, double *cam_out, double *g_out, int post,
-                            const double *s_in, double *s_out, const double *r_in, double *r_out, int64_t lo,
-                            int64_t hi, int rule, double lr, double gscale, double bc1, double bc2, double *R_out,
-                            double *gauge_out, void *stream) {
-    BA_REQUIRE(p && g_out, "ba_camera_step_finalize: null pointer");
+int ba_camera_step_finalize(ba_problem *p, const double *cam_in, const double *cam_in_gauge, double *cam_out,
+                            double *g_out, int post, const double *s_in, double *s_out, const double *r_in,
+                            double *r_out, int64_t lo, int64_t hi, int rule, double lr, double gscale, double bc1,
+                            double bc2, double *R_out, double *gauge_out, double *next_gauge, void *stream) {
+    BA_REQUIRE(p && g_out && cam_in && cam_out && gauge_out, "ba_camera_step_finalize: null pointer");
     BA_REQUIRE(p->pending_partials > 0,
                "ba_camera_step_finalize: no observation pass with BA_EVAL_DEFER_FINALIZE is waiting");
-    return camera_step_impl(p, cam_in, cam_out, nullptr, g_out, 1, post, s_in, s_out, r_in, r_out, lo, hi, rule, lr,
-                            gscale, bc1, bc2, 1, R_out, gauge_out, stream);
+    BA_REQUIRE(rule >= 0 && rule <= 2 && lo >= 0 && hi <= 6 * p->K + 1, "ba_camera_step_finalize: bad rule or range");
+    BA_REQUIRE(rule != 2 || (s_in && s_out && r_in && r_out), "ba_camera_step_finalize: null pointer");
+    BA_REQUIRE(p->K >= 2, "ba_camera_step_finalize: the gauge fix needs two cameras");
+    const int64_t n = 6 * p->K + 1;
+    // no workgroup waits for another: camera 0's old values, which all of them read, must survive the launch
+    BA_REQUIRE(cam_out + n <= cam_in || cam_in + n <= cam_out, "ba_camera_step_finalize: cam_out must not overlap cam_in");
+    BA_REQUIRE(rule != 2 || ((s_out + n <= s_in || s_in + n <= s_out) && (r_out + n <= r_in || r_in + n <= r_out)),
+               "ba_camera_step_finalize: the moments need output buffers of their own");
+    CameraStep a;
+    memset(&a, 0, sizeof(a));
+    a.K = p->K;
+    a.cam_in = cam_in;
+    a.cam = cam_out;
+    a.s_in = s_in;
+    a.r_in = r_in;
+    a.s = s_out;
+    a.r = r_out;
+    a.lo = lo;
+    a.hi = hi;
+    a.rule = make_rule(lo < hi ? rule : 0, lr, gscale, bc1, bc2);
+    if (rule == 2 && lo >= hi) a.rule.mode = 0;
+    a.do_gauge = 1;
+    a.W = p->W;
+    a.H = p->H;
+    a.scalars = p->scalars;
+    a.R_out = R_out;
+    a.gauge = gauge_out;
+    FinalizeArgs fz;
+    fz.partials = p->esum;      // the tiles' sums (over the GPUs too, if a collective ran in between); zeroed once read
+    fz.n_own = 0;
+    fz.n_partials = ESUM_SLOTS;
+    fz.cam_sums = p->cam_sums;
+    fz.g_out = g_out;
+    if (post) {
+        fz.mailbox = p->mailbox_dev;
+        fz.seq = (double)++p->post_seq;
+    }
+    FreeStep fs;
+    fs.T_in = p->cam_table;
+    fs.T_out = p->cam_table_alt;
+    fs.cam0_in = p->cam0_sums + 6 * p->cam0_parity;
+    fs.cam0_zero = p->cam0_sums + 6 * (p->cam0_parity ^ 1);
+    fs.in_scale = cam_in_gauge;
+    fs.next_gauge = next_gauge;
+    p->pending_partials = 0;
+    hipLaunchKernelGGL(k_camera_step_free, dim3(cdiv(p->K - 1, 63)), dim3(256), 0, (hipStream_t)stream, a, fz, fs);
+    BA_HIP(hipGetLastError());
+    std::swap(p->cam_table, p->cam_table_alt);      // the table of the new parameters is the current one
+    p->table_centres_stale = 1;                     // its rows hold rotations only
+    return BA_OK;
+}
+
+/* cam_out = cam_in with the scale of a gauge record applied to the centres (entries 3 .. 3K; camera 0 sits at the
+ * origin): what a caller outside the fused loop needs when a ticket-free camera step left that scale pending. */
+int ba_scale_centres(int64_t K, const double *cam_in, const double *gauge, double *cam_out, void *stream) {
+    BA_REQUIRE(K >= 1 && cam_in && gauge && cam_out && cam_in != cam_out, "ba_scale_centres: null or aliased pointer");
+    hipLaunchKernelGGL(k_scale_centres_copy, dim3(cdiv(6 * K + 1, 256)), dim3(256), 0, (hipStream_t)stream, K, cam_in,
+                       gauge, cam_out);
+    BA_HIP(hipGetLastError());
+    return BA_OK;
 }
 
 int ba_sum_buffer_size(ba_problem *p, int64_t *n_partials) {
     BA_REQUIRE(p && n_partials, "ba_sum_buffer_size: null pointer");
-    *n_partials = p->partials_cap;
+    *n_partials = SUM_EXTRA / 2;
     return BA_OK;
 }
 
 int ba_set_sum_buffer(ba_problem *p, double *buf, int64_t n_partials) {
     BA_REQUIRE(p && buf, "ba_set_sum_buffer: null pointer");
-    BA_REQUIRE(n_partials >= p->partials_cap, "ba_set_sum_buffer: room for fewer partial sums than this problem writes");
+    BA_REQUIRE(n_partials >= SUM_EXTRA / 2, "ba_set_sum_buffer: room for fewer pairs than ba_sum_buffer_size reports");
     BA_REQUIRE(p->pending_partials == 0, "ba_set_sum_buffer: an observation pass is waiting for its finalisation");
     p->cam_sums = buf;
-    p->partials = buf + p->K * 6;
+    p->esum = buf + p->K * 6;
+    p->cam0_sums = p->esum + 2 * ESUM_SLOTS;
     p->ext_partials_cap = n_partials;
     return BA_OK;
 }

@@ -122,7 +122,11 @@ struct RunArgs {
     double *X_out = nullptr, *s_out = nullptr, *r_out = nullptr;
     double *out[3] = {nullptr, nullptr, nullptr};           // per-point outputs (see the Op), any may be null
     double *cam_sums = nullptr;         // Op::NCV x K, component-major, accumulated with atomics
+    double *cam0 = nullptr;             // optional: camera 0's sums go here (Op::NCV doubles) instead of cam_sums
+    const double *C_scale = nullptr;    // optional gauge record: the centres in C still lack its scale factor
     double *partials = nullptr;         // Op::NPART per tile
+    double *esum = nullptr;             // optional: ESUM_SLOTS x Op::NPART accumulators the tiles add their partial sums to
+                                        // instead (atomically; whoever finishes the pass reads 64 pairs, not one per tile)
 };
 
 constexpr int BUFFER_RSRC_WORD3 = 0x00020000;      // raw buffer of 32-bit data on gfx950
@@ -189,7 +193,7 @@ __global__ void __launch_bounds__(TILE_BLOCK, sizeof(typename Rec::raw_t) <= 8 ?
     const int nruns = (int)(a.run_ptr[t + 1] - rb);
     __shared__ double red[NPART][TILE_WAVES];
     if (nruns == 0) {
-        if (tid < NPART) a.partials[NPART * (int64_t)t + tid] = 0.0;
+        if (tid < NPART && !a.esum) a.partials[NPART * (int64_t)t + tid] = 0.0;
         return;
     }
     // this thread's first run: issue the record loads before anything else
@@ -227,7 +231,8 @@ __global__ void __launch_bounds__(TILE_BLOCK, sizeof(typename Rec::raw_t) <= 8 ?
 
     for (int row = tid; row < nc; row += TILE_BLOCK) {
         const int j = tm.j0 >= 0 ? tm.j0 + row : a.cam_list[cb + row];
-        stage_camera_row_rt(a.T + (int64_t)j * CAM_ROW, a.C + 3 * (int64_t)j, rows + row * ROW_LDS);
+        stage_camera_row_rt(a.T + (int64_t)j * CAM_ROW, a.C + 3 * (int64_t)j, a.C_scale ? gauge_factor(a.C_scale) : 1.0,
+                            rows + row * ROW_LDS);
     }
     for (int idx = tid; idx < NCVL * nc * rep; idx += TILE_BLOCK) cacc[idx] = 0.0;
     {
@@ -235,7 +240,8 @@ __global__ void __launch_bounds__(TILE_BLOCK, sizeof(typename Rec::raw_t) <= 8 ?
         double g[13] = {1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0};
         if (G) {
 #pragma unroll
-            for (int k = 0; k < 13; ++k) g[k] = G[k];
+            for (int k = 0; k < 12; ++k) g[k] = G[k];
+            g[12] = gauge_factor(G);
         }
         for (int pt = tid; pt < np; pt += TILE_BLOCK) {
             const double *x = a.X + 3 * (int64_t)(p0 + pt);
@@ -319,7 +325,11 @@ __global__ void __launch_bounds__(TILE_BLOCK, sizeof(typename Rec::raw_t) <= 8 ?
         if (lane == 0) red[k][wid] = v;
     }
     __syncthreads();
-    if (tid < NPART) a.partials[NPART * (int64_t)t + tid] = (red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]);
+    if (tid < NPART) {
+        const double v = (red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]);
+        if (a.esum) __hip_atomic_fetch_add(a.esum + NPART * (t % ESUM_SLOTS) + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else a.partials[NPART * (int64_t)t + tid] = v;
+    }
 
     // every point is written by exactly one tile: its own points and the unobserved ones up to the
     // next tile's first point (zeros)
@@ -338,7 +348,7 @@ __global__ void __launch_bounds__(TILE_BLOCK, sizeof(typename Rec::raw_t) <= 8 ?
                 g = rec_pt[3 + comp];     // the gradient is the first slice of the per-point sums
             } else if (a.X_gauge) {   // a point nobody observes: only the stored value changes frame
                 const double *G = a.X_gauge, *xp = a.X + (gi - comp);
-                x = ((xp[0] - G[9]) * G[comp] + (xp[1] - G[10]) * G[3 + comp] + (xp[2] - G[11]) * G[6 + comp]) * G[12];
+                x = ((xp[0] - G[9]) * G[comp] + (xp[1] - G[10]) * G[3 + comp] + (xp[2] - G[11]) * G[6 + comp]) * gauge_factor(G);
             } else {
                 x = a.X[gi];
             }
@@ -402,7 +412,8 @@ __global__ void __launch_bounds__(TILE_BLOCK, sizeof(typename Rec::raw_t) <= 8 ?
         const int j = tm.j0 >= 0 ? tm.j0 + slot : a.cam_list[cb + slot];
         double v = cacc[idx];
         for (int r = 1; r < rep; ++r) v += cacc[idx + (size_t)r * NCVL * nc];
-        __hip_atomic_fetch_add(a.cam_sums + (int64_t)comp * a.K + j, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        double *dst = (j == 0 && a.cam0) ? a.cam0 + comp : a.cam_sums + (int64_t)comp * a.K + j;
+        __hip_atomic_fetch_add(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

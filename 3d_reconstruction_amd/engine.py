@@ -92,7 +92,8 @@ class Shard:
         # on demand.
         self._X_buf = z(self.N, 3)
         self._X_gauge = None
-        self.cam = z(2 * K3 + 1)
+        self._cam_buf = z(2 * K3 + 1)
+        self._next_rec = None       # gauge record of the next merged camera step (its word 14 already zero)
         self.gX = z(self.N, 3)
         self.red = z(2 * K3 + 2)
         self.gC = self.red[:K3].view(self.K, 3)
@@ -133,13 +134,33 @@ class Shard:
     def X(self, value):
         self._X_buf, self._X_gauge = value, None
 
+    @property
+    def cam(self):
+        """Current [C | Theta | phi_x]; a scale of the gauge fix that is still pending on the centres (the merged
+        camera step leaves it to its consumers and hangs the record on the tensor, `_ba_gauge`) is applied first."""
+        rec = getattr(self._cam_buf, '_ba_gauge', None)
+        if rec is not None:
+            out = torch.empty_like(self._cam_buf)
+            check(self.lib.ba_scale_centres(self.K, self._cam_buf.data_ptr(), rec.data_ptr(), out.data_ptr(), self.stream))
+            self._cam_buf = out
+        return self._cam_buf
+
+    @cam.setter
+    def cam(self, value):
+        self._cam_buf = value
+
+    @property
+    def cam_raw(self):
+        """The current camera tensor as it is (its centres may lack a pending scale, see `cam`)."""
+        return self._cam_buf
+
     def snapshot(self):
         """The current parameters as references (nothing is copied; current tensors are never
         written in place by the optimiser steps)."""
-        return (self._X_buf, self._X_gauge, self.cam)
+        return (self._X_buf, self._X_gauge, self._cam_buf)
 
     def restore(self, snap):
-        self._X_buf, self._X_gauge, self.cam = snap
+        self._X_buf, self._X_gauge, self._cam_buf = snap
 
     @property
     def can_fuse(self):
@@ -155,6 +176,7 @@ class Shard:
                 t = t.to(self.device)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=self.group)
             cap = int(t.item())
+            # [camera-frame sums (6K) | sum r^2, sum m.r]: what one sum over the ranks carries per iteration
             self.raw = torch.zeros(6 * self.K + 2 * cap, dtype=F64, device=self.device)
             check(self.lib.ba_set_sum_buffer(self.handle, self.raw.data_ptr(), cap))
         return self.raw
@@ -218,7 +240,7 @@ class Shard:
 
     @property
     def table_valid(self):
-        return self._table_cam is self.cam
+        return self._table_cam is self._cam_buf
 
     def close(self):
         self._node_exchange = None          # the exchange belongs to the process, not to the shard
@@ -271,7 +293,7 @@ class Shard:
     # ---- parameters -------------------------------------------------------------------------
     def set_params(self, X, C_, Theta, phi_x):
         self.X = self.points_to_engine(X).clone()
-        cam = torch.empty_like(self.cam)
+        cam = torch.empty_like(self._cam_buf)
         K3 = 3 * self.K
         cam[:K3] = _dev_tensor(C_, F64, self.device).reshape(-1)
         cam[K3:2 * K3] = _dev_tensor(Theta, F64, self.device).reshape(-1)
@@ -281,7 +303,7 @@ class Shard:
 
     def adopt(self, X, cam, X_gauge=None):
         """Make X / cam (tensors returned by step_update / eval_update + camera_update) current."""
-        self._X_buf, self._X_gauge, self.cam = X, X_gauge, cam
+        self._X_buf, self._X_gauge, self._cam_buf = X, X_gauge, cam
 
     def invalidate_table(self):
         """Call after writing into the current camera buffer in place."""
@@ -332,10 +354,11 @@ class Shard:
         else:
             mp = (None, None, None, None)
         c = cam_in.data_ptr()
+        cam_rec = getattr(cam_in, '_ba_gauge', None)
         K24 = 24 * self.K
         o = self._out_ptrs
         check(self.lib.ba_eval_update_arm(self.handle, X_in.data_ptr(), None if X_gauge is None else X_gauge.data_ptr(),
-                                          c, c + K24, c + 2 * K24, flags, o[0], None, o[2], o[3], o[4], rule, float(lr),
+                                          c, None if cam_rec is None else cam_rec.data_ptr(), c + K24, c + 2 * K24, flags, o[0], None, o[2], o[3], o[4], rule, float(lr),
                                           1.0 / self.nV, float(bc1), float(bc2), *mp, X_out.data_ptr(),
                                           None if X_alt is None else X_alt.data_ptr()))
         self._armed_cam = cam_in
@@ -395,8 +418,12 @@ class Shard:
         defer_finalize (all camera parameters free): the energy and the camera-side gradient are left
         to the camera_update(finalize=True) that must follow; with several GPUs the raw sums of the
         pass are added up over the ranks in between (one collective)."""
+        cam = self._cam_buf
+        cam_rec = getattr(cam, '_ba_gauge', None)
+        if cam_rec is not None and self._table_cam is not cam:      # no table of these cameras: take the plain route
+            cam, cam_rec = self.cam, None
         flags = (_lib.EVAL_GRAD_CAM if grad_cam else 0) | (_lib.EVAL_GRAD_PHI if grad_phi else 0) | \
-                (_lib.EVAL_TIMED if timed else 0) | (_lib.EVAL_REUSE_TABLE if self._table_cam is self.cam else 0) | \
+                (_lib.EVAL_TIMED if timed else 0) | (_lib.EVAL_REUSE_TABLE if self._table_cam is cam else 0) | \
                 (0 if self.distributed else _lib.EVAL_POST) | (_lib.EVAL_DEFER_FINALIZE if defer_finalize else 0)
         if self.distributed and defer_finalize:
             self._shared_sum_buffer()
@@ -407,14 +434,15 @@ class Shard:
             mp = (s_in.data_ptr(), mom_x[0].data_ptr(), r_in.data_ptr(), mom_x[1].data_ptr())
         else:
             mp = (None, None, None, None)
-        c = self.cam.data_ptr()
+        c = cam.data_ptr()
         K24 = 24 * self.K
         o = self._out_ptrs
         check(self.lib.ba_eval_update(self.handle, self._X_buf.data_ptr(),
-                                      None if self._X_gauge is None else self._X_gauge.data_ptr(), c, c + K24,
+                                      None if self._X_gauge is None else self._X_gauge.data_ptr(), c,
+                                      None if cam_rec is None else cam_rec.data_ptr(), c + K24,
                                       c + 2 * K24, flags, o[0], None, o[2], o[3], o[4], rule, float(lr),
                                       1.0 / self.nV, float(bc1), float(bc2), *mp, X_new.data_ptr(), self.stream))
-        self._table_cam = self.cam
+        self._table_cam = cam
         if self.distributed and defer_finalize:
             self._sum_over_ranks(self.raw)
         elif self.distributed:
@@ -429,6 +457,31 @@ class Shard:
         the points still have to go through."""
         new = (lambda t: t) if in_place else torch.empty_like
         lo, hi = cam_range if cam_range is not None else (0, 0)
+        if finalize:
+            # merged form: no workgroup of it waits for another, so it writes new buffers, leaves the scale of the
+            # gauge fix pending on the centres (the record hangs on the returned tensor) and collects the longest
+            # baseline in word 14 of the record, which the previous step (or zeros(), the first time) left at zero
+            if in_place:
+                raise ValueError('the camera step that finishes a pass writes new buffers')
+            cam_in = self._cam_buf
+            cam_new = torch.empty_like(cam_in)
+            if mom_cam is not None:
+                s_in, r_in = mom_cam
+                mom_cam = (torch.empty_like(s_in), torch.empty_like(r_in))
+                mp = (s_in.data_ptr(), mom_cam[0].data_ptr(), r_in.data_ptr(), mom_cam[1].data_ptr())
+            else:
+                mp = (None, None, None, None)
+            rec = self._next_rec if self._next_rec is not None else torch.zeros(16, dtype=F64, device=self.device)
+            self._next_rec = torch.empty(16, dtype=F64, device=self.device)
+            rec_in = getattr(cam_in, '_ba_gauge', None)
+            check(self.lib.ba_camera_step_finalize(self.handle, cam_in.data_ptr(),
+                                                   None if rec_in is None else rec_in.data_ptr(), cam_new.data_ptr(),
+                                                   self.red.data_ptr(), 1, *mp, lo, hi, rule, float(lr),
+                                                   1.0 / self.nV, float(bc1), float(bc2), self.R_gauge.data_ptr(),
+                                                   rec.data_ptr(), self._next_rec.data_ptr(), self.stream))
+            cam_new._ba_gauge = rec
+            self._table_cam = cam_new
+            return cam_new, mom_cam, rec
         cam_new = new(self.cam)
         if mom_cam is not None:
             s_in, r_in = mom_cam
@@ -437,13 +490,6 @@ class Shard:
         else:
             mp = (None, None, None, None)
         rec = torch.empty(16, dtype=F64, device=self.device) if gauge else None
-        if finalize:        # also finishes the pass queued with defer_finalize (and posts its energy)
-            check(self.lib.ba_camera_step_finalize(self.handle, self.cam.data_ptr(), cam_new.data_ptr(),
-                                                   self.red.data_ptr(), 1, *mp, lo, hi, rule, float(lr),
-                                                   1.0 / self.nV, float(bc1), float(bc2), self.R_gauge.data_ptr(),
-                                                   rec.data_ptr(), self.stream))
-            self._table_cam = cam_new
-            return cam_new, mom_cam, rec
         check(self.lib.ba_camera_step(self.handle, self.cam.data_ptr(), cam_new.data_ptr(), self.red.data_ptr(),
                                       *mp, lo, hi, rule, float(lr), 1.0 / self.nV, float(bc1), float(bc2),
                                       int(bool(gauge)), self.R_gauge.data_ptr(),

@@ -376,7 +376,7 @@ class SceneFit:
         X, mom_x = self.sh.eval_update(rule, self.lr, bc1, bc2, self.mom_x, grad_cam=self.masks[1],
                                        grad_phi=merge or self.masks[2], timed=timed, defer_finalize=merge)
         self._grad_x_valid = False
-        cam, mom_cam, rec = self.sh.cam, self.mom_cam, None
+        cam, mom_cam, rec = self.sh.cam_raw, self.mom_cam, None
         if self.cam_range is not None:
             cam, mom_cam, rec = self.sh.camera_update(rule, self.lr, bc1, bc2, self.cam_range, self.mom_cam, self.gauge,
                                                       finalize=merge)

@@ -92,13 +92,18 @@ int ba_eval(ba_problem *p, const double *X, const double *C, const double *Theta
  * are ((X - C0) @ R0) * factor: it is applied while X is loaded, so the rigid part of the gauge
  * fix (p2w:285-293, 327) needs no pass of its own either.  X_out then holds the updated points
  * BEFORE the next gauge fix; pair it with the gauge record of the camera step that follows.
- * gX may be NULL.  ba_gauge_points applies a gauge record: X_out = ((X_in - C0) @ R0) * factor. */
+ * C_gauge (optional; needs BA_EVAL_REUSE_TABLE): a gauge record whose scale factor is still pending on the camera
+ * centres in C, as ba_camera_step_finalize leaves them; applied while the camera rows are staged.
+ * gX may be NULL.  ba_gauge_points applies a gauge record: X_out = ((X_in - C0) @ R0) * factor.
+ * ba_scale_centres applies a record's pending scale to a parameter vector: cam_out[6K+1] = cam_in with the centres
+ * (entries 3 .. 3K) multiplied by the factor. */
 int ba_can_fuse_update(const ba_problem *p);
-int ba_eval_update(ba_problem *p, const double *X, const double *X_gauge, const double *C, const double *Theta,
-                   const double *phi, int flags, double *E_sum, double *gX, double *gC, double *gTheta,
-                   double *gphi, int rule, double lr, double gscale, double bc1, double bc2, const double *s_in,
-                   double *s_out, const double *r_in, double *r_out, double *X_out, void *stream);
+int ba_eval_update(ba_problem *p, const double *X, const double *X_gauge, const double *C, const double *C_gauge,
+                   const double *Theta, const double *phi, int flags, double *E_sum, double *gX, double *gC,
+                   double *gTheta, double *gphi, int rule, double lr, double gscale, double bc1, double bc2,
+                   const double *s_in, double *s_out, const double *r_in, double *r_out, double *X_out, void *stream);
 int ba_gauge_points(int64_t N, const double *X_in, double *X_out, const double *gauge, void *stream);
+int ba_scale_centres(int64_t K, const double *cam_in, const double *gauge, double *cam_out, void *stream);
 
 /* Copies one double from the device to *h_out and waits for it: the energy read-back the LR schedule
  * branches on (E[iters] at p2w:612 is a host value in the reference). */
@@ -123,10 +128,11 @@ int ba_wait_energy(ba_problem *p, double *h_E_sum, void *stream);
  * intervened, so the next pass starts without the round trip through the host interpreter.  Arming is consumed by
  * the wait either way.  The caller guarantees that the output buffers are free in the case they are used in (each
  * may still be referenced by state that the other outcomes keep alive). */
-int ba_eval_update_arm(ba_problem *p, const double *X, const double *X_gauge, const double *C, const double *Theta,
-                       const double *phi, int flags, double *E_sum, double *gX, double *gC, double *gTheta,
-                       double *gphi, int rule, double lr, double gscale, double bc1, double bc2, const double *s_in,
-                       double *s_out, const double *r_in, double *r_out, double *X_out, double *X_out_alt);
+int ba_eval_update_arm(ba_problem *p, const double *X, const double *X_gauge, const double *C, const double *C_gauge,
+                       const double *Theta, const double *phi, int flags, double *E_sum, double *gX, double *gC,
+                       double *gTheta, double *gphi, int rule, double lr, double gscale, double bc1, double bc2,
+                       const double *s_in, double *s_out, const double *r_in, double *r_out, double *X_out,
+                       double *X_out_alt);
 int ba_wait_energy_fire(ba_problem *p, double *h_E_sum, double divisor, double lo, double hi, double alt_lo,
                         int *h_fired, void *stream);
 
@@ -149,7 +155,8 @@ int ba_sgd_step(int64_t n, double *x, const double *g, double lr, double gscale,
  * Camera 0 goes to the origin with identity rotation; the longest baseline from camera 0
  * gets length 1.  C and Theta must be one buffer [C (3K) | Theta (3K)].  R_out[K][9] (optional)
  * receives R0^T R_j as align_scene(ret_R=True) does.
- * gauge_out[16]: R0 (9, row-major), C0 (3), scale factor, j1, 2 spare. */
+ * gauge_out[16]: R0 (9, row-major), C0 (3), scale factor, j1, squared longest baseline or 0, flag (0: the factor is
+ * word 12; 1: it is 1 / sqrt(word 14), see ba_camera_step_finalize). */
 int ba_gauge_fix(int64_t N, int64_t K, double *X, double *C, double *Theta, double *R_out,
                  double *gauge_out, void *stream);
 
@@ -185,24 +192,34 @@ int ba_camera_step(ba_problem *p, const double *cam_in, double *cam_out, const d
                    double *s_out, const double *r_in, double *r_out, int64_t lo, int64_t hi, int rule,
                    double lr, double gscale, double bc1, double bc2, int gauge, double *R_out,
                    double *gauge_out, void *stream);
-/* ba_camera_step with the gauge fix that also FINISHES a pass made with BA_EVAL_DEFER_FINALIZE: sum of
- * the per-tile partials -> energy and d E / d phi_x, camera-frame sums -> d E / d C, d E / d Theta, all
- * written to g_out = [gC (3K) | gTheta (3K) | gphi | E_sum]; `post` also posts the energy to the
- * mailbox (see ba_wait_energy).  One launch instead of two for a single-GPU iteration (with several
- * GPUs the camera-block reduction sits between the two kernels).  It leaves the rotations of the camera table
- * valid for cam_out but not the rows' centres: the camera-run pass (ba_eval, ba_eval_update with
- * BA_EVAL_REUSE_TABLE) takes the centres from its C argument, every other user of the table rebuilds it first
- * by itself. */
-int ba_camera_step_finalize(ba_problem *p, const double *cam_in, double *cam_out, double *g_out, int post,
-                            const double *s_in, double *s_out, const double *r_in, double *r_out, int64_t lo,
-                            int64_t hi, int rule, double lr, double gscale, double bc1, double bc2, double *R_out,
-                            double *gauge_out, void *stream);
+/* The camera step with the gauge fix that also FINISHES a pass made with BA_EVAL_DEFER_FINALIZE: the pass's energy
+ * accumulators -> energy and d E / d phi_x, camera-frame sums -> d E / d C, d E / d Theta, all written to
+ * g_out = [gC (3K) | gTheta (3K) | gphi | E_sum]; `post` also posts the energy to the mailbox (see ba_wait_energy).
+ * One launch for the whole camera side of an iteration (with several GPUs the sum over the ranks sits between the
+ * pass and this call), and no workgroup of it waits for another one:
+ *   - cam_out, s_out, r_out must not overlap their inputs (every workgroup reads camera 0's old values);
+ *   - the longest baseline is only COLLECTED: gauge_out[14] receives the maximum of the squared baselines by atomic
+ *     max and gauge_out[15] = 1, i.e. the factor of this record is 1 / sqrt(gauge_out[14]) (ba_gauge_points,
+ *     ba_scale_centres and ba_eval_update read records of both forms).  gauge_out[14] must be ZERO when the kernel
+ *     starts: a step zeroes that word of `next_gauge`, the record the caller will pass to the following step
+ *     (optional), the very first record is zeroed by the caller;
+ *   - the centres in cam_out are left WITHOUT that factor: pass gauge_out as C_gauge to the next ba_eval_update and
+ *     as cam_in_gauge to the next ba_camera_step_finalize (NULL: cam_in's centres are final), or apply it with
+ *     ba_scale_centres;
+ *   - it leaves the rotations of the camera table valid for cam_out but not the rows' centres: the camera-run pass
+ *     (ba_eval_update with BA_EVAL_REUSE_TABLE) takes the centres from its C argument, every other user of the
+ *     table rebuilds it first by itself. */
+int ba_camera_step_finalize(ba_problem *p, const double *cam_in, const double *cam_in_gauge, double *cam_out,
+                            double *g_out, int post, const double *s_in, double *s_out, const double *r_in,
+                            double *r_out, int64_t lo, int64_t hi, int rule, double lr, double gscale, double bc1,
+                            double bc2, double *R_out, double *gauge_out, double *next_gauge, void *stream);
 
 /* Several GPUs, no counterpart in the reference (single process): the sums a pass with BA_EVAL_DEFER_FINALIZE
- * leaves for ba_camera_step_finalize - camera-frame sums (6K doubles) followed by pairs of per-tile partial
- * sums - can live in a caller's device buffer of 6K + 2 * n_partials doubles, zeroed once, so that ONE
- * all-reduce of that buffer between the pass and ba_camera_step_finalize adds up the GPUs' shares
- * (n_partials: the largest ba_sum_buffer_size over the GPUs).  The buffer stays the caller's. */
+ * leaves for ba_camera_step_finalize - camera-frame sums (6K doubles) followed by n_partials pairs of energy
+ * accumulators {sum r^2, sum m.r} the pass's tiles add to (n_partials as ba_sum_buffer_size reports: 64) - can live
+ * in a caller's device buffer of 6K + 2 * n_partials doubles, zeroed once, so that ONE all-reduce of that buffer
+ * between the pass and ba_camera_step_finalize adds up the GPUs' shares (the camera step leaves the buffer at zero
+ * again).  The buffer stays the caller's. */
 int ba_sum_buffer_size(ba_problem *p, int64_t *n_partials);
 int ba_set_sum_buffer(ba_problem *p, double *buf, int64_t n_partials);
 int ba_points_step(int64_t N, const double *X_in, double *X_out, const double *gX, const double *s_in,

@@ -698,7 +698,8 @@ def test_table_consumers_after_a_merged_camera_step(ba, golden):
     assert fit.fuse
     for _ in range(3):
         fit.step()
-    assert sh._table_cam is sh.cam                     # the next pass would reuse the table
+    assert sh._table_cam is sh.cam_raw                 # the next pass would reuse the table
+    assert getattr(sh.cam_raw, '_ba_gauge', None) is not None      # ... and apply the pending scale of the centres
     sh.eval()                                          # camera runs: centres from the parameter vector
     E0, gC0, gX0 = sh.energy(), sh.gC.cpu().numpy().copy(), sh.gX.cpu().numpy().copy()
     for kw in (dict(point_major=True), dict(untiled=True), dict(cam_atomics=True)):
