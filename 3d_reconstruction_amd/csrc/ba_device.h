@@ -67,10 +67,11 @@ __device__ __forceinline__ void rotation_yxz(double tx, double ty, double tz, do
 
 // Scale factor of a gauge record (16 doubles: R0 (9), C0 (3), [12] factor, [13] j1, [14] squared longest baseline,
 // [15] flag).  The single-launch camera steps know the longest baseline when they end and store the factor; the
-// ticket-free step only collects the maximum ([14], by atomic max on the bit pattern) and leaves the division to
-// the readers ([15] != 0).  Same expression as those kernels evaluate, so the same bits.
+// ticket-free step only collects the maximum ([14], by atomic max on the bit pattern) and leaves 1 / sqrt to the
+// readers ([15] != 0): every one of them evaluates this same expression, so all see the same number (a few 1e-16
+// from the correctly rounded quotient; the chain of nine instructions sits in the prologue of every tile).
 __device__ __forceinline__ double gauge_factor(const double *__restrict__ G) {
-    return G[15] != 0.0 ? 1.0 / sqrt(G[14]) : G[12];
+    return G[15] != 0.0 ? fast_rsqrt(G[14]) : G[12];
 }
 
 // update rules (p2w:336-360)

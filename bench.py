@@ -196,10 +196,14 @@ def launch_ranks(args, argv):
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1',
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE,
+                                      text=True))
     rc = 0
     for p in procs:
-        rc = max(rc, abs(p.wait()))
+        out, _ = p.communicate()
+        for line in out.splitlines():      # the one JSON line goes to stdout, anything a library printed to stderr
+            print(line, file=sys.stdout if line.startswith('{') else sys.stderr, flush=True)
+        rc = max(rc, abs(p.returncode))
     return rc
 
 
