@@ -138,16 +138,25 @@ __device__ __forceinline__ void mfma_tile_64(const double *__restrict__ P, int64
                                              int64_t ldq, v4f64 acc[4][4]) {
     const int lane = threadIdx.x & 63;
     const int r16 = lane & 15, k4 = lane >> 4;
-    for (int kk = 0; kk < NB; kk += 4) {
-        double af[4], bf[4];
+    // sixteen columns of both operands are requested together (32 loads in flight), then multiplied: a load per
+    // matrix-core step makes the 64 columns sixteen dependent trips to memory, and these small kernels sit on the
+    // critical path of the panel factorisation
+    for (int kk = 0; kk < NB; kk += 16) {
+        double af[4][4], bf[4][4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) af[m] = P[(int64_t)(16 * m + r16) * ldp + kk + k4];
+        for (int c = 0; c < 4; ++c) {
 #pragma unroll
-        for (int n = 0; n < 4; ++n) bf[n] = Q[(int64_t)(16 * n + r16) * ldq + kk + k4];  // B[k][j] = Q[j][k]
+            for (int m = 0; m < 4; ++m) af[c][m] = P[(int64_t)(16 * m + r16) * ldp + kk + 4 * c + k4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+            for (int n = 0; n < 4; ++n) bf[c][n] = Q[(int64_t)(16 * n + r16) * ldq + kk + 4 * c + k4];  // B[k][j] = Q[j][k]
+        }
 #pragma unroll
-            for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[m], bf[n], acc[m][n], 0, 0, 0);
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[c][m], bf[c][n], acc[m][n], 0, 0, 0);
     }
 }
 

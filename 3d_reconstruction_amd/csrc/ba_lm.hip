@@ -807,18 +807,24 @@ struct BacksubArgs {
     const double *V, *Xphi, *gX;
     const double *d;  // solution of the reduced system, camera-major order (6j + k), phi at 6K
     double *dX;
+    double *X_trial;  // optional: X + dX, the trial point of the damped step
 };
 
 __global__ void __launch_bounds__(256) k_backsub(BacksubArgs a) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= a.N) return;
     const int64_t e0 = a.row_ptr[i], e1 = a.row_ptr[i + 1];
+    const double x[3] = {a.X[3 * i], a.X[3 * i + 1], a.X[3 * i + 2]};
     if (e0 == e1) {
         a.dX[3 * i] = a.dX[3 * i + 1] = a.dX[3 * i + 2] = 0.0;
+        if (a.X_trial) {
+            a.X_trial[3 * i] = x[0];
+            a.X_trial[3 * i + 1] = x[1];
+            a.X_trial[3 * i + 2] = x[2];
+        }
         return;
     }
     const double f = a.scalars[SC_F], pcx = a.scalars[SC_CX], pcy = a.scalars[SC_CY];
-    const double x[3] = {a.X[3 * i], a.X[3 * i + 1], a.X[3 * i + 2]};
     const double dphi_x = a.d[6 * a.K];
     double rh[3] = {-a.gX[3 * i] - a.Xphi[3 * i] * dphi_x, -a.gX[3 * i + 1] - a.Xphi[3 * i + 1] * dphi_x,
                     -a.gX[3 * i + 2] - a.Xphi[3 * i + 2] * dphi_x};
@@ -847,9 +853,13 @@ __global__ void __launch_bounds__(256) k_backsub(BacksubArgs a) {
     }
     double Vi[6];
     inv_sym3(a.V + 6 * i, a.lambda, Vi);
-    a.dX[3 * i + 0] = Vi[0] * rh[0] + Vi[1] * rh[1] + Vi[2] * rh[2];
-    a.dX[3 * i + 1] = Vi[1] * rh[0] + Vi[3] * rh[1] + Vi[4] * rh[2];
-    a.dX[3 * i + 2] = Vi[2] * rh[0] + Vi[4] * rh[1] + Vi[5] * rh[2];
+    const double dx[3] = {Vi[0] * rh[0] + Vi[1] * rh[1] + Vi[2] * rh[2], Vi[1] * rh[0] + Vi[3] * rh[1] + Vi[4] * rh[2],
+                          Vi[2] * rh[0] + Vi[4] * rh[1] + Vi[5] * rh[2]};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        a.dX[3 * i + c] = dx[c];
+        if (a.X_trial) a.X_trial[3 * i + c] = x[c] + dx[c];
+    }
 }
 
 // observation range of every point from the sorted point indices
@@ -870,14 +880,18 @@ __global__ void k_max_degree(const int64_t *__restrict__ row_ptr, int64_t N, int
 }
 
 // solution in camera-major order -> packed [dC (3K) | dTheta (3K) | dphi]
-__global__ void k_unpack_solution(int64_t K, const double *__restrict__ d, double *__restrict__ out) {
+// out (optional) receives the packed step, trial (optional) the packed parameters cam + step
+__global__ void k_unpack_solution(int64_t K, const double *__restrict__ d, double *__restrict__ out,
+                                  const double *__restrict__ cam, double *__restrict__ trial) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > 6 * K) return;
+    int64_t at = 6 * K;
     if (t < 6 * K) {
         const int64_t j = t / 6, k = t - 6 * j;
-        out[(k < 3 ? 0 : 3 * K) + 3 * j + (k % 3)] = d[t];
-    } else if (t == 6 * K) {
-        out[6 * K] = d[6 * K];
+        at = (k < 3 ? 0 : 3 * K) + 3 * j + (k % 3);
     }
+    if (out) out[at] = d[t];
+    if (trial) trial[at] = cam[at] + d[t];
 }
 
 static int cdiv_i(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
@@ -998,6 +1012,11 @@ int ba_eval_jtj(ba_problem *p, const double *X, const double *C, const double *T
     return BA_OK;
 }
 
+int ba_build_camera_table(ba_problem *p, const double *C, const double *Theta, const double *phi, void *stream) {
+    BA_REQUIRE(p && C && Theta && phi, "ba_build_camera_table: null pointer");
+    return camera_table(p, C, Theta, phi, (hipStream_t)stream);
+}
+
 static int ensure_row_ptr(ba_problem *p) {
     if (p->row_ptr) return BA_OK;
     BA_HIP(hipMalloc(&p->row_ptr, sizeof(int64_t) * (p->N + 1)));
@@ -1083,8 +1102,11 @@ int ba_schur_build(ba_problem *p, const double *X, double lambda, const double *
 }
 
 int ba_backsubstitute(ba_problem *p, const double *X, double lambda, const double *V, const double *Xphi,
-                      const double *gX, const double *d, double *dcam_packed, double *dX, void *stream) {
+                      const double *gX, const double *d, double *dcam_packed, double *dX, const double *cam,
+                      double *X_trial, double *cam_trial, void *stream) {
     BA_REQUIRE(p && X && V && Xphi && gX && d && dX, "ba_backsubstitute: null pointer");
+    BA_REQUIRE(!cam_trial || cam, "ba_backsubstitute: cam_trial needs the current parameters (cam)");
+    BA_REQUIRE(X_trial != X && X_trial != dX, "ba_backsubstitute: X_trial must be a buffer of its own");
     if (int rc = ensure_row_ptr(p)) return rc;
     hipStream_t st = (hipStream_t)stream;
     BacksubArgs a;
@@ -1102,9 +1124,11 @@ int ba_backsubstitute(ba_problem *p, const double *X, double lambda, const doubl
     a.gX = gX;
     a.d = d;
     a.dX = dX;
+    a.X_trial = X_trial;
     hipLaunchKernelGGL(k_backsub, dim3(cdiv_i(p->N, 256)), dim3(256), 0, st, a);
-    if (dcam_packed)
-        hipLaunchKernelGGL(k_unpack_solution, dim3(cdiv_i(6 * p->K + 1, 256)), dim3(256), 0, st, p->K, d, dcam_packed);
+    if (dcam_packed || cam_trial)
+        hipLaunchKernelGGL(k_unpack_solution, dim3(cdiv_i(6 * p->K + 1, 256)), dim3(256), 0, st, p->K, d, dcam_packed,
+                           cam, cam_trial);
     BA_HIP(hipGetLastError());
     return BA_OK;
 }

@@ -96,10 +96,6 @@ class Shard:
         self._next_rec = None       # gauge record of the next merged camera step (its word 14 already zero)
         self.gX = z(self.N, 3)
         self.red = z(2 * K3 + 2)
-        self.gC = self.red[:K3].view(self.K, 3)
-        self.gTheta = self.red[K3:2 * K3].view(self.K, 3)
-        self.gphi = self.red[2 * K3:2 * K3 + 1]
-        self.E_sum = self.red[2 * K3 + 1:]
         self.gauge = z(16)
         self.R_gauge = z(self.K, 9)
         self._table_cam = None      # the cam tensor the handle's camera table was built from
@@ -113,12 +109,22 @@ class Shard:
         self._stage_reduce = self.distributed and torch.distributed.get_backend(group) == 'gloo'
         self._stream_allreduce = False     # not yet tried; then a StreamAllReduce or None (torch.distributed)
         self._node_exchange = False        # not yet tried; then a NodeExchange (short sums inside one node) or None
-        self._out_ptrs = [t.data_ptr() for t in (self.E_sum, self.gX, self.gC, self.gTheta, self.gphi)]
+        self._bind_gradient(self.gX, self.red)
         self._E_host = C.c_double(0.0)
         # Several GPUs: the sums a deferred pass leaves for the camera step (camera-frame sums, per-tile partial
         # sums) live in one tensor of this class, summed over the ranks with one collective.
         # (created by the first deferred pass: a collective, every rank gets there in the same iteration)
         self.raw = None
+
+    def _bind_gradient(self, gX, red):
+        """Makes (gX, red = [gC | gTheta | gphi | sum r^2]) the buffers the passes write."""
+        K3 = 3 * self.K
+        self.gX, self.red = gX, red
+        self.gC = red[:K3].view(self.K, 3)
+        self.gTheta = red[K3:2 * K3].view(self.K, 3)
+        self.gphi = red[2 * K3:2 * K3 + 1]
+        self.E_sum = red[2 * K3 + 1:]
+        self._out_ptrs = [t.data_ptr() for t in (self.E_sum, self.gX, self.gC, self.gTheta, self.gphi)]
 
     @property
     def X(self):
@@ -530,14 +536,38 @@ class Shard:
             n, ld = C.c_int64(0), C.c_int64(0)
             check(self.lib.ba_schur_dim(self.K, C.byref(n), C.byref(ld)))
             self.n_red, self.ld_red = int(n.value), int(ld.value)
-            self.V, self.Xphi = z(self.N, 6), z(self.N, 3)
+            self.Xphi = z(self.N, 3)
             # camera-side blocks in one buffer (one cross-GPU sum): [B (21K) | bphi (6K) | hphi]
-            self.jred = z(27 * self.K + 1)
-            self.B = self.jred[:21 * self.K].view(self.K, 21)
-            self.bphi = self.jred[21 * self.K:27 * self.K].view(self.K, 6)
-            self.hphi = self.jred[27 * self.K:]
+            self._bind_blocks(z(self.N, 6), z(27 * self.K + 1))
             self.S, self.rhs = z(self.ld_red, self.ld_red), z(self.ld_red)
             self.dX, self.dcam = z(self.N, 3), z(6 * self.K + 1)
+            self.X_trial = self.cam_trial = None
+            self._spare_evaluation = None
+
+    def _bind_blocks(self, V, jred):
+        self.V, self.jred = V, jred
+        self.B = jred[:21 * self.K].view(self.K, 21)
+        self.bphi = jred[21 * self.K:27 * self.K].view(self.K, 6)
+        self.hphi = jred[27 * self.K:]
+
+    def swap_evaluation(self):
+        """Exchanges the buffers the passes write (gradient, energy sum, J^T J blocks) with a second set.
+        A trial point is evaluated into the other set: rejected, the first set still holds the evaluation
+        of the point gone back to, and nothing is evaluated or copied again."""
+        self._lm_buffers()
+        mine = (self.gX, self.red, self.V, self.jred)
+        other = self._spare_evaluation or tuple(torch.zeros_like(t) for t in mine)
+        self._spare_evaluation = mine
+        self._bind_gradient(other[0], other[1])
+        self._bind_blocks(other[2], other[3])
+
+    def rebuild_table(self):
+        """Camera table of the current parameters without a pass (after going back to a kept point)."""
+        cam = self.cam
+        c = cam.data_ptr()
+        K24 = 24 * self.K
+        check(self.lib.ba_build_camera_table(self.handle, c, c + K24, c + 2 * K24, self.stream))
+        self._table_cam = cam
 
     def eval_jtj(self, timed=False, point_major=False, dense_blocks=False):
         """Fused pass that also leaves the Gauss-Newton blocks V (this shard's points) and
@@ -555,9 +585,11 @@ class Shard:
             self._sum_over_ranks(self.red)
             self._sum_over_ranks(self.jred)
 
-    def lm_step(self, lam, on_system=None):
+    def lm_step(self, lam, on_system=None, trial=False):
         """Solve the damped normal equations (J^T J + lam diag) d = -J^T r by Schur complement and
         dense Cholesky; leaves dX and dcam = [dC | dTheta | dphi].  Returns the pivot info (0 = ok).
+        trial: the back-substitution also leaves the trial point in new tensors X_trial = X + dX and
+        cam_trial = cam + dcam (the current parameters are not touched).
         With several GPUs every rank adds its points' part of S and rhs, the sums go over the
         ranks, and every rank factorises the (identical) reduced system itself.
         on_system(S, rhs), if given, sees the reduced system before it is factorised in place."""
@@ -579,8 +611,12 @@ class Shard:
         if status == -4:
             return int(info.value)
         check(status)
+        cam = self.cam
+        self.X_trial = torch.empty_like(X) if trial else None
+        self.cam_trial = torch.empty_like(cam) if trial else None
         check(self.lib.ba_backsubstitute(self.handle, X.data_ptr(), float(lam), ptr(self.V), ptr(self.Xphi),
-                                         ptr(self.gX), ptr(self.rhs), ptr(self.dcam), ptr(self.dX), self.stream))
+                                         ptr(self.gX), ptr(self.rhs), ptr(self.dcam), ptr(self.dX), cam.data_ptr(),
+                                         ptr(self.X_trial), ptr(self.cam_trial), self.stream))
         return 0
 
 

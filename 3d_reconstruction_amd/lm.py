@@ -9,6 +9,11 @@ reached through the same entry point, `fit_scene(..., optimizer='LM')`, and retu
     trial = gauge_fix(params + d); evaluate E and J^T J there
     E decreased: accept, lambda /= 3      otherwise: restore, lambda *= 4 and try again
 
+The trial point is written by the back-substitution into tensors of its own and evaluated into a second
+set of gradient / block buffers, so an accepted step copies nothing and a rejected one neither copies nor
+evaluates again: it goes back to the tensors and the evaluation it still has and rebuilds the camera
+table (one small launch).
+
 The gauge freedom (7 degrees) is handled the same way the reference's loop does it: the trial point
 is mapped back to the gauge "camera 0 at the origin, longest baseline 1" (the energy is invariant),
 and the damping keeps the normal equations positive definite.
@@ -41,7 +46,6 @@ class LMFit:
         sh.eval_jtj()
         E = sh.energy()
         self.E[0] = E
-        X_save, cam_save = sh.X.clone(), sh.cam.clone()
         it = 0
         while it < self.max_iters - 1:
             if it % self.print_step == 0:
@@ -52,14 +56,13 @@ class LMFit:
             if self.lam > self.lam_max:
                 self.print(f'{it} : Reached maximum damping')
                 break
-            if sh.lm_step(self.lam) != 0:          # not positive definite at this damping
+            if sh.lm_step(self.lam, trial=True) != 0:          # not positive definite at this damping
                 self.lam *= self.lam_up
                 continue
-            X_save.copy_(sh.X)
-            cam_save.copy_(sh.cam)
-            sh.X.add_(sh.dX)
-            sh.cam.add_(sh.dcam)
-            sh.gauge_fix()
+            kept = sh.snapshot()
+            sh.adopt(sh.X_trial, sh.cam_trial)
+            sh.gauge_fix()                  # in place on the trial tensors
+            sh.swap_evaluation()
             sh.eval_jtj()
             E_new = sh.energy()
             it += 1
@@ -74,10 +77,9 @@ class LMFit:
                     break
             else:
                 self.rejected += 1
-                sh.X.copy_(X_save)
-                sh.cam.copy_(cam_save)
-                sh.invalidate_table()
-                sh.eval_jtj()
+                sh.restore(kept)
+                sh.swap_evaluation()
+                sh.rebuild_table()
                 self.E[it] = E
                 self.lam *= self.lam_up
         else:

@@ -268,7 +268,13 @@ int ba_resect(int64_t N, int64_t K, const int64_t *col_ptr, const int32_t *oi_by
  * ba_cholesky_solve: blocked Cholesky of S in place (trailing update on the fp64 matrix cores) and
  *   solution of S d = rhs in place; *h_info = 0 or 1 + index of the first non-positive pivot.
  * ba_backsubstitute: dX[N][3] = V'^-1 (-g_X - W d_cam - Xphi d_phi); dcam_packed (optional, 6K+1)
- *   receives d reordered to [dC (3K) | dTheta (3K) | dphi]. */
+ *   receives d reordered to [dC (3K) | dTheta (3K) | dphi].  The trial point of the damped step comes out of
+ *   the same two launches when asked for: X_trial[N][3] (optional) = X + dX, cam_trial (optional, 6K+1) =
+ *   cam + dcam with cam = the current packed [C | Theta | phi_x]; both are buffers of their own, so the
+ *   current parameters stay what a rejected step goes back to.
+ * ba_build_camera_table: rebuilds the handle's camera table (and the pinhole scalars) from the given
+ *   parameters without a pass: after a rejected trial the table holds the trial's cameras, while the
+ *   gradient and the blocks of the accepted point are still in the caller's buffers. */
 int ba_eval_jtj(ba_problem *p, const double *X, const double *C, const double *Theta, const double *phi,
                 int flags, double *E_sum, double *gX, double *gC, double *gTheta, double *gphi,
                 double *V, double *B, double *bphi, double *hphi, void *stream);
@@ -279,7 +285,9 @@ int ba_schur_build(ba_problem *p, const double *X, double lambda, const double *
                    double *S, double *rhs, void *stream);
 int ba_cholesky_solve(int64_t n, int64_t ld, double *S, double *rhs, int *h_info, void *stream);
 int ba_backsubstitute(ba_problem *p, const double *X, double lambda, const double *V, const double *Xphi,
-                      const double *gX, const double *d, double *dcam_packed, double *dX, void *stream);
+                      const double *gX, const double *d, double *dcam_packed, double *dX, const double *cam,
+                      double *X_trial, double *cam_trial, void *stream);
+int ba_build_camera_table(ba_problem *p, const double *C, const double *Theta, const double *phi, void *stream);
 
 /* ---- transform (p2w:192-216) on a list of pairs: model pixels out[n][2], NaN behind the camera
  * (delete_back_points) and optionally outside [0,W)x[0,H) (delete_boundary_points).

@@ -1,19 +1,20 @@
 """Fused fit loop at the three large configurations (points, cameras): iteration time and observations per second."""
 import importlib, sys, time, numpy as np, torch
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '.'))
 ba = importlib.import_module('3d_reconstruction_amd')
-for name, N, K in (('cfg3', 1_000_000, 2000), ('cfg5', 1_000_000, 20000), ('cfg4', 10_000_000, 2000)):
+for name, N, K in (('cfg3', 1_000_000, 2000), ('cfg4/8', 1_250_000, 2000), ('cfg5', 1_000_000, 20000), ('cfg4', 10_000_000, 2000)):
     sc = ba.scenes.orbit_scene(N=N, K=K, track_len=10, seed=0)
     nv = sc['i'].size
     sh = ba.engine.Shard(sc['i'], sc['j'], sc['uv'], sc['N_local'], sc['K'], sc['W'], sc['H'], 'cuda:0')
     sh.set_params(sc['X_0'], sc['C_0'], sc['Theta_0'], sc['phi_x_0'])
-    fit = ba.SceneFit(sh, lr=1e-3, max_iters=400, patience=100000, print_step=10 ** 9, printer=lambda *a: None)
-    for _ in range(30):
+    fit = ba.SceneFit(sh, lr=1e-3, max_iters=800, patience=100000, print_step=10 ** 9, printer=lambda *a: None)
+    for _ in range(300):
         fit.step()
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(100):
+    for _ in range(200):
         fit.step()
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 100
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 200
     print(f'{name}: N={N} K={K} |V|={nv} fused={fit.fuse} iteration {dt * 1e6:.1f} us = {nv / dt:.3e} obs/s, '
           f'E {fit.E[0]:.3f} -> {fit.E[fit.iters - 1]:.4f}', flush=True)
     sh.close(); del sh, fit, sc

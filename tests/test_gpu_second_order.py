@@ -121,6 +121,37 @@ def test_lm_step_matches_dense_solve(ba):
     sh.close()
 
 
+def test_rejected_trial_goes_back_without_a_new_pass(ba):
+    """The trial point comes out of the back-substitution (X + dX, cam + dcam exactly) into tensors of its own
+    and is evaluated into the second set of buffers; going back (restore, swap_evaluation, rebuild_table) leaves
+    the engine where a fresh evaluation of the kept point would: the next damped step is the same."""
+    sc, sh, r, J = _scene(ba, N=250, K=60, seed=9)
+    sh.eval_jtj()
+    E0 = sh.energy()
+    X0, cam0 = sh.X.clone(), sh.cam.clone()
+    assert sh.lm_step(1e-2, trial=True) == 0
+    assert torch.equal(sh.X_trial, X0 + sh.dX) and torch.equal(sh.cam_trial, cam0 + sh.dcam)
+    assert torch.equal(sh.X, X0) and torch.equal(sh.cam, cam0)
+    kept = sh.snapshot()
+    sh.adopt(sh.X_trial, sh.cam_trial)
+    sh.gauge_fix()
+    sh.swap_evaluation()
+    sh.eval_jtj()
+    assert sh.energy() != E0
+    sh.restore(kept)
+    sh.swap_evaluation()
+    sh.rebuild_table()
+    assert sh.energy() == E0 and torch.equal(sh.X, X0) and torch.equal(sh.cam, cam0)
+    assert sh.lm_step(4e-2) == 0
+    d_back, dX_back = sh.dcam.clone(), sh.dX.clone()
+    sh.invalidate_table()
+    sh.eval_jtj()
+    assert sh.lm_step(4e-2) == 0
+    assert rel_err(d_back.cpu().numpy(), sh.dcam.cpu().numpy()) < 1e-9
+    assert rel_err(dX_back.cpu().numpy(), sh.dX.cpu().numpy()) < 1e-9
+    sh.close()
+
+
 def test_schur_tile_kernel_matches_point_kernel_and_dense(ba):
     """Few cameras per tile: the Schur complement is summed per tile in LDS.  Same S and rhs as the
     one-wave-per-point kernel, same step as the dense normal equations."""
