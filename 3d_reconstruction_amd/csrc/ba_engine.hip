@@ -1567,10 +1567,9 @@ __global__ void __launch_bounds__(256) k_camera_step_mb(CameraStep a, CameraStep
 // Camera 0's own results are staged and written by the workgroup that draws the last ticket,
 // together with the scale factor (see k_camera_step_mb for the protocol), because every
 // workgroup reads camera 0's OLD values.
-// FINALIZE: the kernel also finishes the observation pass (sum of the per-tile partials -> energy,
-// d E / d phi_x; camera-frame sums -> d E / d C, d E / d Theta; energy mailbox) instead of a
-// separate k_finalize launch, and leaves the camera-frame sums at zero.
+// (The step that also finishes a deferred observation pass is k_camera_step_free below.)
 // --------------------------------------------------------------------------------------------
+// what a camera step that finishes the observation pass needs besides CameraStep
 struct FinalizeArgs {
     double *partials = nullptr;         // 2 per tile
     int n_partials = 0;                 // entries to add up
@@ -1592,12 +1591,10 @@ __device__ __forceinline__ double quad_bcast(double v) {
 
 constexpr int STAGE_DOUBLES = 32;   // camera 0: Theta (3), s (6), r (6), table row R (9) + cos/sin theta_z (2)
 
-template <bool FINALIZE>
-__global__ void __launch_bounds__(256) k_camera_step_quad(CameraStep a, CameraStepShared sh, FinalizeArgs fz) {
+__global__ void __launch_bounds__(256) k_camera_step_quad(CameraStep a, CameraStepShared sh) {
     __shared__ double sR0[9], sC0[3];
     __shared__ double red_v[4];
     __shared__ long long red_j[4];
-    __shared__ double red_e[2][4];
     __shared__ int s_last;
     __shared__ double s_factor;
     const int64_t K = a.K;
@@ -1611,21 +1608,7 @@ __global__ void __launch_bounds__(256) k_camera_step_quad(CameraStep a, CameraSt
     const int64_t jj = j < K ? j : 0;
     const int cc = comp < 3 ? comp : 0;
 
-    // ---- everything this lane reads, requested before workgroup 0 adds up the partial sums (one trip to memory
-    // on its path instead of two: the last ticket is drawn when the slowest workgroup arrives)
-    double in_sums[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, in_row[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    if (FINALIZE) {
-        const double *row = a.T + jj * CAM_ROW;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) in_sums[k] = fz.cam_sums[k * K + jj];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            in_row[k] = row[3 * cc + k];
-            in_row[3 + k] = row[3 + k];
-        }
-        in_row[6] = row[12];
-        in_row[7] = row[13];
-    }
+    // ---- everything this lane reads, requested up front
     double in_x[2], in_s[2] = {0.0, 0.0}, in_r[2] = {0.0, 0.0}, in_g[2] = {0.0, 0.0};
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -1635,49 +1618,11 @@ __global__ void __launch_bounds__(256) k_camera_step_quad(CameraStep a, CameraSt
             in_s[h] = a.s_in[t];
             in_r[h] = a.r_in[t];
         }
-        if (!FINALIZE && a.g) in_g[h] = a.g[t];
+        if (a.g) in_g[h] = a.g[t];
     }
 
-    const double dphi_old = (FINALIZE && blockIdx.x == 0) ? a.scalars[SC_DPHI] : 0.0;
-    if (FINALIZE && blockIdx.x == 0) {
-        double e = 0.0, ps = 0.0;
-        const double2 *pp = (const double2 *)fz.partials;
-        // 12 loads per thread in flight (a load per loop trip would cost a trip to memory each)
-        for (int t0 = 0; t0 < fz.n_partials; t0 += 12 * 256) {
-            double2 v[12];
-#pragma unroll
-            for (int u = 0; u < 12; ++u) {
-                const int t = t0 + u * 256 + tid;
-                v[u] = t < fz.n_partials ? pp[t] : make_double2(0.0, 0.0);
-            }
-#pragma unroll
-            for (int u = 0; u < 12; ++u) {
-                const int t = t0 + u * 256 + tid;
-                e += v[u].x;
-                ps += v[u].y;
-                if (t >= fz.n_own && t < fz.n_partials) ((double2 *)fz.partials)[t] = make_double2(0.0, 0.0);
-            }
-        }
-        e = wave_sum(e);
-        ps = wave_sum(ps);
-        if ((tid & 63) == 0) {
-            red_e[0][tid >> 6] = e;
-            red_e[1][tid >> 6] = ps;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            const double e_sum = (red_e[0][0] + red_e[0][1]) + (red_e[0][2] + red_e[0][3]);
-            fz.g_out[6 * K + 1] = e_sum;
-            fz.g_out[6 * K] = dphi_old * ((red_e[1][0] + red_e[1][1]) + (red_e[1][2] + red_e[1][3]));
-            if (fz.mailbox) {
-                fz.mailbox[0] = e_sum;
-                __threadfence_system();
-                fz.mailbox[1] = fz.seq;
-            }
-        }
-    }
     // phi_x and the scalars that depend on it: one thread of workgroup 0, off the tail of the kernel (nothing
-    // else in this launch reads them; the old d f / d phi factor was read above)
+    // else in this launch reads them)
     if (blockIdx.x == 0 && tid == 64) {
         const int64_t t = 6 * K;
         double ph = a.cam_in[t];
@@ -1687,8 +1632,7 @@ __global__ void __launch_bounds__(256) k_camera_step_quad(CameraStep a, CameraSt
                 sv = a.s_in[t];
                 rv = a.r_in[t];
             }
-            const double gphi = FINALIZE ? dphi_old * ((red_e[1][0] + red_e[1][1]) + (red_e[1][2] + red_e[1][3])) : a.g[t];
-            ph = apply_rule(a.rule, ph, gphi, &sv, &rv);
+            ph = apply_rule(a.rule, ph, a.g[t], &sv, &rv);
             if (a.rule.mode == 2) {
                 a.s[t] = sv;
                 a.r[t] = rv;
@@ -1705,23 +1649,7 @@ __global__ void __launch_bounds__(256) k_camera_step_quad(CameraStep a, CameraSt
     }
 
     // ---- un-normalised gradient of C[comp], Theta[comp] of this quad's camera
-    double gc, gt;
-    if (FINALIZE) {
-        const double s0 = in_sums[0], s1 = in_sums[1], s2 = in_sums[2], w0 = in_sums[3], w1 = in_sums[4], w2 = in_sums[5];
-        gc = -(in_row[0] * s0 + in_row[1] * s1 + in_row[2] * s2);
-        gt = cc == 0 ? -(in_row[6] * w0 - in_row[7] * w1) : (cc == 1 ? -(in_row[3] * w0 + in_row[4] * w1 + in_row[5] * w2) : -w2);
-        if (own || stage0) {
-            fz.g_out[3 * jj + cc] = gc;
-            fz.g_out[3 * K + 3 * jj + cc] = gt;
-        }
-        if (own) {      // the sums are consumed: leave them at zero for the next pass (camera 0: in the tail)
-            fz.cam_sums[cc * K + jj] = 0.0;
-            fz.cam_sums[(3 + cc) * K + jj] = 0.0;
-        }
-    } else {
-        gc = in_g[0];
-        gt = in_g[1];
-    }
+    const double gc = in_g[0], gt = in_g[1];
 
     // ---- update rule (p2w:704-708) on the two parameters of this lane
     double pnew[2], snew[2] = {0.0, 0.0}, rnew[2] = {0.0, 0.0};
@@ -1945,7 +1873,6 @@ __global__ void __launch_bounds__(256) k_camera_step_quad(CameraStep a, CameraSt
             }
         }
     }
-    if (FINALIZE && tid >= 96 && tid < 102) fz.cam_sums[(tid - 96) * K] = 0.0;     // camera 0 (read by every workgroup)
     __syncthreads();
     // scale of the centres: 24 loads per thread in flight at once (the caches were just invalidated, so a batch
     // costs a round trip to memory; K = 2000 is one batch, the one requested above)
@@ -3057,13 +2984,13 @@ int ba_points_step(int64_t N, const double *X_in, double *X_out, const double *g
     return BA_OK;
 }
 
-static int camera_step_impl(ba_problem *p, const double *cam_in, double *cam_out, const double *g, double *g_out,
-                            int finalize, int post, const double *s_in, double *s_out, const double *r_in,
-                            double *r_out, int64_t lo, int64_t hi, int rule, double lr, double gscale, double bc1,
-                            double bc2, int gauge, double *R_out, double *gauge_out, void *stream) {
+static int camera_step_impl(ba_problem *p, const double *cam_in, double *cam_out, const double *g, const double *s_in,
+                            double *s_out, const double *r_in, double *r_out, int64_t lo, int64_t hi, int rule,
+                            double lr, double gscale, double bc1, double bc2, int gauge, double *R_out,
+                            double *gauge_out, void *stream) {
     BA_REQUIRE(p && cam_in && cam_out, "ba_camera_step: null pointer");
     BA_REQUIRE(rule >= 0 && rule <= 2 && lo >= 0 && hi <= 6 * p->K + 1, "ba_camera_step: bad rule or range");
-    BA_REQUIRE(rule == 0 || lo >= hi || ((g || finalize) && (rule != 2 || (s_in && s_out && r_in && r_out))),
+    BA_REQUIRE(rule == 0 || lo >= hi || (g && (rule != 2 || (s_in && s_out && r_in && r_out))),
                "ba_camera_step: null pointer");
     BA_REQUIRE(!gauge || (p->K >= 2 && gauge_out), "ba_camera_step: the gauge fix needs two cameras and gauge_out");
     BA_REQUIRE(same_or_disjoint(cam_in, cam_out, 6 * p->K + 1),
@@ -3084,10 +3011,7 @@ static int camera_step_impl(ba_problem *p, const double *cam_in, double *cam_out
     a.W = p->W;
     a.H = p->H;
     a.T = p->cam_table;
-    // merged form: its consumer is the next run pass, which takes the centres from the parameter vector; writing
-    // them into the 128-byte rows as well (one cache line per camera, from one workgroup) was a quarter of the kernel
-    a.table_centres = (gauge && finalize) ? 0 : 1;
-    if (!a.table_centres) p->table_centres_stale = 1;
+    a.table_centres = 1;
     a.scale_later = (gauge && p->K > 2048) ? 1 : 0;     // beyond one batch of the kernel's last workgroup
     a.scalars = p->scalars;
     a.R_out = R_out;
@@ -3097,24 +3021,7 @@ static int camera_step_impl(ba_problem *p, const double *cam_in, double *cam_out
     sh.block_best = p->step_best;
     sh.stage = p->step_stage;
     if (gauge) {
-        FinalizeArgs fz;
-        if (finalize) {
-            fz.partials = p->partials;
-            fz.n_own = p->pending_partials;
-            fz.n_partials = p->ext_partials_cap > 0 ? (int)p->ext_partials_cap : p->pending_partials;
-            fz.cam_sums = p->cam_sums;
-            fz.g_out = g_out;
-            if (post) {
-                fz.mailbox = p->mailbox_dev;
-                fz.seq = (double)++p->post_seq;
-            }
-            p->pending_partials = 0;
-            hipLaunchKernelGGL(k_camera_step_quad<true>, dim3(cdiv(p->K - 1, 63)), dim3(256), 0, (hipStream_t)stream, a,
-                               sh, fz);
-        } else {
-            hipLaunchKernelGGL(k_camera_step_quad<false>, dim3(cdiv(p->K - 1, 63)), dim3(256), 0, (hipStream_t)stream,
-                               a, sh, fz);
-        }
+        hipLaunchKernelGGL(k_camera_step_quad, dim3(cdiv(p->K - 1, 63)), dim3(256), 0, (hipStream_t)stream, a, sh);
         if (a.scale_later)
             hipLaunchKernelGGL(k_scale_centres, dim3(cdiv(3 * p->K - 3, 256)), dim3(256), 0, (hipStream_t)stream, p->K,
                                a.cam, a.table_centres ? a.T : nullptr, a.gauge);
@@ -3132,8 +3039,8 @@ extern "C" {
 int ba_camera_step(ba_problem *p, const double *cam_in, double *cam_out, const double *g, const double *s_in,
                    double *s_out, const double *r_in, double *r_out, int64_t lo, int64_t hi, int rule, double lr,
                    double gscale, double bc1, double bc2, int gauge, double *R_out, double *gauge_out, void *stream) {
-    return camera_step_impl(p, cam_in, cam_out, g, nullptr, 0, 0, s_in, s_out, r_in, r_out, lo, hi, rule, lr, gscale,
-                            bc1, bc2, gauge, R_out, gauge_out, stream);
+    return camera_step_impl(p, cam_in, cam_out, g, s_in, s_out, r_in, r_out, lo, hi, rule, lr, gscale, bc1, bc2, gauge,
+                            R_out, gauge_out, stream);
 }
 
 int ba_camera_step_finalize(ba_problem *p, const double *cam_in, const double *cam_in_gauge, double *cam_out,
