@@ -3,9 +3,11 @@
 //
 // Storage: lower triangle, row-major, leading dimension ld (a multiple of 64); rows/columns past n
 // are the identity.  Three-level right-looking factorisation:
-//   panel  (256 columns): per 64-column block  potrf64 -> trsm -> update of the panel's remaining
-//          columns (v_mfma_f64_16x16x4_f64, operands from global memory).  O(n 256^2) flops per
-//          panel, latency-bound, small next to the updates below.
+//   panel  (256 columns): its diagonal block per 64-column block (potrf64, then two small launches for the
+//          blocks below and behind inside the diagonal block), then ONE launch for all rows below the
+//          diagonal block (k_panel_rows: every wave keeps a strip of 16 rows in registers across the
+//          whole blocked triangular solve).  O(n 256^2) flops per panel, latency-bound, small next to the
+//          updates below.
 //   outer panel (1024 columns = 4 panels): after each panel only the remaining columns of the outer
 //          panel are updated with it; everything behind the outer panel is updated once, with all
 //          1024 columns as the inner dimension.  What this buys is traffic: an update reads and
@@ -18,8 +20,6 @@
 // The inverse of every diagonal block is kept (trsm is a product with it, and so are the two
 // triangular solves of the right-hand side).
 //
-// Matrix-core tile v_mfma_f64_16x16x4_f64: lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15];
-// it holds D[(l >> 4) + 4 r][l & 15] in register r = 0..3.
 #include "ba_device.h"
 
 #include <stdlib.h>
@@ -33,7 +33,6 @@ constexpr int OB = 1024;  // outer panel = inner dimension of the update of ever
 constexpr int TS = 128;   // tile of the trailing update
 constexpr int KC = 16;    // columns of the panel staged in LDS at a time
 constexpr int LDT = TS + 4;    // row pitch of the staged (column-major) panel chunks in LDS
-typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 static int cdiv_c(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
@@ -133,81 +132,234 @@ __global__ void __launch_bounds__(256) k_potrf64(double *__restrict__ A, int64_t
     }
 }
 
-// D (64x64) += P (64 x 64 slice, row-major, leading dimension ldp) times Q^T, one wave
-__device__ __forceinline__ void mfma_tile_64(const double *__restrict__ P, int64_t ldp, const double *__restrict__ Q,
-                                             int64_t ldq, v4f64 acc[4][4]) {
-    const int lane = threadIdx.x & 63;
-    const int r16 = lane & 15, k4 = lane >> 4;
-    // sixteen columns of both operands are requested together (32 loads in flight), then multiplied: a load per
-    // matrix-core step makes the 64 columns sixteen dependent trips to memory, and these small kernels sit on the
-    // critical path of the panel factorisation
-    for (int kk = 0; kk < NB; kk += 16) {
-        double af[4][4], bf[4][4];
+// ---------------------------------------------------------------------------------------------------------
+// Panel factorisation.
+//
+// Everything in a panel acts on rows independently except the factorisation of its diagonal block: with
+// L_d = chol(A_dd) (pw x pw, pw <= 256) the rows below become A_below L_d^-T.  The diagonal block is factorised
+// per 64 columns (k_potrf64, then k_diag_trsm / k_diag_syrk for what lies below and behind inside the diagonal block);
+// k_panel_rows then gives every wave a strip of 16 rows below, held in registers across the whole blocked
+// solve (no barrier between waves is needed for the data, only for the operand blocks staged in LDS).
+// A launch per 64 columns for the rows below (a product with the inverse, then the update of the panel's
+// remaining columns, one wave per 64 x 64 block on v_mfma_f64_16x16x4_f64) took 167 us per panel at n = 12 001,
+// bound by the matrix-core time of the one wave that owns a block; the rows kernel takes 50 us.
+//
+// Strip products run on v_mfma_f64_4x4x4_4b_f64 (lane layout in the header of k_syrk_trailing).  For a strip
+// S (16 rows) and a 64 x 64 block M the instruction sequence computes (M S^T), whose result registers hold
+// exactly the layout the next product wants as its operand: lane l keeps, of row (l & 15) of the strip, the
+// columns 4 e + (l >> 4), e = 0..15 - as loaded from memory, as operand, and as result.  Nothing is ever
+// transposed or exchanged between lanes.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int LP = NB + 4;  // row pitch of an operand block in LDS: the 4 rows x 4 columns an operand read touches
+                            // fall on 16 different bank pairs
+
+// acc (+)= S M^T for the strip operand b (b[e]: S[row lane & 15][column 4 e + (lane >> 4)]) and M in LDS at pitch LP
+__device__ __forceinline__ void strip_mma(const double *__restrict__ M, const double (&b)[16], double (&acc)[16], int lane) {
+    const double *m = M + (lane & 3) * LP + (lane >> 4);
+    // The operands of column group ks + 1 are read while the matrix cores work on group ks (sixteen instructions
+    // = 256 cycles for the reads to return): left to the compiler the reads sit a few instructions ahead of their
+    // use, and with one wave per SIMD nothing else hides their latency.
+    double a0[16], a1[16];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+    for (int I = 0; I < 16; ++I) a0[I] = m[4 * I * LP];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) af[c][m] = P[(int64_t)(16 * m + r16) * ldp + kk + 4 * c + k4];
+    for (int ks = 0; ks < 16; ks += 2) {
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int n = 0; n < 4; ++n) bf[c][n] = Q[(int64_t)(16 * n + r16) * ldq + kk + 4 * c + k4];  // B[k][j] = Q[j][k]
+        for (int I = 0; I < 16; ++I) a1[I] = m[4 * I * LP + 4 * (ks + 1)];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int I = 0; I < 16; ++I) acc[I] = __builtin_amdgcn_mfma_f64_4x4x4f64(a0[I], b[ks], acc[I], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks + 2 < 16) {
+#pragma unroll
+            for (int I = 0; I < 16; ++I) a0[I] = m[4 * I * LP + 4 * (ks + 2)];
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int n = 0; n < 4; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[c][m], bf[c][n], acc[m][n], 0, 0, 0);
+        for (int I = 0; I < 16; ++I) acc[I] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[I], b[ks + 1], acc[I], 0, 0, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);
 }
 
-__device__ __forceinline__ void zero_acc(v4f64 acc[4][4]) {
+__device__ __forceinline__ void strip_load(const double *__restrict__ src, int64_t pitch, double (&v)[16], int lane) {
+    const double *p = src + (int64_t)(lane & 15) * pitch + (lane >> 4);
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int n = 0; n < 4; ++n) acc[m][n] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    for (int e = 0; e < 16; ++e) v[e] = p[4 * e];
 }
 
-// A_ik <- A_ik L_kk^-T  (= A_ik times (L^-1)^T): one wave per 64-row block below the diagonal block
-__global__ void __launch_bounds__(64) k_trsm(double *__restrict__ A, int64_t ld, int64_t k0,
-                                             const double *__restrict__ Linv) {
-    const int64_t i0 = k0 + NB + (int64_t)blockIdx.x * NB;
-    v4f64 acc[4][4];
-    zero_acc(acc);
-    double *P = A + i0 * ld + k0;
-    mfma_tile_64(P, ld, Linv, NB, acc);
-    const int lane = threadIdx.x & 63, col = lane & 15, rq = lane >> 4;
-    // every accumulator depends on all of P, so P has been read completely before the first store
+__device__ __forceinline__ void strip_store(double *__restrict__ dst, int64_t pitch, const double (&v)[16], int lane) {
+    double *p = dst + (int64_t)(lane & 15) * pitch + (lane >> 4);
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int nn = 0; nn < 4; ++nn)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) P[(int64_t)(16 * m + rq + 4 * r) * ld + 16 * nn + col] = acc[m][nn][r];
+    for (int e = 0; e < 16; ++e) p[4 * e] = v[e];
 }
 
-// Inside a panel: A_ij -= A_ik A_jk^T for row blocks i behind block column k (all the way down) and
-// the column blocks j of the panel behind k; one wave per 64x64 block, blocks above the diagonal skipped.
-__global__ void __launch_bounds__(256) k_syrk_panel(double *__restrict__ A, int64_t ld, int64_t k0, int col_blocks,
-                                                    int64_t n_tiles) {
-    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= n_tiles) return;
-    const int64_t bi = t / col_blocks, bj = t - bi * col_blocks;
-    if (bj > bi) return;
-    const int64_t i0 = k0 + NB * (1 + bi), j0 = k0 + NB * (1 + bj);
-    v4f64 acc[4][4];
-    zero_acc(acc);
-    mfma_tile_64(A + i0 * ld + k0, ld, A + j0 * ld + k0, ld, acc);
-    const int lane = threadIdx.x & 63, col = lane & 15, rq = lane >> 4;
-    double *Cc = A + i0 * ld + j0;
+// The same through a 16 x 64 patch of LDS owned by the wave (pitch TP): in memory a wave instruction then covers 512
+// consecutive bytes of one row instead of 32 bytes of each of 16 rows a whole matrix row apart (rows kernel with
+// this and the row-wise staging of the operand blocks: 62 -> 47 us).  Only the wave itself touches its patch: no
+// barrier.
+constexpr int TP = NB + 2;  // 2 mod 32: the operand-layout reads of rows 0..15 x columns q, q + 1 hit 32 different bank pairs
+__device__ __forceinline__ void strip_request(const double *__restrict__ src, int64_t pitch, double (&t)[16], int lane) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int r = 0; r < 16; ++r) t[r] = src[(int64_t)r * pitch + lane];
+}
+
+// barrier of the workgroup that orders LDS accesses only: __syncthreads() also waits until every global store of
+// the wave has completed (a round trip to memory per step of the rows kernel)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ void strip_from_rows(const double (&t)[16], double *__restrict__ patch, double (&v)[16], int lane) {
 #pragma unroll
-        for (int nn = 0; nn < 4; ++nn)
+    for (int r = 0; r < 16; ++r) patch[r * TP + lane] = t[r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const double *p = patch + (lane & 15) * TP + (lane >> 4);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double *dst = Cc + (int64_t)(16 * m + rq + 4 * r) * ld + 16 * nn + col;
-                *dst -= acc[m][nn][r];
+    for (int e = 0; e < 16; ++e) v[e] = p[4 * e];
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ void strip_store_lds(double *__restrict__ dst, int64_t pitch, double *__restrict__ patch,
+                                                const double (&v)[16], int lane) {
+    double *p = patch + (lane & 15) * TP + (lane >> 4);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) p[4 * e] = v[e];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double t[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = patch[r * TP + lane];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dst[(int64_t)r * pitch + lane] = t[r];
+    __builtin_amdgcn_wave_barrier();
+}
+
+// 64 x 64 block, 256 threads: thread -> columns 2 (tid % 32), +1 of rows tid / 32 + 8 u (a wave instruction reads two
+// whole 512-byte rows)
+__device__ __forceinline__ void block_fetch(const double *__restrict__ g, int64_t pitch, double2 (&st)[8], int tid) {
+    const double *p = g + (int64_t)(tid >> 5) * pitch + 2 * (tid & 31);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) st[u] = *(const double2 *)(p + 8 * u * pitch);
+}
+
+__device__ __forceinline__ void block_put(double *__restrict__ d, const double2 (&st)[8], int tid) {
+    double *p = d + (tid >> 5) * LP + 2 * (tid & 31);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) *(double2 *)(p + 8 * u * LP) = st[u];
+}
+
+constexpr int DIAG_LDS_DOUBLES = NB * LP + 4 * 16 * TP;     // one operand block + a patch per wave
+
+__device__ __forceinline__ void stage_block(const double *__restrict__ g, int64_t pitch, double *__restrict__ sm, int tid) {
+    double2 st[8];
+    block_fetch(g, pitch, st, tid);
+    block_put(sm, st, tid);
+}
+
+// Inside the diagonal block of a panel (64 nbk columns from p0), after potrf64 of its block kb: the blocks below it
+// times the inverse, A_jk <- A_jk L_kk^-T.  Workgroup = block row kb + 1 + blockIdx.x, wave = 16-row strip.
+__global__ void __launch_bounds__(256) k_diag_trsm(double *__restrict__ A, int64_t ld, int64_t p0, int kb,
+                                                   const double *__restrict__ Li) {
+    extern __shared__ double sm[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t k0 = p0 + NB * kb;
+    double *strip = A + (k0 + NB * (1 + blockIdx.x) + 16 * w) * ld + k0;
+    double *patch = sm + NB * LP + w * 16 * TP;
+    double t[16], b[16], acc[16];
+    strip_request(strip, ld, t, lane);
+    stage_block(Li, NB, sm, tid);
+    strip_from_rows(t, patch, b, lane);
+    lds_barrier();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0;
+    strip_mma(sm, b, acc, lane);
+    strip_store_lds(strip, ld, patch, acc, lane);
+}
+
+// ... then the update of the blocks behind, A_ij -= A_ik A_jk^T for the pairs j <= i of block rows behind kb.
+// Workgroup = pair (ti, tj) counted from block row kb + 1, wave = 16-row strip of block (i, j).
+// (Both steps and potrf64 as phases of one workgroup - one launch per panel for its whole diagonal block - were
+// measured: potrf64 runs at 37 us there instead of 26 us, eight waves walking through its 64 barriers, and the
+// strips of a phase queue up on the one CU: 231 us per panel against 104 us of potrf64 plus 14 us per step here.)
+__global__ void __launch_bounds__(256) k_diag_syrk(double *__restrict__ A, int64_t ld, int64_t p0, int kb) {
+    extern __shared__ double sm[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t k0 = p0 + NB * kb;
+    const int pair = blockIdx.x;
+    const int ti = pair < 1 ? 0 : (pair < 3 ? 1 : 2), tj = pair - ti * (ti + 1) / 2;
+    double *strip = A + (k0 + NB * (1 + ti) + 16 * w) * ld + k0 + NB * (1 + tj);
+    const double *mine = A + (k0 + NB * (1 + ti) + 16 * w) * ld + k0;       // this strip's rows of A_ik
+    double *patch = sm + NB * LP + w * 16 * TP;
+    double t0[16], t1[16], b[16], acc[16];
+    strip_request(mine, ld, t0, lane);
+    strip_request(strip, ld, t1, lane);
+    stage_block(A + (k0 + NB * (1 + tj)) * ld + k0, ld, sm, tid);
+    strip_from_rows(t0, patch, b, lane);
+    strip_from_rows(t1, patch, acc, lane);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) b[e] = -b[e];
+    lds_barrier();
+    strip_mma(sm, b, acc, lane);
+    strip_store_lds(strip, ld, patch, acc, lane);
+}
+
+// Rows below the diagonal block of a panel: A[r, p0 : p0 + 64 NBK) <- the same times L_d^-T, by blocks: for every
+// column block kb, T_kb = S_kb L_kk^-T, then S_jb -= T_kb L_jk^T for the blocks jb behind it.  Workgroup = 64 rows,
+// wave = 16 rows; the operand blocks (inverses from Linv, L_jk from the factorised diagonal block) pass through two
+// LDS buffers, the next one loaded while the matrix cores work on the current one.
+template <int NBK>
+__global__ void __launch_bounds__(256) k_panel_rows(double *__restrict__ A, int64_t ld, int64_t p0,
+                                                    const double *__restrict__ Linv) {
+    extern __shared__ double sm[];
+    constexpr int NOPS = NBK * (NBK + 1) / 2;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    double *rows = A + (p0 + NB * NBK + (int64_t)NB * blockIdx.x + 16 * w) * ld + p0;
+    double *patch = sm + 2 * NB * LP + w * 16 * TP;
+    double S[NBK][16];
+#pragma unroll
+    for (int kb = 0; kb < NBK; kb += 2) {       // two blocks' rows in flight at a time
+        double t0[16], t1[16];
+        strip_request(rows + NB * kb, ld, t0, lane);
+        if (kb + 1 < NBK) strip_request(rows + NB * (kb + 1), ld, t1, lane);
+        strip_from_rows(t0, patch, S[kb], lane);
+        if (kb + 1 < NBK) strip_from_rows(t1, patch, S[kb + 1], lane);
+    }
+    double2 st[8];
+    // jb == kb: the inverse of diagonal block kb, else L_jk of the factorised diagonal block
+#define BA_FETCH(kb_, jb_)                                                                                         \
+    block_fetch((jb_) == (kb_) ? Linv + (int64_t)(kb_) * NB * NB : A + (p0 + NB * (jb_)) * ld + p0 + NB * (kb_),  \
+                (jb_) == (kb_) ? (int64_t)NB : ld, st, tid)
+#define BA_PUT(n_) block_put(sm + ((n_) & 1) * NB * LP, st, tid)
+    BA_FETCH(0, 0);
+    BA_PUT(0);
+    lds_barrier();
+    int n = 0;
+#pragma unroll
+    for (int kb = 0; kb < NBK; ++kb) {
+#pragma unroll
+        for (int jb = kb; jb < NBK; ++jb) {      // jb == kb: the product with the inverse; behind it the updates
+            if (n + 1 < NOPS) BA_FETCH(jb + 1 < NBK ? kb : kb + 1, jb + 1 < NBK ? jb + 1 : kb + 1);
+            const double *M = sm + (n & 1) * NB * LP;
+            if (jb == kb) {
+                double acc[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] = 0.0;
+                strip_mma(M, S[kb], acc, lane);
+                strip_store_lds(rows + NB * kb, ld, patch, acc, lane);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) S[kb][e] = -acc[e];    // from here on the operand of the updates
+            } else {
+                strip_mma(M, S[kb], S[jb], lane);
             }
+            if (n + 1 < NOPS) BA_PUT(n + 1);    // the other buffer: its readers passed the barrier of the step before
+            lds_barrier();
+            ++n;
+        }
+    }
+#undef BA_FETCH
+#undef BA_PUT
 }
 
 // Update behind a panel: C[i0:+128, j0:+128] -= P_i P_j^T with P = A[:, k0 : k0 + kw], for the 128-tiles of
@@ -425,6 +577,19 @@ int ba_cholesky_solve(int64_t n, int64_t ld, double *S, double *rhs, int *h_info
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void *)k_potrf64, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(sizeof(double) * POTRF_LDS_DOUBLES));
+    const size_t lds_diag = sizeof(double) * DIAG_LDS_DOUBLES, lds_rows = sizeof(double) * (2 * NB * LP + 4 * 16 * TP);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void *)k_diag_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void *)k_diag_syrk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_diag);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void *)k_panel_rows<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void *)k_panel_rows<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void *)k_panel_rows<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void *)k_panel_rows<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows);
     if (e == hipSuccess) {
         // tiles of the region C[c0.., c0 .. c_end): lower triangle of the first tile columns, whole rows below
         auto trailing = [&](int64_t k_first, int64_t kw, int64_t c0, int64_t c_end) {
@@ -440,17 +605,25 @@ int ba_cholesky_solve(int64_t n, int64_t ld, double *S, double *rhs, int *h_info
             const int64_t o_end = (ld - o0 < OB) ? ld : o0 + OB;
             for (int64_t p0 = o0; p0 < o_end; p0 += PB) {
                 const int64_t pw = (o_end - p0 < PB) ? o_end - p0 : PB;
-                for (int64_t k0 = p0; k0 < p0 + pw; k0 += NB) {
-                    double *Li = Linv + (k0 / NB) * NB * NB;
-                    hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(256), sizeof(double) * POTRF_LDS_DOUBLES, st, S, ld, k0, Li, info);
-                    const int64_t rows_behind = (ld - k0 - NB) / NB;
-                    if (rows_behind > 0) {
-                        hipLaunchKernelGGL(k_trsm, dim3((int)rows_behind), dim3(64), 0, st, S, ld, k0, Li);
-                        const int col_blocks = (int)((p0 + pw - k0 - NB) / NB);
-                        if (col_blocks > 0) {
-                            const int64_t tiles = rows_behind * col_blocks;
-                            hipLaunchKernelGGL(k_syrk_panel, dim3(cdiv_c(tiles, 4)), dim3(256), 0, st, S, ld, k0, col_blocks, tiles);
+                {
+                    const int nbk = (int)(pw / NB);
+                    double *Li = Linv + (p0 / NB) * NB * NB;
+                    for (int kb = 0; kb < nbk; ++kb) {
+                        hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(256), sizeof(double) * POTRF_LDS_DOUBLES, st, S, ld,
+                                           p0 + NB * kb, Li + (int64_t)kb * NB * NB, info);
+                        const int below = nbk - 1 - kb;
+                        if (below > 0) {
+                            hipLaunchKernelGGL(k_diag_trsm, dim3(below), dim3(256), lds_diag, st, S, ld, p0, kb,
+                                               Li + (int64_t)kb * NB * NB);
+                            hipLaunchKernelGGL(k_diag_syrk, dim3(below * (below + 1) / 2), dim3(256), lds_diag, st, S, ld, p0, kb);
                         }
+                    }
+                    const int slabs = (int)((ld - p0 - pw) / NB);
+                    if (slabs > 0) {
+                        if (nbk == 4) hipLaunchKernelGGL(k_panel_rows<4>, dim3(slabs), dim3(256), lds_rows, st, S, ld, p0, Li);
+                        else if (nbk == 3) hipLaunchKernelGGL(k_panel_rows<3>, dim3(slabs), dim3(256), lds_rows, st, S, ld, p0, Li);
+                        else if (nbk == 2) hipLaunchKernelGGL(k_panel_rows<2>, dim3(slabs), dim3(256), lds_rows, st, S, ld, p0, Li);
+                        else hipLaunchKernelGGL(k_panel_rows<1>, dim3(slabs), dim3(256), lds_rows, st, S, ld, p0, Li);
                     }
                 }
                 // inside the outer panel: only its remaining columns see this 256-wide panel now
