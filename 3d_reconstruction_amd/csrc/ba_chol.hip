@@ -503,6 +503,21 @@ __global__ void __launch_bounds__(256, 2) k_syrk_trailing(double *__restrict__ A
     }
 }
 
+// The forward solve L y = b rides along with the factorisation: with b^T stored as the last (padding) row of the
+// matrix, the row that the factorisation leaves there is y^T (the row's entries solve  row . L^T = b^T), computed by
+// the panel and update kernels like any other row.  Only the row's own pivot is meaningless: nothing depends on
+// it, and a diagonal entry of 1e300 keeps it positive and finite whatever |y|^2 is taken away from it.  That
+// replaces ld / 64 dependent launches of k_solve_step.
+__global__ void k_rhs_into_row(double *__restrict__ A, int64_t ld, int64_t n, const double *__restrict__ rhs) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < ld) A[(ld - 1) * ld + c] = c < n ? rhs[c] : (c == ld - 1 ? 1e300 : 0.0);
+}
+
+__global__ void k_row_to_rhs(const double *__restrict__ A, int64_t ld, int64_t n, double *__restrict__ rhs) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < ld) rhs[c] = c < n ? A[(ld - 1) * ld + c] : 0.0;
+}
+
 // One block step of a triangular solve with the stored inverses of the diagonal blocks.
 // forward  (L y = b):   y_k = Linv_k b_k, then b_i -= L_ik y_k for the rows i behind block k
 // backward (L^T x = y): x_k = Linv_k^T b_k, then b_i -= L_ki^T x_k for the rows i before block k
@@ -590,7 +605,9 @@ int ba_cholesky_solve(int64_t n, int64_t ld, double *S, double *rhs, int *h_info
         e = hipFuncSetAttribute((const void *)k_panel_rows<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void *)k_panel_rows<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows);
+    const bool ride_along = ld > n;     // a padding row is there to carry the right-hand side
     if (e == hipSuccess) {
+        if (ride_along) hipLaunchKernelGGL(k_rhs_into_row, dim3(cdiv_c(ld, 256)), dim3(256), 0, st, S, ld, n, rhs);
         // tiles of the region C[c0.., c0 .. c_end): lower triangle of the first tile columns, whole rows below
         auto trailing = [&](int64_t k_first, int64_t kw, int64_t c0, int64_t c_end) {
             if (c0 >= ld || c_end <= c0) return;
@@ -632,11 +649,15 @@ int ba_cholesky_solve(int64_t n, int64_t ld, double *S, double *rhs, int *h_info
             // behind the outer panel: one update with all its columns as the inner dimension
             trailing(o0, o_end - o0, o_end, ld);
         }
-        // L y = b, then L^T x = y; the result of every block step lands in tmp
-        for (int64_t k = 0; k < nb; ++k)
-            hipLaunchKernelGGL(k_solve_step, dim3(k + 1 < nb ? cdiv_c(ld - (k + 1) * NB, 256) : 1), dim3(256), 0, st, S, ld,
-                               k * NB, Linv + k * NB * NB, rhs, tmp, 0);
-        e = hipMemcpyAsync(rhs, tmp, sizeof(double) * ld, hipMemcpyDeviceToDevice, st);
+        // L y = b (unless it rode along), then L^T x = y; the result of every block step lands in tmp
+        if (ride_along) {
+            hipLaunchKernelGGL(k_row_to_rhs, dim3(cdiv_c(ld, 256)), dim3(256), 0, st, S, ld, n, rhs);
+        } else {
+            for (int64_t k = 0; k < nb; ++k)
+                hipLaunchKernelGGL(k_solve_step, dim3(k + 1 < nb ? cdiv_c(ld - (k + 1) * NB, 256) : 1), dim3(256), 0, st, S,
+                                   ld, k * NB, Linv + k * NB * NB, rhs, tmp, 0);
+            e = hipMemcpyAsync(rhs, tmp, sizeof(double) * ld, hipMemcpyDeviceToDevice, st);
+        }
         for (int64_t k = nb - 1; k >= 0; --k)
             hipLaunchKernelGGL(k_solve_step, dim3(k > 0 ? cdiv_c(k * NB, 256) : 1), dim3(256), 0, st, S, ld, k * NB,
                                Linv + k * NB * NB, rhs, tmp, 1);

@@ -267,6 +267,9 @@ int ba_resect(int64_t N, int64_t K, const int64_t *col_ptr, const int32_t *oi_by
  *   cross-GPU sums).
  * ba_cholesky_solve: blocked Cholesky of S in place (trailing update on the fp64 matrix cores) and
  *   solution of S d = rhs in place; *h_info = 0 or 1 + index of the first non-positive pivot.
+ *   Rows and columns n .. ld-1 of S must be the identity and rhs[n .. ld) zero on entry (ba_schur_build leaves
+ *   them so).  When ld > n the last of these rows is used as work space (it carries the right-hand side through
+ *   the factorisation) and does not hold the identity afterwards.
  * ba_backsubstitute: dX[N][3] = V'^-1 (-g_X - W d_cam - Xphi d_phi); dcam_packed (optional, 6K+1)
  *   receives d reordered to [dC (3K) | dTheta (3K) | dphi].  The trial point of the damped step comes out of
  *   the same two launches when asked for: X_trial[N][3] (optional) = X + dX, cam_trial (optional, 6K+1) =
