@@ -163,8 +163,9 @@ def run_loop(ba, sh, sc, steps, warmup, sync, timed=True):
     fit = ba.SceneFit(sh, lr=1e-3, max_iters=total + 8, patience=1000, print_step=10 ** 9, printer=lambda *a: None)
     # HIP events on about ten launches of the observation-pass kernel spread over the timed region (handed to the
     # dispatch itself, so they hold the kernel's own begin and end; such a launch costs the host about 30 us more than
-    # a plain one, which is why not every launch carries them), at least three samples in short runs
-    fit.timed_every = max(1, steps // 10 if steps >= 90 else -(-steps // 3)) if timed else 0
+    # a plain one, which is why not every launch carries them), two samples in short runs (each is 2.5 % of a
+    # 20-iteration run)
+    fit.timed_every = max(1, steps // 10 if steps >= 90 else -(-steps // 2)) if timed else 0
     for _ in range(warmup):
         if not fit.step():
             raise RuntimeError('the fit stopped during the warm-up')
@@ -214,6 +215,12 @@ def exchange_trial(args, rank, world, local_rank):
     port = int(os.environ.get('MASTER_PORT', '29500')) + 23
     env = dict(os.environ, MASTER_PORT=str(port), BA_NODE_EXCHANGE='1', RANK=str(rank), LOCAL_RANK=str(local_rank),
                WORLD_SIZE=str(world))
+    # under torch.distributed.run the ranks carry the launcher's rendezvous settings (TORCHELASTIC_USE_AGENT_STORE
+    # makes every rank a CLIENT of the launcher's store): the children form a group of their own on their own port
+    for name in list(env):
+        if name.startswith('TORCHELASTIC_') or name in ('GROUP_RANK', 'ROLE_RANK', 'ROLE_NAME', 'ROLE_WORLD_SIZE',
+                                                        'GROUP_WORLD_SIZE', 'LOCAL_WORLD_SIZE'):
+            del env[name]
     cmd = [sys.executable, os.path.abspath(__file__), '--gpus', str(world), '--steps', str(args.steps), '--warmup',
            str(args.warmup), '--cameras', str(args.cameras), '--track-len', str(args.track_len), '--total-points',
            str(args.total_points), '--exchange-child']
@@ -270,8 +277,15 @@ def main():
         else:
             dist.init_process_group('nccl', device_id=dev)
 
+    t_start = time.perf_counter()
+
+    def note(msg):      # progress on stderr: a run over 100 M observations is silent for a minute at a time otherwise
+        if rank == 0 and not args.exchange_child:
+            print(f'[bench.py {time.perf_counter() - t_start:6.1f} s] {msg}', file=sys.stderr, flush=True)
+
     ba = importlib.import_module('3d_reconstruction_amd')
     N_total = args.points_per_gpu if world == 1 else args.total_points
+    note(f'building the scene ({N_total} points, part {rank + 1} of {world})')
     sc = ba.scenes.orbit_scene(N=N_total, K=args.cameras, track_len=args.track_len, seed=0, part=rank, parts=world)
     nv_local = int(sc['i'].size)
     nv_t = torch.tensor([nv_local], dtype=torch.int64, device='cpu' if share else dev)
@@ -291,6 +305,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    note(f'{nv_total} observations in all, {nv_local} here: problem set-up, pre-heating, timed loop')
     sh = ba.engine.Shard(sc['i'], sc['j'], sc['uv'], sc['N_local'], sc['K'], sc['W'], sc['H'], dev,
                          n_visible_total=nv_total)
     fit, dt = run_loop(ba, sh, sc, args.steps, args.warmup, sync)
@@ -347,6 +362,7 @@ def main():
     # ---- the pass with the J^T J blocks, stand-alone, on this rank's shard (and, at N = 1, on the 12.5 M-observation
     # share a GPU holds when 100 M observations are split eight ways)
     if not args.no_jtj:
+        note(f'timed loop done ({dt / args.steps * 1e6:.1f} us per iteration); the pass with the J^T J blocks')
         jt = time_jtj_pass(ba, sc, dev, nv_total)
         if rank == 0:
             out['roofline_jtj'] = roofline_block(
@@ -369,6 +385,7 @@ def main():
 
     # ---- N > 1: the same scene on ONE GPU (rank 0 builds every rank's shard), for the 1 -> N speed-up
     if world > 1 and not args.no_one_gpu_reference:
+        note('the whole scene on one GPU (rank 0 builds every part; the other ranks wait)')
         if rank == 0:
             # rank 0 builds the other ranks' shards of the scene itself (seconds each; the others wait at the barrier)
             parts = [sc] + [ba.scenes.orbit_scene(N=N_total, K=args.cameras, track_len=args.track_len, seed=0, part=r,
@@ -393,6 +410,7 @@ def main():
 
     # ---- N > 1: the node exchange kernel as the carrier of the sums, measured by child processes
     if world > 1 and not args.no_exchange_trial:
+        note('the same loop with the node exchange kernel, in child processes')
         rep = exchange_trial(args, rank, world, local_rank)
         if rank == 0:
             out['config']['transports'] = {
@@ -402,6 +420,7 @@ def main():
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
+            note('CPU baseline (one host core)')
             out['cpu_baseline'] = cpu_baseline(sc)
         print(json.dumps(out), flush=True)
     if world > 1:
