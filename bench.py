@@ -163,9 +163,10 @@ def run_loop(ba, sh, sc, steps, warmup, sync, timed=True):
     fit = ba.SceneFit(sh, lr=1e-3, max_iters=total + 8, patience=1000, print_step=10 ** 9, printer=lambda *a: None)
     # HIP events on about ten launches of the observation-pass kernel spread over the timed region (handed to the
     # dispatch itself, so they hold the kernel's own begin and end; such a launch costs the host about 30 us more than
-    # a plain one, which is why not every launch carries them), two samples in short runs (each is 2.5 % of a
-    # 20-iteration run)
-    fit.timed_every = max(1, steps // 10 if steps >= 90 else -(-steps // 2)) if timed else 0
+    # a plain one - the launch is issued by the wait for the previous energy, with a few microseconds of camera step
+    # left to hide it - which is why not every launch carries them): one sample in runs under 40 iterations (2.5 %
+    # of a 20-iteration run), two up to 90, then one in every tenth of the run
+    fit.timed_every = max(1, steps // 10 if steps >= 90 else (-(-steps // 2) if steps >= 40 else steps)) if timed else 0
     for _ in range(warmup):
         if not fit.step():
             raise RuntimeError('the fit stopped during the warm-up')

@@ -11,7 +11,7 @@ def fresh(max_iters):
 f0 = fresh(800)
 for _ in range(700): f0.step()
 torch.cuda.synchronize()
-for timed_every, warm, steps in ((0, 5, 20), (6, 5, 20), (0, 5, 20), (0, 50, 20), (0, 5, 100), (0, 300, 300)):
+for timed_every, warm, steps in ((0, 5, 20), (10, 5, 20), (20, 5, 20), (0, 5, 20), (0, 50, 20), (0, 5, 100), (0, 300, 300)):
     fit = fresh(warm + steps + 8)
     fit.timed_every = timed_every
     for _ in range(warm): fit.step()
