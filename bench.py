@@ -209,19 +209,25 @@ def launch_ranks(args, argv):
     return rc
 
 
-def exchange_trial(args, rank, world, local_rank):
-    """The same distributed loop with the sums over the ranks carried by the library's node exchange instead of
-    RCCL, in CHILD processes of the ranks (a group of their own on another port): whatever happens to them, the
-    measurement already taken stands.  Returns the child's report on rank 0 (a dict) or an error string."""
-    port = int(os.environ.get('MASTER_PORT', '29500')) + 23
-    env = dict(os.environ, MASTER_PORT=str(port), BA_NODE_EXCHANGE='1', RANK=str(rank), LOCAL_RANK=str(local_rank),
+def exchange_child_env(environ, rank, local_rank, world):
+    """Environment of an exchange-trial child: a group of its own on its own port.  Under torch.distributed.run
+    the ranks carry the launcher's rendezvous settings (TORCHELASTIC_USE_AGENT_STORE makes every rank a CLIENT of
+    the launcher's store, which does not exist on the children's port): those do not travel."""
+    port = int(environ.get('MASTER_PORT', '29500')) + 23
+    env = dict(environ, MASTER_PORT=str(port), BA_NODE_EXCHANGE='1', RANK=str(rank), LOCAL_RANK=str(local_rank),
                WORLD_SIZE=str(world))
-    # under torch.distributed.run the ranks carry the launcher's rendezvous settings (TORCHELASTIC_USE_AGENT_STORE
-    # makes every rank a CLIENT of the launcher's store): the children form a group of their own on their own port
     for name in list(env):
         if name.startswith('TORCHELASTIC_') or name in ('GROUP_RANK', 'ROLE_RANK', 'ROLE_NAME', 'ROLE_WORLD_SIZE',
                                                         'GROUP_WORLD_SIZE', 'LOCAL_WORLD_SIZE'):
             del env[name]
+    return env
+
+
+def exchange_trial(args, rank, world, local_rank):
+    """The same distributed loop with the sums over the ranks carried by the library's node exchange instead of
+    RCCL, in CHILD processes of the ranks (a group of their own on another port): whatever happens to them, the
+    measurement already taken stands.  Returns the child's report on rank 0 (a dict) or an error string."""
+    env = exchange_child_env(os.environ, rank, local_rank, world)
     cmd = [sys.executable, os.path.abspath(__file__), '--gpus', str(world), '--steps', str(args.steps), '--warmup',
            str(args.warmup), '--cameras', str(args.cameras), '--track-len', str(args.track_len), '--total-points',
            str(args.total_points), '--exchange-child']

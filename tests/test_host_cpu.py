@@ -324,3 +324,31 @@ def test_track_files_round_trip(tmp_path):
         pickle.dump((X_pix, W, H, print), fh, protocol=4)
     with pytest.raises(ValueError, match='not a pickled'):
         tracks.load_tracks(str(evil))
+
+
+def test_bench_launcher_without_enough_gpus_and_child_environment():
+    """`bench.py --gpus N` on a machine with fewer GPUs: one line on stderr, status 2, nothing on stdout, nothing
+    run.  The exchange-trial children do not inherit the launcher's rendezvous variables."""
+    import importlib.util
+    import os
+    import subprocess
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.device_count() < 2:
+        env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'BA_BENCH_SHARE_GPU')}
+        res = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2'], env=env, capture_output=True,
+                             text=True, timeout=300)
+        assert res.returncode == 2 and res.stdout == ''
+        lines = [ln for ln in res.stderr.strip().splitlines() if 'bench.py' in ln]
+        assert len(lines) == 1 and '--gpus 2' in lines[0] and 'nothing was run' in lines[0]
+    spec = importlib.util.spec_from_file_location('bench_under_test', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    launcher = {'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': '29500', 'RANK': '3', 'LOCAL_RANK': '3', 'WORLD_SIZE': '8',
+                'TORCHELASTIC_USE_AGENT_STORE': 'True', 'TORCHELASTIC_RUN_ID': 'none', 'GROUP_RANK': '0',
+                'LOCAL_WORLD_SIZE': '8', 'HOME': '/root'}
+    env = bench.exchange_child_env(launcher, 3, 3, 8)
+    assert env['MASTER_PORT'] == '29523' and env['RANK'] == '3' and env['WORLD_SIZE'] == '8'
+    assert env['BA_NODE_EXCHANGE'] == '1' and env['HOME'] == '/root' and env['MASTER_ADDR'] == '127.0.0.1'
+    assert not any(k.startswith('TORCHELASTIC_') or k in ('GROUP_RANK', 'LOCAL_WORLD_SIZE') for k in env)
