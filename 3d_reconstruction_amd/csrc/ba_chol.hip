@@ -20,10 +20,22 @@
 // The inverse of every diagonal block is kept (trsm is a product with it, and so are the two
 // triangular solves of the right-hand side).
 //
+// Structural zeros.  The storage is dense, the work is not: the reduced camera system of a video is block-banded
+// (two cameras are coupled only if they see a common point) plus the dense row of the shared field of view.
+// Cholesky factorisation creates no entries left of a row's first entry (the envelope), so before factorising,
+// the first occupied 64-column block of every 64-row block is read off the matrix (k_block_profile), and from it
+// reach[k] = the last block row that has an entry at or left of column block k.  Rows behind reach[k] hold zeros
+// in a panel that ends at block k: the rows kernel and the update kernel leave them out, by grid size (their block
+// index skips from the band to the dense border - the block rows of the last unknown and the padding, and before
+// them any last rows that reach far back, as the last cameras of a closed path do - through RowMap).  A dense matrix gives reach = everything and the plain factorisation.  BA_CHOL_DENSE=1 turns the
+// skipping off.
+//
 #include "ba_device.h"
 
 #include <stdlib.h>
+#include <algorithm>
 #include <string>
+#include <vector>
 
 namespace ba {
 
@@ -35,6 +47,40 @@ constexpr int KC = 16;    // columns of the panel staged in LDS at a time
 constexpr int LDT = TS + 4;    // row pitch of the staged (column-major) panel chunks in LDS
 
 static int cdiv_c(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// logical index of a row block / tile inside a launch -> physical index: the indices from gap_start on skip gap_len
+struct RowMap {
+    int gap_start = 0x7fffffff, gap_len = 0;
+    __host__ __device__ int64_t operator()(int64_t logical) const { return logical >= gap_start ? logical + gap_len : logical; }
+};
+
+// first[ib] (preset to ib) = the first 64-column block of block row ib of the lower triangle that holds a nonzero
+// entry.  Workgroup (ib, chunk): scans PROFILE_CHUNK column blocks from the left, stops at the first hit.
+constexpr int PROFILE_CHUNK = 32;
+__global__ void __launch_bounds__(256) k_block_profile(const double *__restrict__ A, int64_t ld, int *__restrict__ first) {
+    __shared__ int s_first;
+    const int ib = blockIdx.x, j_begin = blockIdx.y * PROFILE_CHUNK;
+    const int j_end = min(ib, j_begin + PROFILE_CHUNK);
+    const int tid = threadIdx.x;
+    if (j_begin >= j_end) return;
+    if (tid == 0) s_first = first[ib];
+    __syncthreads();
+    if (j_begin >= s_first) return;       // a chunk further left already found one (the others settle it by atomicMin)
+    const double *row = A + ((int64_t)NB * ib + (tid >> 2)) * ld + 16 * (tid & 3);
+    for (int jb = j_begin; jb < j_end; ++jb) {
+        const double2 *p = (const double2 *)(row + (int64_t)NB * jb);
+        int nz = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double2 v = p[u];
+            nz |= (v.x != 0.0) | (v.y != 0.0);
+        }
+        if (__syncthreads_or(nz)) {
+            if (tid == 0) atomicMin(first + ib, jb);
+            return;
+        }
+    }
+}
 
 // L_kk = chol(A_kk) in place and Linv = L_kk^-1 (64 x 64, row-major), one workgroup of four waves.
 // Factorisation: thread (row i = tid % 64, wave q = tid / 64) keeps L[i][q + 4u], u = 0..15, in
@@ -311,11 +357,11 @@ __global__ void __launch_bounds__(256) k_diag_syrk(double *__restrict__ A, int64
 // LDS buffers, the next one loaded while the matrix cores work on the current one.
 template <int NBK>
 __global__ void __launch_bounds__(256) k_panel_rows(double *__restrict__ A, int64_t ld, int64_t p0,
-                                                    const double *__restrict__ Linv) {
+                                                    const double *__restrict__ Linv, RowMap map) {
     extern __shared__ double sm[];
     constexpr int NOPS = NBK * (NBK + 1) / 2;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    double *rows = A + (p0 + NB * NBK + (int64_t)NB * blockIdx.x + 16 * w) * ld + p0;
+    double *rows = A + (p0 + NB * NBK + (int64_t)NB * map(blockIdx.x) + 16 * w) * ld + p0;
     double *patch = sm + 2 * NB * LP + w * 16 * TP;
     double S[NBK][16];
 #pragma unroll
@@ -384,7 +430,7 @@ __global__ void __launch_bounds__(256) k_panel_rows(double *__restrict__ A, int6
 // row per lane makes every load instruction touch 64 cache lines and leaves the kernel bound by the
 // address pipeline of the vector memory unit.
 __global__ void __launch_bounds__(256, 2) k_syrk_trailing(double *__restrict__ A, int64_t ld, int64_t k0, int kw, int64_t c0,
-                                                          int64_t nct) {
+                                                          int64_t nct, RowMap map) {
     extern __shared__ double smem[];
     double(*As)[LDT] = (double(*)[LDT])smem;
     double(*Bs)[LDT] = (double(*)[LDT])(smem + KC * LDT);
@@ -402,7 +448,7 @@ __global__ void __launch_bounds__(256, 2) k_syrk_trailing(double *__restrict__ A
         bi = nct + (t - tri) / nct;
         bj = (t - tri) % nct;
     }
-    const int64_t i0 = c0 + TS * bi, j0 = c0 + TS * bj;
+    const int64_t i0 = c0 + TS * map(bi), j0 = c0 + TS * map(bj);     // tiles counted without the rows left out
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
     const int r16 = lane & 15, k4 = lane >> 4, j4 = lane & 3;
     const bool active = !(bi == bj && wc > wr);     // the sub-tile above the diagonal is never used
@@ -606,17 +652,68 @@ int ba_cholesky_solve(int64_t n, int64_t ld, double *S, double *rhs, int *h_info
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void *)k_panel_rows<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows);
     const bool ride_along = ld > n;     // a padding row is there to carry the right-hand side
+    // reach[k]: the last block row before the dense border (block rows from `border` on: the last unknown's and the
+    // padding) with an entry at or left of column block k; see "Structural zeros" at the top
+    int64_t border = (n - 1) / NB;
+    std::vector<int> reach((size_t)nb);
+    for (int64_t k = 0; k < nb; ++k) reach[k] = (int)(nb - 1);
+    if (e == hipSuccess && !getenv("BA_CHOL_DENSE") && border > 1) {
+        std::vector<int> first((size_t)nb);
+        for (int64_t k = 0; k < nb; ++k) first[k] = (int)k;
+        int *d_first = nullptr;
+        e = hipMalloc(&d_first, sizeof(int) * nb);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_first, first.data(), sizeof(int) * nb, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_block_profile, dim3((unsigned)nb, (unsigned)cdiv_c(nb, PROFILE_CHUNK)), dim3(256), 0, st, S, ld,
+                               d_first);
+            e = hipMemcpyAsync(first.data(), d_first, sizeof(int) * nb, hipMemcpyDeviceToHost, st);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        hipFree(d_first);
+        if (e == hipSuccess) {
+            // The last block rows before the structural border join it when they reach far further back than the
+            // typical row does (a closed camera path couples the last cameras with the first): any choice of the
+            // border is correct - its rows are always processed in full - this one keeps them from defining reach.
+            std::vector<int> width((size_t)border);
+            for (int64_t ib = 0; ib < border; ++ib) width[ib] = (int)ib - first[ib];
+            std::nth_element(width.begin(), width.begin() + border / 2, width.end());
+            const int typical = width[border / 2];
+            while (border > 2 && (border - 1) - first[border - 1] > 4 * typical + 4) --border;
+            std::vector<int> last((size_t)nb, -1);      // last[c]: the last block row (before the border) that starts at column block c
+            for (int64_t ib = 0; ib < border; ++ib) last[first[ib]] = (int)ib;
+            int far = 0;
+            for (int64_t k = 0; k < nb; ++k) {
+                far = std::max(far, std::max(last[k], (int)k));
+                reach[k] = far;
+            }
+        }
+    }
+    // block rows / tiles a launch covers when its panel ends at column block k_last and its rows start at block
+    // (tile) `start`, in units of `unit` blocks: those up to reach[k_last], then the border; returns their number
+    auto row_map = [&](int64_t k_last, int64_t start, int unit, RowMap &map) {
+        const int64_t total = cdiv_c(nb, unit), border_u = border / unit, reach_u = reach[k_last] / unit;
+        map = RowMap();
+        if (start >= border_u || reach_u + 1 >= border_u) return total - start;
+        const int64_t band = std::max<int64_t>(reach_u - start + 1, 0);
+        map.gap_start = (int)band;
+        map.gap_len = (int)(border_u - (start + band));
+        return band + (total - border_u);
+    };
     if (e == hipSuccess) {
         if (ride_along) hipLaunchKernelGGL(k_rhs_into_row, dim3(cdiv_c(ld, 256)), dim3(256), 0, st, S, ld, n, rhs);
         // tiles of the region C[c0.., c0 .. c_end): lower triangle of the first tile columns, whole rows below
         auto trailing = [&](int64_t k_first, int64_t kw, int64_t c0, int64_t c_end) {
             if (c0 >= ld || c_end <= c0) return;
-            const int64_t nt = cdiv_c(ld - c0, TS);
-            int64_t nct = cdiv_c(c_end - c0, TS);
-            if (nct > nt) nct = nt;
+            RowMap map;
+            const int64_t nt = row_map((k_first + kw - 1) / NB, c0 / TS, TS / NB, map);     // tile rows, the left-out ones not counted
+            // tile columns: those of the rows kept whose physical column lies before c_end
+            const int64_t c_end_t = cdiv_c(c_end - c0, TS);
+            int64_t nct = 0;
+            while (nct < nt && map(nct) < c_end_t) ++nct;
+            if (nct == 0) return;
             const int64_t tiles = nct * (nct + 1) / 2 + (nt - nct) * nct;
             hipLaunchKernelGGL(k_syrk_trailing, dim3((unsigned)tiles), dim3(256), lds_trailing, st, S, ld, k_first, (int)kw, c0,
-                               nct);
+                               nct, map);
         };
         for (int64_t o0 = 0; o0 < ld; o0 += OB) {
             const int64_t o_end = (ld - o0 < OB) ? ld : o0 + OB;
@@ -635,12 +732,13 @@ int ba_cholesky_solve(int64_t n, int64_t ld, double *S, double *rhs, int *h_info
                             hipLaunchKernelGGL(k_diag_syrk, dim3(below * (below + 1) / 2), dim3(256), lds_diag, st, S, ld, p0, kb);
                         }
                     }
-                    const int slabs = (int)((ld - p0 - pw) / NB);
-                    if (slabs > 0) {
-                        if (nbk == 4) hipLaunchKernelGGL(k_panel_rows<4>, dim3(slabs), dim3(256), lds_rows, st, S, ld, p0, Li);
-                        else if (nbk == 3) hipLaunchKernelGGL(k_panel_rows<3>, dim3(slabs), dim3(256), lds_rows, st, S, ld, p0, Li);
-                        else if (nbk == 2) hipLaunchKernelGGL(k_panel_rows<2>, dim3(slabs), dim3(256), lds_rows, st, S, ld, p0, Li);
-                        else hipLaunchKernelGGL(k_panel_rows<1>, dim3(slabs), dim3(256), lds_rows, st, S, ld, p0, Li);
+                    if (p0 + pw < ld) {
+                        RowMap map;
+                        const int slabs = (int)row_map((p0 + pw - 1) / NB, (p0 + pw) / NB, 1, map);
+                        if (nbk == 4) hipLaunchKernelGGL(k_panel_rows<4>, dim3(slabs), dim3(256), lds_rows, st, S, ld, p0, Li, map);
+                        else if (nbk == 3) hipLaunchKernelGGL(k_panel_rows<3>, dim3(slabs), dim3(256), lds_rows, st, S, ld, p0, Li, map);
+                        else if (nbk == 2) hipLaunchKernelGGL(k_panel_rows<2>, dim3(slabs), dim3(256), lds_rows, st, S, ld, p0, Li, map);
+                        else hipLaunchKernelGGL(k_panel_rows<1>, dim3(slabs), dim3(256), lds_rows, st, S, ld, p0, Li, map);
                     }
                 }
                 // inside the outer panel: only its remaining columns see this 256-wide panel now

@@ -2,6 +2,7 @@
 has no such solver: these results are pinned by this repository's own dense normal equations
 (oracle.dense_jacobian) on small scenes — "parity unpinned" with respect to the reference."""
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -104,6 +105,47 @@ def test_cholesky_solve_random_spd(ba):
     info = C.c_int(0)
     assert lib.ba_cholesky_solve(64, 64, C.c_void_p(Sd.data_ptr()), C.c_void_p(bd.data_ptr()), C.byref(info), None) == -4
     assert info.value == 1
+
+
+def test_cholesky_skips_structural_zeros_correctly(ba):
+    """Block-banded matrices with a dense last row (the shape of a video's reduced camera system), one of them with
+    a row in the middle that reaches back to the first columns: the factorisation leaves out the rows a panel cannot
+    touch and must still give the dense result - solution and factor."""
+    lib = ba.engine._lib.load()
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    for n, bw, far_row in ((1500, 70, None), (3000, 200, None), (5000, 90, 2600), (4097, 300, 1000)):
+        ld = (n + 63) // 64 * 64
+        S = np.zeros((n, n))
+        for d in range(1, bw + 1):
+            v = rng.normal(size=n - d)
+            S[np.arange(d, n), np.arange(n - d)] = v
+        S[n - 1, :n - 1] = rng.normal(size=n - 1)            # the arrow
+        if far_row is not None:
+            S[far_row, :40] = rng.normal(size=40)            # one row far outside the band
+            S[n - 60:n - 1, :50] = rng.normal(size=(59, 50))  # and the last rows coupled with the first columns (closed path)
+        S = S + S.T
+        S[np.diag_indices(n)] = np.abs(S).sum(axis=1) + 1.0  # diagonally dominant: positive definite
+        b = rng.normal(size=n)
+        Sp = np.eye(ld)
+        Sp[:n, :n] = S
+        Sp[np.triu_indices(ld, 1)] = np.nan
+        want_x, want_L = np.linalg.solve(S, b), np.linalg.cholesky(S)
+        for dense in (False, True):
+            Sd = torch.from_numpy(Sp).to(DEV)
+            bd = torch.zeros(ld, dtype=torch.float64, device=DEV)
+            bd[:n] = torch.from_numpy(b)
+            info = C.c_int(7)
+            if dense:
+                os.environ['BA_CHOL_DENSE'] = '1'
+            try:
+                ba.engine.check(lib.ba_cholesky_solve(n, ld, C.c_void_p(Sd.data_ptr()), C.c_void_p(bd.data_ptr()),
+                                                      C.byref(info), None))
+            finally:
+                os.environ.pop('BA_CHOL_DENSE', None)
+            assert info.value == 0
+            assert rel_err(bd.cpu().numpy()[:n], want_x) < 1e-10
+            assert rel_err(np.tril(Sd.cpu().numpy()[:n, :n]), want_L) < 1e-11
 
 
 def test_lm_step_matches_dense_solve(ba):
