@@ -449,6 +449,11 @@ __global__ void __launch_bounds__(256, 2) k_syrk_trailing(double *__restrict__ A
         bj = (t - tri) % nct;
     }
     const int64_t i0 = c0 + TS * map(bi), j0 = c0 + TS * map(bj);     // tiles counted without the rows left out
+    // With few tiles (a banded matrix) the panel's columns are split over gridDim.y workgroups per tile, kw columns
+    // each, which add their parts to C with atomics: one workgroup walking through 1024 columns alone is 200 us of
+    // latency with the rest of the chip idle.
+    k0 += (int64_t)blockIdx.y * kw;
+    const bool shared_tile = gridDim.y > 1;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
     const int r16 = lane & 15, k4 = lane >> 4, j4 = lane & 3;
     const bool active = !(bi == bj && wc > wr);     // the sub-tile above the diagonal is never used
@@ -544,7 +549,9 @@ __global__ void __launch_bounds__(256, 2) k_syrk_trailing(double *__restrict__ A
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int64_t cc = j0 + 64 * wc + 16 * c + r16;
-            if (cc < ld) A[row * ld + cc] -= acc[I][c];
+            if (cc >= ld) continue;
+            if (shared_tile) __hip_atomic_fetch_add(A + row * ld + cc, -acc[I][c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else A[row * ld + cc] -= acc[I][c];
         }
     }
 }
@@ -569,9 +576,10 @@ __global__ void k_row_to_rhs(const double *__restrict__ A, int64_t ld, int64_t n
 // backward (L^T x = y): x_k = Linv_k^T b_k, then b_i -= L_ki^T x_k for the rows i before block k
 // Every workgroup forms the 64-vector itself (b_k is not overwritten by this launch: the result
 // goes to `out`), then updates its own 256 rows.  Workgroup 0 stores the result.
+// transpose: rows before i_begin are left out (the block row k has no entries there).
 __global__ void __launch_bounds__(256) k_solve_step(const double *__restrict__ A, int64_t ld, int64_t k0,
                                                     const double *__restrict__ Linv, double *__restrict__ b,
-                                                    double *__restrict__ out, int transpose) {
+                                                    double *__restrict__ out, int transpose, int64_t i_begin) {
     __shared__ double bk[NB], yk[NB], part[4][NB];
     const int tid = threadIdx.x;
     if (tid < NB) bk[tid] = b[k0 + tid];
@@ -600,7 +608,7 @@ __global__ void __launch_bounds__(256) k_solve_step(const double *__restrict__ A
         for (int c = 0; c < NB; ++c) s += Ar[c] * yk[c];
         b[i] -= s;
     } else {
-        const int64_t i = row;
+        const int64_t i = i_begin + row;
         if (i >= k0) return;
         double s = 0.0;
 #pragma unroll 8
@@ -655,7 +663,7 @@ int ba_cholesky_solve(int64_t n, int64_t ld, double *S, double *rhs, int *h_info
     // reach[k]: the last block row before the dense border (block rows from `border` on: the last unknown's and the
     // padding) with an entry at or left of column block k; see "Structural zeros" at the top
     int64_t border = (n - 1) / NB;
-    std::vector<int> reach((size_t)nb);
+    std::vector<int> reach((size_t)nb), row_first((size_t)nb, 0);     // row_first[k]: first occupied column block of block row k
     for (int64_t k = 0; k < nb; ++k) reach[k] = (int)(nb - 1);
     if (e == hipSuccess && !getenv("BA_CHOL_DENSE") && border > 1) {
         std::vector<int> first((size_t)nb);
@@ -674,6 +682,7 @@ int ba_cholesky_solve(int64_t n, int64_t ld, double *S, double *rhs, int *h_info
             // The last block rows before the structural border join it when they reach far further back than the
             // typical row does (a closed camera path couples the last cameras with the first): any choice of the
             // border is correct - its rows are always processed in full - this one keeps them from defining reach.
+            row_first = first;
             std::vector<int> width((size_t)border);
             for (int64_t ib = 0; ib < border; ++ib) width[ib] = (int)ib - first[ib];
             std::nth_element(width.begin(), width.begin() + border / 2, width.end());
@@ -712,8 +721,10 @@ int ba_cholesky_solve(int64_t n, int64_t ld, double *S, double *rhs, int *h_info
             while (nct < nt && map(nct) < c_end_t) ++nct;
             if (nct == 0) return;
             const int64_t tiles = nct * (nct + 1) / 2 + (nt - nct) * nct;
-            hipLaunchKernelGGL(k_syrk_trailing, dim3((unsigned)tiles), dim3(256), lds_trailing, st, S, ld, k_first, (int)kw, c0,
-                               nct, map);
+            int split = 1;      // workgroups per tile: as long as the launch stays within one round of the chip
+            while (tiles * split * 2 <= 256 && kw % (split * 2 * NB) == 0) split *= 2;
+            hipLaunchKernelGGL(k_syrk_trailing, dim3((unsigned)tiles, (unsigned)split), dim3(256), lds_trailing, st, S, ld,
+                               k_first, (int)(kw / split), c0, nct, map);
         };
         for (int64_t o0 = 0; o0 < ld; o0 += OB) {
             const int64_t o_end = (ld - o0 < OB) ? ld : o0 + OB;
@@ -753,12 +764,14 @@ int ba_cholesky_solve(int64_t n, int64_t ld, double *S, double *rhs, int *h_info
         } else {
             for (int64_t k = 0; k < nb; ++k)
                 hipLaunchKernelGGL(k_solve_step, dim3(k + 1 < nb ? cdiv_c(ld - (k + 1) * NB, 256) : 1), dim3(256), 0, st, S,
-                                   ld, k * NB, Linv + k * NB * NB, rhs, tmp, 0);
+                                   ld, k * NB, Linv + k * NB * NB, rhs, tmp, 0, (int64_t)0);
             e = hipMemcpyAsync(rhs, tmp, sizeof(double) * ld, hipMemcpyDeviceToDevice, st);
         }
-        for (int64_t k = nb - 1; k >= 0; --k)
-            hipLaunchKernelGGL(k_solve_step, dim3(k > 0 ? cdiv_c(k * NB, 256) : 1), dim3(256), 0, st, S, ld, k * NB,
-                               Linv + k * NB * NB, rhs, tmp, 1);
+        for (int64_t k = nb - 1; k >= 0; --k) {
+            const int64_t i_begin = (int64_t)row_first[k] * NB;     // L has nothing left of the row's first entry
+            hipLaunchKernelGGL(k_solve_step, dim3(k * NB > i_begin ? cdiv_c(k * NB - i_begin, 256) : 1), dim3(256), 0, st, S, ld,
+                               k * NB, Linv + k * NB * NB, rhs, tmp, 1, i_begin);
+        }
         if (e == hipSuccess) e = hipMemcpyAsync(rhs, tmp, sizeof(double) * ld, hipMemcpyDeviceToDevice, st);
         if (e == hipSuccess) e = hipGetLastError();
     }
