@@ -269,7 +269,10 @@ int ba_resect(int64_t N, int64_t K, const int64_t *col_ptr, const int32_t *oi_by
  *   solution of S d = rhs in place; *h_info = 0 or 1 + index of the first non-positive pivot.
  *   Rows and columns n .. ld-1 of S must be the identity and rhs[n .. ld) zero on entry (ba_schur_build leaves
  *   them so).  When ld > n the last of these rows is used as work space (it carries the right-hand side through
- *   the factorisation) and does not hold the identity afterwards.
+ *   the factorisation) and does not hold the identity afterwards.  Blocks that are structurally zero are not
+ *   computed: the first occupied 64-column block of every 64-row block is read off S before the factorisation
+ *   (Cholesky creates no entries left of it), which costs one pass over the lower triangle and one host
+ *   synchronisation; the environment variable BA_CHOL_DENSE=1 computes every tile.
  * ba_backsubstitute: dX[N][3] = V'^-1 (-g_X - W d_cam - Xphi d_phi); dcam_packed (optional, 6K+1)
  *   receives d reordered to [dC (3K) | dTheta (3K) | dphi].  The trial point of the damped step comes out of
  *   the same two launches when asked for: X_trial[N][3] (optional) = X + dX, cam_trial (optional, 6K+1) =
