@@ -218,6 +218,17 @@ class Shard:
         else:
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM, group=self.group)
 
+    def _broadcast_first(self, t):
+        """The first rank's values of a device tensor to every rank of the group, in place."""
+        dist = torch.distributed
+        src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+        if self._stage_reduce:
+            host = t.cpu()
+            dist.broadcast(host, src=src, group=self.group)
+            t.copy_(host)
+        else:
+            dist.broadcast(t, src=src, group=self.group)
+
     @property
     def rank_sum_path(self):
         """How the short sums over the ranks travel (known after the first one)."""
@@ -608,6 +619,16 @@ class Shard:
             on_system(self.S, self.rhs)
         status = self.lib.ba_cholesky_solve(self.n_red, self.ld_red, ptr(self.S), ptr(self.rhs), C.byref(info),
                                             self.stream)
+        if self.distributed:
+            # Every rank factorised the same system, but sums inside the factorisation are not ordered (the update
+            # kernel adds parts of a tile with atomics): the ranks' solutions can differ in the last bits, and at a
+            # borderline pivot even their verdicts.  The first rank's verdict and solution become everybody's, so the
+            # replicated camera state stays bit-identical.
+            verdict = torch.tensor([float(status), float(info.value)], dtype=F64, device=self.device)
+            self._broadcast_first(verdict)
+            status, info.value = int(verdict[0].item()), int(verdict[1].item())
+            if status == 0:
+                self._broadcast_first(self.rhs)
         if status == -4:
             return int(info.value)
         check(status)

@@ -20,8 +20,9 @@ and the damping keeps the normal equations positive definite.
 
 Several GPUs: points are sharded like in the first-order path; the camera-side blocks, the
 Schur complement and its right-hand side are summed over the ranks (engine.Shard.eval_jtj,
-lm_step), every rank solves the reduced system itself, and the loop below runs identically on all
-ranks (the energy it branches on is the cross-GPU sum)."""
+lm_step), every rank solves the reduced system itself and adopts the first rank's solution (the ranks'
+own ones agree only to rounding), and the loop below runs identically on all ranks (the energy it
+branches on is the cross-GPU sum)."""
 from __future__ import annotations
 
 import numpy as np
