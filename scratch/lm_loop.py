@@ -1,0 +1,19 @@
+"""Wall time of whole LM iterations (lm.LMFit) at cfg3 / cfg5 sizes: lm_loop.py [K] [N] [iterations]"""
+import importlib, os, sys, time, numpy as np
+sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '.'))
+import torch
+ba = importlib.import_module('3d_reconstruction_amd')
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
+iters = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+sc = ba.scenes.orbit_scene(N=N, K=K, track_len=10, seed=0)
+sh = ba.engine.Shard(sc['i'], sc['j'], sc['uv'], sc['N_local'], K, sc['W'], sc['H'], 'cuda:0')
+sh.set_params(sc['X_0'], sc['C_0'], sc['Theta_0'], sc['phi_x_0'])
+lines = []
+fit = ba.lm.LMFit(sh, iters + 1, lam=1e-3, print_step=10 ** 9, printer=lines.append)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+fit.run()
+torch.cuda.synchronize(); dt = time.perf_counter() - t0
+E = fit.energies()
+print(f'K={K} N={N} |V|={sc["i"].size}: {fit.iters} LM iterations ({fit.accepted} accepted, {fit.rejected} rejected) in {dt*1e3:.1f} ms '
+      f'= {dt/max(fit.iters,1)*1e3:.1f} ms each; E ' + ' '.join(f'{e:.5g}' for e in E), flush=True)
