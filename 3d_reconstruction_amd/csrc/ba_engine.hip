@@ -1105,7 +1105,6 @@ struct CameraStep {
     int do_gauge;
     double W, H;
     double *T;            // camera table (K x CAM_ROW), may be null
-    int table_centres;    // 0: leave the centres of the rows unwritten (quad kernel only)
     int scale_later;      // 1: k_scale_centres follows and applies the scale factor (quad kernel only)
     double *scalars;      // may be null
     double *R_out;        // optional K x 9
@@ -1893,7 +1892,7 @@ __global__ void __launch_bounds__(256) k_camera_step_quad(CameraStep a, CameraSt
                 const double c = v[u] * factor;
                 a.cam[idx] = c;
                 const int jc = idx / 3;
-                if (a.T && a.table_centres) a.T[(int64_t)jc * CAM_ROW + 9 + (idx - 3 * jc)] = c;
+                if (a.T) a.T[(int64_t)jc * CAM_ROW + 9 + (idx - 3 * jc)] = c;
             }
         }
     }
@@ -3011,7 +3010,6 @@ static int camera_step_impl(ba_problem *p, const double *cam_in, double *cam_out
     a.W = p->W;
     a.H = p->H;
     a.T = p->cam_table;
-    a.table_centres = 1;
     a.scale_later = (gauge && p->K > 2048) ? 1 : 0;     // beyond one batch of the kernel's last workgroup
     a.scalars = p->scalars;
     a.R_out = R_out;
@@ -3024,7 +3022,7 @@ static int camera_step_impl(ba_problem *p, const double *cam_in, double *cam_out
         hipLaunchKernelGGL(k_camera_step_quad, dim3(cdiv(p->K - 1, 63)), dim3(256), 0, (hipStream_t)stream, a, sh);
         if (a.scale_later)
             hipLaunchKernelGGL(k_scale_centres, dim3(cdiv(3 * p->K - 3, 256)), dim3(256), 0, (hipStream_t)stream, p->K,
-                               a.cam, a.table_centres ? a.T : nullptr, a.gauge);
+                               a.cam, a.T, a.gauge);
     } else {
         hipLaunchKernelGGL(k_camera_step_mb, dim3(cdiv(p->K, 256)), dim3(256), 0, (hipStream_t)stream, a, sh);
     }
