@@ -10,7 +10,8 @@ constexpr int BLOCK = 256;
 constexpr int UNROLL = 12;
 
 // MODE 0: ds_add_f64 no return   1: ds_write_b64   2: ds_read_b64   3: ds_write_b128   4: ds_add_f32   5: ds_read_b128
-//      6: ds_add_u64 no return   7: ds_add_u32 no return   8: ds_pk_add (two f32 atomics of one lane: lo/hi words)
+//      6: ds_add_u64 no return   7: ds_add_u32 no return   9 / 10: ds_add_f64 from half the lanes (lower half / even lanes)
+//      11: ds_add_f64 with lanes l and l + 32 on the same address
 // PAT  0: lane -> consecutive doubles   1: (p & 7) * S + (p >> 3) with S = 2 * odd   2: all lanes of 16 different, random permutation
 template <int MODE, int PAT>
 __global__ void __launch_bounds__(BLOCK) k(int iters, int S, const int *perm, double *out) {
@@ -37,6 +38,9 @@ __global__ void __launch_bounds__(BLOCK) k(int iters, int S, const int *perm, do
                 *(LDSP(v2d))a2 = (v2d){v, v};
             }
             if (MODE == 4) __hip_atomic_fetch_add((float *)a, (float)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (MODE == 9 && (tid & 63) < 32) __hip_atomic_fetch_add(a, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (MODE == 10 && (tid & 1) == 0) __hip_atomic_fetch_add(a, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (MODE == 11) __hip_atomic_fetch_add(lds + (u & 1) * PS + (sw & ~32), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (MODE == 6)
                 __hip_atomic_fetch_add((unsigned long long *)a, (unsigned long long)tid + 1ull, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -95,6 +99,9 @@ int main() {
         run<0, 1>("ds_add_f64 swizzled", w, S, dperm, dout);
         run<0, 2>("ds_add_f64 random perm", w, S, dperm, dout);
         run<4, 0>("ds_add_f32 linear (8B stride)", w, S, dperm, dout);
+        run<9, 0>("ds_add_f64 lanes 0..31 only", w, S, dperm, dout);
+        run<10, 0>("ds_add_f64 even lanes only", w, S, dperm, dout);
+        run<11, 0>("ds_add_f64 lanes l, l+32 same addr", w, S, dperm, dout);
         run<6, 0>("ds_add_u64 linear", w, S, dperm, dout);
         run<6, 1>("ds_add_u64 swizzled", w, S, dperm, dout);
         run<7, 0>("ds_add_u32 linear (8B stride)", w, S, dperm, dout);
