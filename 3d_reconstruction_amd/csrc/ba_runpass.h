@@ -223,7 +223,16 @@ __global__ void __launch_bounds__(TILE_BLOCK, sizeof(typename Rec::raw_t) <= 8 ?
     constexpr int PREC = pt_record_doubles(NPV);                // doubles of a point's LDS record
     // copies of the camera accumulators: a tile spreads its flushes over as many copies as the accumulator space
     // holds for its camera count (copy = round mod rep, by multiply and shift)
-    const int rep = min(15, a.cacc_slots / nc), rep_inv = (256 + rep - 1) / rep;
+    // The copies lie 8 (mod 32) doubles apart when there is room: the 32 lanes the LDS serves together hold 8 cameras
+    // x 4 rounds = 4 consecutive copies, which then fall on 32 different bank pairs.
+    const int csz = NCVL * nc, cspace = a.cacc_slots * NCVL;
+    int cstride = csz + ((8 - csz) & 31), rep = 1 + (cspace - csz) / cstride;
+    if (rep < 2 || rep < a.cacc_slots / nc) {       // the padding would cost a copy: pack them
+        cstride = csz;
+        rep = a.cacc_slots / nc;
+    }
+    rep = min(15, rep);
+    const int rep_inv = (256 + rep - 1) / rep;
     const int S = a.pt_stride;
     double *rows = lds;                                         // cam_cap x ROW_LDS
     double *cacc = rows + (size_t)a.cam_cap * ROW_LDS;          // rep x NCVL x nc (component-major, used sums only)
@@ -234,7 +243,7 @@ __global__ void __launch_bounds__(TILE_BLOCK, sizeof(typename Rec::raw_t) <= 8 ?
         stage_camera_row_rt(a.T + (int64_t)j * CAM_ROW, a.C + 3 * (int64_t)j, a.C_scale ? gauge_factor(a.C_scale) : 1.0,
                             rows + row * ROW_LDS);
     }
-    for (int idx = tid; idx < NCVL * nc * rep; idx += TILE_BLOCK) cacc[idx] = 0.0;
+    for (int idx = tid; idx < (rep - 1) * cstride + csz; idx += TILE_BLOCK) cacc[idx] = 0.0;
     {
         const double *G = a.X_gauge;
         double g[13] = {1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0};
@@ -311,7 +320,7 @@ __global__ void __launch_bounds__(TILE_BLOCK, sizeof(typename Rec::raw_t) <= 8 ?
                 __hip_atomic_fetch_add(pt_cur + 3 + v, pv[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __builtin_amdgcn_sched_barrier(0);     // keep the eight bodies apart: their live ranges add up otherwise
         }
-        double *acc = cacc + (size_t)(round - rep * ((round * rep_inv) >> 8)) * NCVL * nc + slot;
+        double *acc = cacc + (size_t)(round - rep * ((round * rep_inv) >> 8)) * cstride + slot;
 #pragma unroll
         for (int k = 0; k < NCV; ++k)
             if (Op::cv_used(k))
@@ -411,7 +420,7 @@ __global__ void __launch_bounds__(TILE_BLOCK, sizeof(typename Rec::raw_t) <= 8 ?
         const int comp = Op::cv_from_lds(cl);
         const int j = tm.j0 >= 0 ? tm.j0 + slot : a.cam_list[cb + slot];
         double v = cacc[idx];
-        for (int r = 1; r < rep; ++r) v += cacc[idx + (size_t)r * NCVL * nc];
+        for (int r = 1; r < rep; ++r) v += cacc[idx + (size_t)r * cstride];
         double *dst = (j == 0 && a.cam0) ? a.cam0 + comp : a.cam_sums + (int64_t)comp * a.K + j;
         __hip_atomic_fetch_add(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
