@@ -214,7 +214,7 @@ class NodeExchange:
         must ask for it at the same point of the program."""
         import os
         # opt-in: the default path for the sums over the ranks is RCCL on the compute stream (StreamAllReduce)
-        if os.environ.get('BA_NODE_EXCHANGE') != '1' or os.environ.get('BA_NO_NODE_EXCHANGE'):
+        if os.environ.get('BA_NODE_EXCHANGE') != '1':
             return None
         dist = torch.distributed
         pg = group if group is not None else dist.distributed_c10d._get_default_group()
@@ -247,8 +247,6 @@ class NodeExchange:
         import os
         import socket
         dist = torch.distributed
-        if os.environ.get('BA_NO_NODE_EXCHANGE'):
-            return None
         host = dist.get_backend(group) == 'gloo'
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         handle, obj = C.c_void_p(), None
