@@ -2391,8 +2391,10 @@ static int build_tiles(ba_problem *p) {
     hipFree(tile_sums);
     BA_HIP(e);
     // tiles pay off only while fetching every tile's camera rows stays small next to the
-    // observation stream
-    p->tiles_worth = getenv("BA_FORCE_TILES") || (double)total_cams * 128.0 <= 0.5 * 24.0 * (double)nV;
+    // observation stream - or when the scene is so small that bytes do not matter and the number of launches per
+    // iteration does (the tile form fuses the point update into the pass: two launches instead of four; a scene of
+    // 100 points x 300 frames: 28 -> 23 us per iteration)
+    p->tiles_worth = getenv("BA_FORCE_TILES") || (double)total_cams * 128.0 <= 0.5 * 24.0 * (double)nV || nV <= 200000;
     {
         BA_HIP(hipMalloc(&p->cam_list, sizeof(int32_t) * (total_cams > 0 ? total_cams : 1)));
         BA_HIP(hipMalloc(&p->opack, sizeof(uint32_t) * nV));
