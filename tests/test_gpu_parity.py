@@ -734,3 +734,44 @@ def test_parkour_shaped_scene(ba):
     for a, b in zip(got[:3], ref[:3]):
         assert np.abs(a - b).max() < 1e-6
     assert abs(got[3] - ref[3]) < 1e-6
+
+
+@pytest.mark.parametrize('seed', range(10))
+def test_random_scene_shapes_match_oracle(ba, seed):
+    """Scenes of random shape - few or many cameras per point, holes punched into the tracks, points seen once,
+    cameras that see nothing, either optimiser, a short patience so that the schedule raises and lowers the learning
+    rate - through the fused and the unfused loop against the oracle: every energy, the printed lines, the final
+    parameters."""
+    rng = np.random.default_rng(1000 + seed)
+    N = int(rng.choice([40, 300, 2500, 12000]))
+    K = int(rng.choice([2, 5, 30, 150, 600]))
+    track = int(rng.integers(2, max(3, min(K, 40)) + 1))
+    sc = ba.scenes.orbit_scene(N, K, track_len=min(track, K), seed=seed, stride=int(rng.integers(1, 3)))
+    keep = rng.random(sc['i'].size) > rng.choice([0.0, 0.1, 0.4])            # holes in the tracks
+    if K > 4:
+        keep &= sc['j'] != int(rng.integers(1, K))                           # a camera that sees nothing
+    i, j, uv = sc['i'][keep], sc['j'][keep], sc['uv'][keep]
+    if i.size < 20:
+        pytest.skip('nothing left of the scene')
+    opt = 'Adam' if seed % 3 else 'SGD'
+    lr = 1e-3 if opt == 'Adam' else 1e-7
+    kw = dict(optimizer=opt, patience=3, factor=2.0)
+    iters = 25
+    ref_log = []
+    ref = orc.fit_scene(i, j, uv, N, K, sc['W'], sc['H'], lr, iters, sc['X_0'], sc['C_0'], sc['Theta_0'], sc['phi_x_0'],
+                        log=ref_log, **kw)
+    for fuse in (True, False):
+        lines = []
+        sh = ba.engine.Shard(i, j, uv, N, K, sc['W'], sc['H'], DEV)
+        sh.set_params(sc['X_0'], sc['C_0'], sc['Theta_0'], sc['phi_x_0'])
+        fit = ba.SceneFit(sh, lr, iters, printer=lambda *a: lines.append(' '.join(str(x) for x in a)), print_step=10 ** 9,
+                          fuse=fuse, **kw).run()
+        assert rel_err(fit.energies(), ref[4]) < TOL, (N, K, track, opt, fuse)
+        events = [ln for ln in lines if 'LR' in ln or 'Reached' in ln]
+        assert events == [ln for ln in ref_log if 'LR' in ln or 'Reached' in ln]
+        cam = sh.cam.cpu().numpy()
+        assert np.abs(sh.points_to_caller(sh.X).cpu().numpy() - ref[0]).max() < 1e-8
+        assert np.abs(cam[:3 * K].reshape(K, 3) - ref[1]).max() < 1e-8
+        assert np.abs(cam[3 * K:6 * K].reshape(K, 3) - ref[2]).max() < 1e-8
+        assert abs(cam[6 * K] - ref[3]) < 1e-10
+        sh.close()
