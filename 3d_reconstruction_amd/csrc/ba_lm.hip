@@ -645,13 +645,19 @@ __global__ void __launch_bounds__(SCHUR_TILE_BLOCK) k_schur_tile(SchurTileArgs a
         // all ordered pairs (o, o') of the point's observations with slot >= slot': the pair loop is
         // wave-uniform, lane (al, be) < 36 owns one entry of the 6 x 6 block (no index arithmetic
         // with divisions inside the loop)
+        // a point's observations usually come in the order of the camera slots: the pairs with slot >= slot' are then
+        // the pairs o' <= o, and the inner loop needs no test (half its trips would fail it)
+        bool ascending = true;
+        for (int o = lane; o + 1 < deg; o += 64) ascending = ascending && sl[o] <= sl[o + 1];
+        ascending = __all(ascending);
         if (lane < 36) {
             const int al = lane / 6, be = lane - 6 * al;
             for (int o = 0; o < deg; ++o) {
                 const int so = sl[o];
                 const double w0 = Wl[o * 18 + al], w1 = Wl[o * 18 + 6 + al], w2 = Wl[o * 18 + 12 + al];
                 double *dst = St + (size_t)(so * (so + 1) / 2) * 36 + lane;
-                for (int o2 = 0; o2 < deg; ++o2) {
+                const int o2_end = ascending ? o + 1 : deg;
+                for (int o2 = 0; o2 < o2_end; ++o2) {
                     const int so2 = sl[o2];
                     if (so < so2) continue;
                     const double v = w0 * Zl[o2 * 18 + be] + w1 * Zl[o2 * 18 + 6 + be] + w2 * Zl[o2 * 18 + 12 + be];
