@@ -1,4 +1,4 @@
-"""Fused iteration time and the camera step's kernel time (torch profiler-free: events around 200 iterations) for BA_LIB."""
+"""Fused iteration time and the pass kernel's time for BA_LIB: ab_iter.py [points] [cameras]"""
 import importlib, os, sys, time, numpy as np
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '.'))
 if os.environ.get('BA_LIB'):
@@ -7,8 +7,9 @@ import torch
 ba = importlib.import_module('3d_reconstruction_amd')
 tag = os.path.basename(os.environ.get('BA_LIB', 'built'))
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-sc = ba.scenes.orbit_scene(N=N, K=2000, track_len=10, seed=0)
-sh = ba.engine.Shard(sc['i'], sc['j'], sc['uv'], N, 2000, sc['W'], sc['H'], 'cuda:0')
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
+sc = ba.scenes.orbit_scene(N=N, K=K, track_len=10, seed=0)
+sh = ba.engine.Shard(sc['i'], sc['j'], sc['uv'], N, K, sc['W'], sc['H'], 'cuda:0')
 sh.set_params(sc['X_0'], sc['C_0'], sc['Theta_0'], sc['phi_x_0'])
 fit = ba.SceneFit(sh, lr=1e-3, max_iters=5000, patience=100000, print_step=10 ** 9, printer=lambda *a: None)
 fit.timed_every = 8

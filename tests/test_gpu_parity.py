@@ -775,3 +775,18 @@ def test_random_scene_shapes_match_oracle(ba, seed):
         assert np.abs(cam[3 * K:6 * K].reshape(K, 3) - ref[2]).max() < 1e-8
         assert abs(cam[6 * K] - ref[3]) < 1e-10
         sh.close()
+
+
+@pytest.mark.parametrize('N,K,track', [(50, 3000, 400), (200, 5000, 1500), (30, 1500, 900)])
+def test_small_scenes_with_many_cameras(ba, N, K, track):
+    """Few points seen from thousands of cameras: scenes this small always take the tile form, whatever their
+    camera lists cost; five updates against the oracle."""
+    sc = ba.scenes.orbit_scene(N, K, track_len=track, seed=2)
+    ref = orc.fit_scene(sc['i'], sc['j'], sc['uv'], N, K, sc['W'], sc['H'], 1e-3, 6, sc['X_0'], sc['C_0'], sc['Theta_0'],
+                        sc['phi_x_0'])
+    sh = ba.engine.Shard(sc['i'], sc['j'], sc['uv'], N, K, sc['W'], sc['H'], DEV)
+    sh.set_params(sc['X_0'], sc['C_0'], sc['Theta_0'], sc['phi_x_0'])
+    fit = ba.SceneFit(sh, 1e-3, 6, printer=lambda *a: None).run()
+    assert rel_err(fit.energies(), ref[4]) < TOL
+    assert np.abs(sh.points_to_caller(sh.X).cpu().numpy() - ref[0]).max() < 1e-9
+    sh.close()
