@@ -82,95 +82,130 @@ __global__ void __launch_bounds__(256) k_block_profile(const double *__restrict_
     }
 }
 
+// 1 / x for x far from the ends of the exponent range: hardware estimate (relative error 5e-8, measured) and one
+// third-order correction step, three dependent instructions behind the estimate (relative error 1.1e-16)
+__device__ __forceinline__ double rcp_cubic(double x) {
+    const double r = __builtin_amdgcn_rcp(x);
+    const double e = fma(-x, r, 1.0);
+    return fma(r, fma(e, e, e), r);
+}
+
 // L_kk = chol(A_kk) in place and Linv = L_kk^-1 (64 x 64, row-major), one workgroup of four waves.
-// Factorisation: thread (row i = tid % 64, wave q = tid / 64) keeps L[i][q + 4u], u = 0..15, in
-// registers; the loop over the 64 columns is fully unrolled, column k reaches everybody through a
-// double-buffered 64-entry LDS vector (one barrier per column); what a column costs is the
-// dependent sqrt / divide, not the update.
-// Inverse: the four 16 x 16 diagonal blocks by substitution (16 lanes of each wave), then the
-// blocks below them level by level, X_ij = -X_ii (sum_m L_im X_mj), one thread per entry.
-// Entries above the diagonal are never used as inputs (they may hold anything, NaN included).
-constexpr int POTRF_LDS_DOUBLES = 2 * NB * (NB + 1) + 2 * NB + 16 * 16;
+//
+// What a column costs here is not arithmetic but the trip of the finished column from the wave that owns it to the
+// other three (LDS write, barrier, LDS read: about 440 cycles, measured) and the chain of dependent instructions from
+// the pivot to the next column.  So the kernel takes TWO columns per barrier, and keeps square roots and divisions off
+// the chain: the columns stay unscaled (a_ik as the elimination leaves it; L_ik = a_ik / sqrt(d_k) is formed once, at
+// the end), the update of a later entry is a_ij -= a_ik a_jk / d_k, the reciprocal of the second pivot of a pair comes
+// from the determinant of the 2 x 2 pivot block (d_k' = det / d_k), so that both reciprocals start at once.
+// The inverse rides along: the 64 rows of the identity go through the same column operations as the rows of A
+// (row i of Y = I L^-T, i.e. column i of the inverse), two more multiply-adds per entry and step instead of a
+// separate substitution phase (which took a third of the kernel before).
+// Thread (row i = tid % 64, wave q = tid / 64) keeps, of row i of A and of row i of Y, the columns
+// j(u) = 8 (u / 2) + 2 q + (u & 1), u = 0..15: pairs of neighbouring columns dealt out to the waves in turn.
+// Entries above the diagonal are never used as inputs (they may hold anything, NaN included): what is computed from
+// them stays above the diagonal.
+constexpr int POTRF_LDS_DOUBLES = 2 * NB * (NB + 1) + 2 * 2 * 2 * NB + 3 * NB;
 __global__ void __launch_bounds__(256) k_potrf64(double *__restrict__ A, int64_t ld, int64_t k0, double *__restrict__ Linv,
                                                  int *__restrict__ info) {
     extern __shared__ double sm[];
-    double(*Ls)[NB + 1] = (double(*)[NB + 1])sm;
-    double(*Xs)[NB + 1] = (double(*)[NB + 1])(sm + NB * (NB + 1));
-    double(*raw)[NB] = (double(*)[NB])(sm + 2 * NB * (NB + 1));
-    double(*Ts)[16] = (double(*)[16])(sm + 2 * NB * (NB + 1) + 2 * NB);
+    double(*Ls)[NB + 1] = (double(*)[NB + 1])sm;                      // the block on its way in and out
+    double(*Xs)[NB + 1] = (double(*)[NB + 1])(sm + NB * (NB + 1));    // the inverse on its way out
+    double2(*rawA)[NB] = (double2(*)[NB])(sm + 2 * NB * (NB + 1));    // [step & 1][row]: the step's two columns of A
+    double2(*rawY)[NB] = rawA + 2;                                    // ... and of Y
+    double *piv = (double *)(rawY + 2), *invs = piv + NB, *dsq = invs + NB;
     const int tid = threadIdx.x, i = tid & 63, q = tid >> 6;
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-        const int r = idx >> 6, c = idx & 63;
-        Ls[r][c] = A[(k0 + r) * ld + k0 + c];
-        Xs[r][c] = 0.0;
-    }
-    __syncthreads();
-    double reg[16];
+    {
+        double2 tmp[8];
+        const int r0 = tid >> 5, c0 = 2 * (tid & 31);
 #pragma unroll
-    for (int u = 0; u < 16; ++u) reg[u] = Ls[i][q + 4 * u];
-    int bad = 0;
+        for (int m = 0; m < 8; ++m) tmp[m] = *(const double2 *)(A + (k0 + r0 + 8 * m) * ld + k0 + c0);
 #pragma unroll
-    for (int k = 0; k < NB; ++k) {
-        constexpr int dummy = 0;
-        (void)dummy;
-        const int qk = k & 3, uk = k >> 2, buf = k & 1;
-        if (q == qk) raw[buf][i] = reg[uk];
-        __syncthreads();
-        const double dkk = raw[buf][k];
-        if (!(dkk > 0.0) && bad == 0) bad = k + 1;
-        // the column waits for this chain: reciprocal square root by Newton's iteration, then the square root
-        // from it with one correction step (sqrt followed by a division is five times as long)
-        const double inv = fast_rsqrt(dkk);
-        double d = dkk * inv;
-        d = fma(0.5 * inv, fma(-d, d, dkk), d);
-        const double ci = raw[buf][i] * inv;
-        if (q == qk) reg[uk] = (i == k) ? d : ci;
-#pragma unroll
-        for (int u = uk; u < 16; ++u) {
-            const int j = q + 4 * u;
-            const double cj = raw[buf][j] * inv;
-            const double v = reg[u] - ci * cj;      // L[i][j] -= L[i][k] L[j][k]
-            reg[u] = (j > k) ? v : reg[u];
+        for (int m = 0; m < 8; ++m) {
+            Ls[r0 + 8 * m][c0] = tmp[m].x;
+            Ls[r0 + 8 * m][c0 + 1] = tmp[m].y;
         }
     }
-    if (bad && tid == 0) atomicCAS(info, 0, (int)(k0 + bad));
     __syncthreads();
+    double reg[16], y[16];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) Ls[i][q + 4 * u] = (q + 4 * u <= i) ? reg[u] : 0.0;
-    __syncthreads();
-
-    // ---- inverse: diagonal 16 x 16 blocks, wave q takes block q, lane c < 16 column c
-    if ((tid & 63) < 16) {
-        const int c = tid & 63, o = 16 * q;
-        double li[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            double v = (r == c) ? 1.0 : 0.0;
-#pragma unroll
-            for (int m = 0; m < r; ++m) v -= Ls[o + r][o + m] * li[m];
-            li[r] = v / Ls[o + r][o + r];
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) Xs[o + r][o + c] = li[r];
+    for (int u = 0; u < 16; ++u) {
+        const int j = 8 * (u >> 1) + 2 * q + (u & 1);
+        reg[u] = Ls[i][j];
+        y[u] = (j == i) ? 1.0 : 0.0;
+    }
+    if (q == 0) {
+        rawA[0][i] = make_double2(reg[0], reg[1]);
+        rawY[0][i] = make_double2(y[0], y[1]);
     }
     __syncthreads();
-    // ---- blocks below the diagonal, by distance from it; thread -> entry (r, c) of the 16 x 16 block
-    const int r = tid >> 4, c = tid & 15;
-    for (int dist = 1; dist < 4; ++dist) {
-        for (int bi = dist; bi < 4; ++bi) {
-            const int bj = bi - dist;
-            double t = 0.0;
-            for (int m = 16 * bj; m < 16 * bi; ++m) t += Ls[16 * bi + r][m] * Xs[m][16 * bj + c];
-            Ts[r][c] = t;
-            __syncthreads();
-            double x = 0.0;
 #pragma unroll
-            for (int m = 0; m < 16; ++m) x -= Xs[16 * bi + r][16 * bi + m] * Ts[m][c];
-            __syncthreads();
-            Xs[16 * bi + r][16 * bj + c] = x;
+    for (int s = 0; s < NB / 2; ++s) {
+        // columns k, k + 1, owned by wave qs in its registers u0, u0 + 1; the next pair belongs to wave qn
+        const int k = 2 * s, qs = s & 3, u0 = 2 * (s >> 2), buf = s & 1;
+        const int qn = (s + 1) & 3, un = 2 * ((s + 1) >> 2);
+        // every read of the step goes out right behind the barrier (left to itself the compiler sinks them to their
+        // uses, one LDS latency after the other)
+        const double2 P = rawA[buf][k], Q = rawA[buf][k + 1];       // pivot block: P.x = d_k, Q = (a_k+1,k , a_k+1,k+1)
+        const double2 Ri = rawA[buf][i], Yi = rawY[buf][i];
+        double2 Rj[16];
+#pragma unroll
+        for (int u = u0; u < 16; ++u) Rj[u] = rawA[buf][8 * (u >> 1) + 2 * q + (u & 1)];
+        __builtin_amdgcn_sched_barrier(0);
+        const double det = fma(P.x, Q.y, -(Q.x * Q.x));
+        const double r0 = rcp_cubic(P.x);           // 1 / d_k
+        const double r1 = P.x * rcp_cubic(det);     // 1 / d_k+1
+        const double t = Q.x * r0;
+        const double ai1 = fma(-Ri.x, t, Ri.y), yi1 = fma(-Yi.x, t, Yi.y);     // column k + 1 after column k
+        const double w0 = Ri.x * r0, w1 = ai1 * r1, v0 = Yi.x * r0, v1 = yi1 * r1;
+        const bool behind = q > qs, own = q == qs;
+#pragma unroll
+        for (int u = u0; u < 16; ++u) {
+            const double aj1 = fma(-Rj[u].x, t, Rj[u].y);
+            const double rn = fma(-w1, aj1, fma(-w0, Rj[u].x, reg[u]));
+            const double yn = fma(-v1, aj1, fma(-v0, Rj[u].x, y[u]));
+            if (u >= u0 + 2) {
+                reg[u] = rn;
+                y[u] = yn;
+            } else if (u == u0) {       // registers of the current pair: columns behind the step's in the waves after qs
+                reg[u] = behind ? rn : reg[u];
+                y[u] = behind ? yn : y[u];
+            } else {                    // the finished column k + 1 stays in its owner's registers, unscaled
+                reg[u] = behind ? rn : (own ? ai1 : reg[u]);
+                y[u] = behind ? yn : (own ? yi1 : y[u]);
+            }
+            if (s + 1 < NB / 2 && u == un + 1 && q == qn) {     // the next pair leaves as soon as it is complete
+                rawA[buf ^ 1][i] = make_double2(reg[un], reg[un + 1]);
+                rawY[buf ^ 1][i] = make_double2(y[un], y[un + 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         __syncthreads();
     }
+    // pivots = the unscaled diagonal entries; their square roots and reciprocal square roots, once
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+        if (8 * (u >> 1) + 2 * q + (u & 1) == i) piv[i] = reg[u];
+    __syncthreads();
+    if (tid < NB) {
+        const double p = piv[tid];
+        const double inv = fast_rsqrt(p);
+        double d = p * inv;
+        d = fma(0.5 * inv, fma(-d, d, p), d);
+        invs[tid] = inv;
+        dsq[tid] = d;
+        const unsigned long long bad = __ballot(!(p > 0.0));
+        if (bad && tid == 0) atomicCAS(info, 0, (int)(k0 + __ffsll((long long)bad)));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int j = 8 * (u >> 1) + 2 * q + (u & 1);
+        const double sc = invs[j];
+        Ls[i][j] = (j < i) ? reg[u] * sc : (j == i ? dsq[i] : 0.0);
+        Xs[j][i] = y[u] * sc;
+    }
+    __syncthreads();
     for (int idx = tid; idx < NB * NB; idx += 256) {
         const int rr = idx >> 6, cc = idx & 63;
         if (cc <= rr) A[(k0 + rr) * ld + k0 + cc] = Ls[rr][cc];
@@ -559,11 +594,12 @@ __global__ void __launch_bounds__(256, 2) k_syrk_trailing(double *__restrict__ A
 // The forward solve L y = b rides along with the factorisation: with b^T stored as the last (padding) row of the
 // matrix, the row that the factorisation leaves there is y^T (the row's entries solve  row . L^T = b^T), computed by
 // the panel and update kernels like any other row.  Only the row's own pivot is meaningless: nothing depends on
-// it, and a diagonal entry of 1e300 keeps it positive and finite whatever |y|^2 is taken away from it.  That
+// it, and a diagonal entry of 1e200 keeps it positive and finite whatever |y|^2 is taken away from it (and its product
+// with the pivot before it, which the diagonal-block kernel forms, finite as well).  That
 // replaces ld / 64 dependent launches of k_solve_step.
 __global__ void k_rhs_into_row(double *__restrict__ A, int64_t ld, int64_t n, const double *__restrict__ rhs) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < ld) A[(ld - 1) * ld + c] = c < n ? rhs[c] : (c == ld - 1 ? 1e300 : 0.0);
+    if (c < ld) A[(ld - 1) * ld + c] = c < n ? rhs[c] : (c == ld - 1 ? 1e200 : 0.0);
 }
 
 __global__ void k_row_to_rhs(const double *__restrict__ A, int64_t ld, int64_t n, double *__restrict__ rhs) {
