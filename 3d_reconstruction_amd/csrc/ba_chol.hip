@@ -48,10 +48,20 @@ constexpr int LDT = TS + 4;    // row pitch of the staged (column-major) panel c
 
 static int cdiv_c(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
-// logical index of a row block / tile inside a launch -> physical index: the indices from gap_start on skip gap_len
-struct RowMap {
-    int gap_start = 0x7fffffff, gap_len = 0;
-    __host__ __device__ int64_t operator()(int64_t logical) const { return logical >= gap_start ? logical + gap_len : logical; }
+// Which rows (and, for the update kernel, columns) a launch covers: logical unit l (a 64-row block or a 128-row tile,
+// counted from the launch's first row) -> row offset from that first row.  Three runs of consecutive units:
+//   band    l < n1:            unit l of the band that follows the panel; a chain's band lies chain_rows rows (and
+//                              columns) behind the band of the chain before it (see "Independent chains" above)
+//   window  l < n1 + n2:       the separator rows on either side of the chain, win_rows + win_step max(chain - 1, 0)
+//   tail    the rest:          the dense border, from tail_rows on
+struct RowSel {
+    int n1 = 0x7fffffff, n2 = 0;
+    int64_t chain_rows = 0, win_rows = 0, win_step = 0, tail_rows = 0;
+    __host__ __device__ int64_t operator()(int64_t l, int unit_rows, int chain) const {
+        if (l < n1) return unit_rows * l + chain * chain_rows;
+        if (l < (int64_t)n1 + n2) return win_rows + win_step * (chain > 0 ? chain - 1 : 0) + unit_rows * (l - n1);
+        return tail_rows + unit_rows * (l - n1 - n2);
+    }
 };
 
 // first[ib] (preset to ib) = the first 64-column block of block row ib of the lower triangle that holds a nonzero
@@ -107,8 +117,10 @@ __device__ __forceinline__ double rcp_cubic(double x) {
 // them stays above the diagonal.
 constexpr int POTRF_LDS_DOUBLES = 2 * NB * (NB + 1) + 2 * 2 * 2 * NB + 3 * NB;
 __global__ void __launch_bounds__(256) k_potrf64(double *__restrict__ A, int64_t ld, int64_t k0, double *__restrict__ Linv,
-                                                 int *__restrict__ info) {
+                                                 int *__restrict__ info, int64_t chain_rows) {
     extern __shared__ double sm[];
+    k0 += blockIdx.y * chain_rows;                      // workgroup y: the same block of chain y
+    Linv += blockIdx.y * chain_rows * NB;
     double(*Ls)[NB + 1] = (double(*)[NB + 1])sm;                      // the block on its way in and out
     double(*Xs)[NB + 1] = (double(*)[NB + 1])(sm + NB * (NB + 1));    // the inverse on its way out
     double2(*rawA)[NB] = (double2(*)[NB])(sm + 2 * NB * (NB + 1));    // [step & 1][row]: the step's two columns of A
@@ -342,10 +354,11 @@ __device__ __forceinline__ void stage_block(const double *__restrict__ g, int64_
 // Inside the diagonal block of a panel (64 nbk columns from p0), after potrf64 of its block kb: the blocks below it
 // times the inverse, A_jk <- A_jk L_kk^-T.  Workgroup = block row kb + 1 + blockIdx.x, wave = 16-row strip.
 __global__ void __launch_bounds__(256) k_diag_trsm(double *__restrict__ A, int64_t ld, int64_t p0, int kb,
-                                                   const double *__restrict__ Li) {
+                                                   const double *__restrict__ Li, int64_t chain_rows) {
     extern __shared__ double sm[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int64_t k0 = p0 + NB * kb;
+    const int64_t k0 = p0 + NB * kb + blockIdx.y * chain_rows;
+    Li += blockIdx.y * chain_rows * NB;
     double *strip = A + (k0 + NB * (1 + blockIdx.x) + 16 * w) * ld + k0;
     double *patch = sm + NB * LP + w * 16 * TP;
     double t[16], b[16], acc[16];
@@ -364,10 +377,10 @@ __global__ void __launch_bounds__(256) k_diag_trsm(double *__restrict__ A, int64
 // (Both steps and potrf64 as phases of one workgroup - one launch per panel for its whole diagonal block - were
 // measured: potrf64 runs at 37 us there instead of 26 us, eight waves walking through its 64 barriers, and the
 // strips of a phase queue up on the one CU: 231 us per panel against 104 us of potrf64 plus 14 us per step here.)
-__global__ void __launch_bounds__(256) k_diag_syrk(double *__restrict__ A, int64_t ld, int64_t p0, int kb) {
+__global__ void __launch_bounds__(256) k_diag_syrk(double *__restrict__ A, int64_t ld, int64_t p0, int kb, int64_t chain_rows) {
     extern __shared__ double sm[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int64_t k0 = p0 + NB * kb;
+    const int64_t k0 = p0 + NB * kb + blockIdx.y * chain_rows;
     const int pair = blockIdx.x;
     const int ti = pair < 1 ? 0 : (pair < 3 ? 1 : 2), tj = pair - ti * (ti + 1) / 2;
     double *strip = A + (k0 + NB * (1 + ti) + 16 * w) * ld + k0 + NB * (1 + tj);
@@ -392,11 +405,14 @@ __global__ void __launch_bounds__(256) k_diag_syrk(double *__restrict__ A, int64
 // LDS buffers, the next one loaded while the matrix cores work on the current one.
 template <int NBK>
 __global__ void __launch_bounds__(256) k_panel_rows(double *__restrict__ A, int64_t ld, int64_t p0,
-                                                    const double *__restrict__ Linv, RowMap map) {
+                                                    const double *__restrict__ Linv, RowSel sel) {
     extern __shared__ double sm[];
     constexpr int NOPS = NBK * (NBK + 1) / 2;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    double *rows = A + (p0 + NB * NBK + (int64_t)NB * map(blockIdx.x) + 16 * w) * ld + p0;
+    const int chain = blockIdx.y;
+    double *rows = A + (p0 + NB * NBK + sel(blockIdx.x, NB, chain) + 16 * w) * ld + p0 + chain * sel.chain_rows;
+    p0 += chain * sel.chain_rows;           // from here on: the panel's diagonal block, rows and columns of the chain
+    Linv += chain * sel.chain_rows * NB;
     double *patch = sm + 2 * NB * LP + w * 16 * TP;
     double S[NBK][16];
 #pragma unroll
@@ -465,7 +481,7 @@ __global__ void __launch_bounds__(256) k_panel_rows(double *__restrict__ A, int6
 // row per lane makes every load instruction touch 64 cache lines and leaves the kernel bound by the
 // address pipeline of the vector memory unit.
 __global__ void __launch_bounds__(256, 2) k_syrk_trailing(double *__restrict__ A, int64_t ld, int64_t k0, int kw, int64_t c0,
-                                                          int64_t nct, RowMap map) {
+                                                          int64_t nct, RowSel sel) {
     extern __shared__ double smem[];
     double(*As)[LDT] = (double(*)[LDT])smem;
     double(*Bs)[LDT] = (double(*)[LDT])(smem + KC * LDT);
@@ -483,12 +499,14 @@ __global__ void __launch_bounds__(256, 2) k_syrk_trailing(double *__restrict__ A
         bi = nct + (t - tri) / nct;
         bj = (t - tri) % nct;
     }
-    const int64_t i0 = c0 + TS * map(bi), j0 = c0 + TS * map(bj);     // tiles counted without the rows left out
+    const int chain = blockIdx.z;
+    const int64_t i0 = c0 + sel(bi, TS, chain), j0 = c0 + sel(bj, TS, chain);     // tiles counted without the rows left out
     // With few tiles (a banded matrix) the panel's columns are split over gridDim.y workgroups per tile, kw columns
     // each, which add their parts to C with atomics: one workgroup walking through 1024 columns alone is 200 us of
-    // latency with the rest of the chip idle.
-    k0 += (int64_t)blockIdx.y * kw;
-    const bool shared_tile = gridDim.y > 1;
+    // latency with the rest of the chip idle.  Tiles in the columns of the separators and of the border receive the
+    // updates of several chains at once: atomics as well.
+    k0 += (int64_t)blockIdx.y * kw + chain * sel.chain_rows;
+    const bool shared_tile = gridDim.y > 1 || (gridDim.z > 1 && bj >= sel.n1);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
     const int r16 = lane & 15, k4 = lane >> 4, j4 = lane & 3;
     const bool active = !(bi == bj && wc > wr);     // the sub-tile above the diagonal is never used
@@ -597,14 +615,53 @@ __global__ void __launch_bounds__(256, 2) k_syrk_trailing(double *__restrict__ A
 // it, and a diagonal entry of 1e200 keeps it positive and finite whatever |y|^2 is taken away from it (and its product
 // with the pivot before it, which the diagonal-block kernel forms, finite as well).  That
 // replaces ld / 64 dependent launches of k_solve_step.
-__global__ void k_rhs_into_row(double *__restrict__ A, int64_t ld, int64_t n, const double *__restrict__ rhs) {
+// (newpos: the position of every 64-block in the order the factorisation works in, or null)
+__global__ void k_rhs_into_row(double *__restrict__ A, int64_t ld, int64_t n, const double *__restrict__ rhs,
+                               const int *__restrict__ newpos) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < ld) A[(ld - 1) * ld + c] = c < n ? rhs[c] : (c == ld - 1 ? 1e200 : 0.0);
+    if (c >= ld) return;
+    const int64_t cn = newpos ? (int64_t)newpos[c / NB] * NB + c % NB : c;
+    A[(ld - 1) * ld + cn] = c < n ? rhs[c] : (c == ld - 1 ? 1e200 : 0.0);
 }
 
 __global__ void k_row_to_rhs(const double *__restrict__ A, int64_t ld, int64_t n, double *__restrict__ rhs) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c < ld) rhs[c] = c < n ? A[(ld - 1) * ld + c] : 0.0;
+}
+
+// solution in the order the factorisation worked in -> the caller's order
+__global__ void k_solution_back(const double *__restrict__ x, int64_t ld, const int *__restrict__ newpos, double *__restrict__ out) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < ld) out[c] = x[(int64_t)newpos[c / NB] * NB + c % NB];
+}
+
+// Symmetric permutation of the 64-blocks of the lower triangle, in place, by way of a copy of the occupied blocks:
+// workgroup b takes block (from[b].x, from[b].y) to T (mode 0), clears it (mode 1), or stores T[b] as block
+// (to[b].x, to[b].y) - transposed when to[b].z says that the block crossed the diagonal (mode 2).
+__global__ void __launch_bounds__(256) k_move_blocks(double *__restrict__ A, int64_t ld, const int4 *__restrict__ moves,
+                                                     double *__restrict__ T, int mode) {
+    __shared__ double tile[NB][NB + 1];
+    const int4 m = moves[blockIdx.x];
+    const int tid = threadIdx.x;
+    double *t = T + (int64_t)blockIdx.x * NB * NB;
+    if (mode == 0) {
+        const double *src = A + (int64_t)m.x * NB * ld + (int64_t)m.y * NB;
+        for (int idx = tid; idx < NB * NB; idx += 256) t[idx] = src[(int64_t)(idx >> 6) * ld + (idx & 63)];
+    } else if (mode == 1) {
+        double *dst = A + (int64_t)m.x * NB * ld + (int64_t)m.y * NB;
+        for (int idx = tid; idx < NB * NB; idx += 256) dst[(int64_t)(idx >> 6) * ld + (idx & 63)] = 0.0;
+    } else {
+        double *dst = A + (int64_t)m.z * NB * ld + (int64_t)m.w * NB;
+        const bool flip = m.z < 0;
+        if (!flip) {
+            for (int idx = tid; idx < NB * NB; idx += 256) dst[(int64_t)(idx >> 6) * ld + (idx & 63)] = t[idx];
+        } else {
+            dst = A + (int64_t)(-m.z - 1) * NB * ld + (int64_t)m.w * NB;
+            for (int idx = tid; idx < NB * NB; idx += 256) tile[idx >> 6][idx & 63] = t[idx];
+            __syncthreads();
+            for (int idx = tid; idx < NB * NB; idx += 256) dst[(int64_t)(idx >> 6) * ld + (idx & 63)] = tile[idx & 63][idx >> 6];
+        }
+    }
 }
 
 // One block step of a triangular solve with the stored inverses of the diagonal blocks.
@@ -615,9 +672,13 @@ __global__ void k_row_to_rhs(const double *__restrict__ A, int64_t ld, int64_t n
 // transpose: rows before i_begin are left out (the block row k has no entries there).
 __global__ void __launch_bounds__(256) k_solve_step(const double *__restrict__ A, int64_t ld, int64_t k0,
                                                     const double *__restrict__ Linv, double *__restrict__ b,
-                                                    double *__restrict__ out, int transpose, int64_t i_begin) {
+                                                    double *__restrict__ out, int transpose, int64_t i_begin,
+                                                    int64_t chain_rows) {
     __shared__ double bk[NB], yk[NB], part[4][NB];
     const int tid = threadIdx.x;
+    k0 += blockIdx.y * chain_rows;
+    i_begin += blockIdx.y * chain_rows;
+    Linv += blockIdx.y * chain_rows * NB;
     if (tid < NB) bk[tid] = b[k0 + tid];
     __syncthreads();
     {
@@ -701,8 +762,9 @@ int ba_cholesky_solve(int64_t n, int64_t ld, double *S, double *rhs, int *h_info
     int64_t border = (n - 1) / NB;
     std::vector<int> reach((size_t)nb), row_first((size_t)nb, 0);     // row_first[k]: first occupied column block of block row k
     for (int64_t k = 0; k < nb; ++k) reach[k] = (int)(nb - 1);
+    std::vector<int> first;
     if (e == hipSuccess && !getenv("BA_CHOL_DENSE") && border > 1) {
-        std::vector<int> first((size_t)nb);
+        first.resize((size_t)nb);
         for (int64_t k = 0; k < nb; ++k) first[k] = (int)k;
         int *d_first = nullptr;
         e = hipMalloc(&d_first, sizeof(int) * nb);
@@ -724,75 +786,173 @@ int ba_cholesky_solve(int64_t n, int64_t ld, double *S, double *rhs, int *h_info
             std::nth_element(width.begin(), width.begin() + border / 2, width.end());
             const int typical = width[border / 2];
             while (border > 2 && (border - 1) - first[border - 1] > 4 * typical + 4) --border;
-            std::vector<int> last((size_t)nb, -1);      // last[c]: the last block row (before the border) that starts at column block c
-            for (int64_t ib = 0; ib < border; ++ib) last[first[ib]] = (int)ib;
-            int far = 0;
-            for (int64_t k = 0; k < nb; ++k) {
-                far = std::max(far, std::max(last[k], (int)k));
-                reach[k] = far;
-            }
+        } else {
+            first.clear();
         }
     }
-    // block rows / tiles a launch covers when its panel ends at column block k_last and its rows start at block
-    // (tile) `start`, in units of `unit` blocks: those up to reach[k_last], then the border; returns their number
-    auto row_map = [&](int64_t k_last, int64_t start, int unit, RowMap &map) {
-        const int64_t total = cdiv_c(nb, unit), border_u = border / unit, reach_u = reach[k_last] / unit;
-        map = RowMap();
-        if (start >= border_u || reach_u + 1 >= border_u) return total - start;
-        const int64_t band = std::max<int64_t>(reach_u - start + 1, 0);
-        map.gap_start = (int)band;
-        map.gap_len = (int)(border_u - (start + band));
+
+    // ---- independent chains (see the top of the file): P chains of s blocks, a separator of bw blocks behind each,
+    // what is left of the band, the border.  Chosen to make the number of dependent block steps, s + (blocks
+    // behind the chains), small.
+    int P = 1;
+    int64_t s_blocks = 0, bw = 1;
+    if (!first.empty() && ride_along && !getenv("BA_CHOL_NO_CHAINS")) {
+        for (int64_t ib = 0; ib < border; ++ib) bw = std::max<int64_t>(bw, ib - first[ib]);
+        int64_t best = nb - nb / 3;       // worth it from a third fewer steps on
+        for (int cand = 2; cand <= 96; ++cand) {
+            int64_t sc = (border - (int64_t)cand * bw) / cand;
+            sc -= sc & 1;       // chains start on even blocks: the 128-row tiles of the update never straddle two chains
+            if (sc < 4 * bw || sc < 4) break;
+            const int64_t steps = sc + (nb - cand * sc);
+            if (steps < best) best = steps, P = cand, s_blocks = sc;
+        }
+    }
+    const int64_t S_rows = s_blocks * NB;                    // rows (and columns) of a chain
+    const int64_t B0 = (int64_t)P * s_blocks;                // first block behind the chains (P > 1)
+    const int64_t T0 = B0 + (int64_t)P * bw;                 // first block behind the separators
+    int *d_newpos = nullptr;
+    std::vector<int> chain_reach, chain_first;               // per block of a chain: reach and first column, over all chains
+    if (P > 1 && e == hipSuccess) {
+        std::vector<int> newpos((size_t)nb);
+        for (int64_t ib = 0; ib < nb; ++ib) {
+            const int64_t c = ib / (s_blocks + bw), l = ib % (s_blocks + bw);
+            if (c >= P) newpos[ib] = (int)ib;                                   // rest of the band, border: where they were
+            else if (l < s_blocks) newpos[ib] = (int)(c * s_blocks + l);
+            else newpos[ib] = (int)(B0 + c * bw + (l - s_blocks));
+        }
+        // the occupied blocks (from the profile), gathered, cleared, stored at their new places
+        std::vector<int4> moves;
+        for (int64_t ib = 0; ib < nb; ++ib)
+            for (int64_t jb = first[ib]; jb <= ib; ++jb) {
+                const int a = newpos[ib], bcol = newpos[jb];
+                moves.push_back(a >= bcol ? make_int4((int)ib, (int)jb, a, bcol) : make_int4((int)ib, (int)jb, -bcol - 1, a));
+            }
+        int4 *d_moves = nullptr;
+        double *T = nullptr;
+        e = hipMalloc(&d_moves, sizeof(int4) * moves.size());
+        if (e == hipSuccess) e = hipMalloc(&T, sizeof(double) * NB * NB * moves.size());
+        if (e == hipSuccess) e = hipMalloc(&d_newpos, sizeof(int) * nb);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_moves, moves.data(), sizeof(int4) * moves.size(), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_newpos, newpos.data(), sizeof(int) * nb, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) {
+            for (int mode = 0; mode < 3; ++mode)
+                hipLaunchKernelGGL(k_move_blocks, dim3((unsigned)moves.size()), dim3(256), 0, st, S, ld, d_moves, T, mode);
+            e = hipStreamSynchronize(st);       // the host vectors and T go out of use here
+        }
+        hipFree(d_moves);
+        hipFree(T);
+        // structure of a chain, over all chains: the first column block of local row l and from it the reach
+        chain_first.assign((size_t)s_blocks, 0x7fffffff);
+        for (int c = 0; c < P; ++c)
+            for (int64_t l = 0; l < s_blocks; ++l) {
+                const int64_t old_start = c * (s_blocks + bw);
+                chain_first[l] = std::min(chain_first[l], (int)std::max<int64_t>(first[old_start + l] - old_start, 0));
+            }
+        std::vector<int> last((size_t)s_blocks, -1);
+        for (int64_t l = 0; l < s_blocks; ++l) last[chain_first[l]] = (int)l;
+        chain_reach.resize((size_t)s_blocks);
+        int far = 0;
+        for (int64_t k = 0; k < s_blocks; ++k) {
+            far = std::max(far, std::max(last[k], (int)k));
+            chain_reach[k] = far;
+        }
+    } else if (!first.empty() && e == hipSuccess) {
+        std::vector<int> last((size_t)nb, -1);      // last[c]: the last block row (before the border) that starts at column block c
+        for (int64_t ib = 0; ib < border; ++ib) last[first[ib]] = (int)ib;
+        int far = 0;
+        for (int64_t k = 0; k < nb; ++k) {
+            far = std::max(far, std::max(last[k], (int)k));
+            reach[k] = far;
+        }
+    }
+
+    // Rows a launch covers when its panel ends at column block k_last and its rows start at block `start`, in units of
+    // `unit` blocks; returns their number.
+    //   one chain (P == 1): those up to reach[k_last], then the border
+    //   chains: blocks are counted inside the chain; those up to the chain's reach, the separators on either side
+    //           of the chain, everything behind the separators
+    //   behind the chains (dense == true): all rows
+    auto select_rows = [&](int64_t k_last, int64_t start, int unit, bool chains, bool dense, RowSel &sel) -> int64_t {
+        sel = RowSel();
+        if (dense) return cdiv_c(nb - start, unit);
+        const int64_t unit_rows = (int64_t)unit * NB;
+        if (chains) {
+            const int64_t band_end = std::min<int64_t>(chain_reach[k_last] + 1, s_blocks);     // blocks of the chain kept: [start, band_end)
+            const int64_t band = std::max<int64_t>(cdiv_c(std::max<int64_t>(band_end - start, 0), unit), 0);
+            sel.n1 = (int)band;
+            sel.n2 = (int)cdiv_c(2 * bw, unit);
+            sel.chain_rows = S_rows;
+            sel.win_rows = (B0 - start) * NB;
+            sel.win_step = bw * NB;
+            sel.tail_rows = (T0 - start) * NB;
+            return band + sel.n2 + cdiv_c(nb - T0, unit);
+        }
+        const int64_t total = cdiv_c(nb, unit), border_u = border / unit, reach_u = reach[k_last] / unit, start_u = start / unit;
+        if (start_u >= border_u || reach_u + 1 >= border_u) return total - start_u;
+        const int64_t band = std::max<int64_t>(reach_u - start_u + 1, 0);
+        sel.n1 = (int)band;
+        sel.tail_rows = (border_u - start_u) * unit_rows;
         return band + (total - border_u);
     };
     if (e == hipSuccess) {
-        if (ride_along) hipLaunchKernelGGL(k_rhs_into_row, dim3(cdiv_c(ld, 256)), dim3(256), 0, st, S, ld, n, rhs);
-        // tiles of the region C[c0.., c0 .. c_end): lower triangle of the first tile columns, whole rows below
-        auto trailing = [&](int64_t k_first, int64_t kw, int64_t c0, int64_t c_end) {
-            if (c0 >= ld || c_end <= c0) return;
-            RowMap map;
-            const int64_t nt = row_map((k_first + kw - 1) / NB, c0 / TS, TS / NB, map);     // tile rows, the left-out ones not counted
-            // tile columns: those of the rows kept whose physical column lies before c_end
-            const int64_t c_end_t = cdiv_c(c_end - c0, TS);
-            int64_t nct = 0;
-            while (nct < nt && map(nct) < c_end_t) ++nct;
-            if (nct == 0) return;
-            const int64_t tiles = nct * (nct + 1) / 2 + (nt - nct) * nct;
-            int split = 1;      // workgroups per tile: as long as the launch stays within one round of the chip
-            while (tiles * split * 2 <= 256 && kw % (split * 2 * NB) == 0) split *= 2;
-            hipLaunchKernelGGL(k_syrk_trailing, dim3((unsigned)tiles, (unsigned)split), dim3(256), lds_trailing, st, S, ld,
-                               k_first, (int)(kw / split), c0, nct, map);
-        };
-        for (int64_t o0 = 0; o0 < ld; o0 += OB) {
-            const int64_t o_end = (ld - o0 < OB) ? ld : o0 + OB;
-            for (int64_t p0 = o0; p0 < o_end; p0 += PB) {
-                const int64_t pw = (o_end - p0 < PB) ? o_end - p0 : PB;
-                {
+        if (ride_along) hipLaunchKernelGGL(k_rhs_into_row, dim3(cdiv_c(ld, 256)), dim3(256), 0, st, S, ld, n, rhs, d_newpos);
+        // Factorisation of the columns [begin, end) - of every chain at once when n_chains > 1 (begin, end inside the
+        // chain then) - and update of everything behind them.
+        auto factor = [&](int64_t begin, int64_t end, int n_chains, bool dense) {
+            const bool chains = n_chains > 1;
+            const int64_t chain_rows = chains ? S_rows : 0;
+            // tiles of the region C[c0.., c0 .. c_end): lower triangle of the first tile columns, whole rows below
+            auto trailing = [&](int64_t k_first, int64_t kw, int64_t c0, int64_t c_end) {
+                if (c0 >= ld || c_end <= c0) return;
+                RowSel sel;
+                const int64_t nt = select_rows((k_first + kw - 1) / NB, c0 / NB, TS / NB, chains, dense, sel);   // tile rows kept
+                int64_t nct = 0;        // tile columns: those of the rows kept that lie before c_end
+                while (nct < nt && sel(nct, TS, 0) < c_end - c0) ++nct;
+                if (nct == 0) return;
+                const int64_t tiles = nct * (nct + 1) / 2 + (nt - nct) * nct;
+                int split = 1;      // workgroups per tile: as long as the launch stays within one round of the chip
+                while (tiles * n_chains * split * 2 <= 256 && kw % (split * 2 * NB) == 0) split *= 2;
+                hipLaunchKernelGGL(k_syrk_trailing, dim3((unsigned)tiles, (unsigned)split, (unsigned)n_chains), dim3(256),
+                                   lds_trailing, st, S, ld, k_first, (int)(kw / split), c0, nct, sel);
+            };
+            for (int64_t o0 = begin; o0 < end; o0 += OB) {
+                const int64_t o_end = (end - o0 < OB) ? end : o0 + OB;
+                for (int64_t p0 = o0; p0 < o_end; p0 += PB) {
+                    const int64_t pw = (o_end - p0 < PB) ? o_end - p0 : PB;
                     const int nbk = (int)(pw / NB);
                     double *Li = Linv + (p0 / NB) * NB * NB;
                     for (int kb = 0; kb < nbk; ++kb) {
-                        hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(256), sizeof(double) * POTRF_LDS_DOUBLES, st, S, ld,
-                                           p0 + NB * kb, Li + (int64_t)kb * NB * NB, info);
+                        hipLaunchKernelGGL(k_potrf64, dim3(1, n_chains), dim3(256), sizeof(double) * POTRF_LDS_DOUBLES, st, S, ld,
+                                           p0 + NB * kb, Li + (int64_t)kb * NB * NB, info, chain_rows);
                         const int below = nbk - 1 - kb;
                         if (below > 0) {
-                            hipLaunchKernelGGL(k_diag_trsm, dim3(below), dim3(256), lds_diag, st, S, ld, p0, kb,
-                                               Li + (int64_t)kb * NB * NB);
-                            hipLaunchKernelGGL(k_diag_syrk, dim3(below * (below + 1) / 2), dim3(256), lds_diag, st, S, ld, p0, kb);
+                            hipLaunchKernelGGL(k_diag_trsm, dim3(below, n_chains), dim3(256), lds_diag, st, S, ld, p0, kb,
+                                               Li + (int64_t)kb * NB * NB, chain_rows);
+                            hipLaunchKernelGGL(k_diag_syrk, dim3(below * (below + 1) / 2, n_chains), dim3(256), lds_diag, st, S, ld,
+                                               p0, kb, chain_rows);
                         }
                     }
                     if (p0 + pw < ld) {
-                        RowMap map;
-                        const int slabs = (int)row_map((p0 + pw - 1) / NB, (p0 + pw) / NB, 1, map);
-                        if (nbk == 4) hipLaunchKernelGGL(k_panel_rows<4>, dim3(slabs), dim3(256), lds_rows, st, S, ld, p0, Li, map);
-                        else if (nbk == 3) hipLaunchKernelGGL(k_panel_rows<3>, dim3(slabs), dim3(256), lds_rows, st, S, ld, p0, Li, map);
-                        else if (nbk == 2) hipLaunchKernelGGL(k_panel_rows<2>, dim3(slabs), dim3(256), lds_rows, st, S, ld, p0, Li, map);
-                        else hipLaunchKernelGGL(k_panel_rows<1>, dim3(slabs), dim3(256), lds_rows, st, S, ld, p0, Li, map);
+                        RowSel sel;
+                        const int slabs = (int)select_rows((p0 + pw - 1) / NB, (p0 + pw) / NB, 1, chains, dense, sel);
+                        const dim3 grid(slabs, n_chains);
+                        if (nbk == 4) hipLaunchKernelGGL(k_panel_rows<4>, grid, dim3(256), lds_rows, st, S, ld, p0, Li, sel);
+                        else if (nbk == 3) hipLaunchKernelGGL(k_panel_rows<3>, grid, dim3(256), lds_rows, st, S, ld, p0, Li, sel);
+                        else if (nbk == 2) hipLaunchKernelGGL(k_panel_rows<2>, grid, dim3(256), lds_rows, st, S, ld, p0, Li, sel);
+                        else hipLaunchKernelGGL(k_panel_rows<1>, grid, dim3(256), lds_rows, st, S, ld, p0, Li, sel);
                     }
+                    // inside the outer panel: only its remaining columns see this 256-wide panel now
+                    trailing(p0, pw, p0 + pw, o_end);
                 }
-                // inside the outer panel: only its remaining columns see this 256-wide panel now
-                trailing(p0, pw, p0 + pw, o_end);
+                // behind the outer panel: one update with all its columns as the inner dimension
+                trailing(o0, o_end - o0, o_end, 2 * ld);
             }
-            // behind the outer panel: one update with all its columns as the inner dimension
-            trailing(o0, o_end - o0, o_end, ld);
+        };
+        if (P > 1) {
+            factor(0, S_rows, P, false);            // the chains, side by side
+            factor(B0 * NB, ld, 1, true);           // separators, rest of the band, border: dense
+        } else {
+            factor(0, ld, 1, false);
         }
         // L y = b (unless it rode along), then L^T x = y; the result of every block step lands in tmp
         if (ride_along) {
@@ -800,15 +960,27 @@ int ba_cholesky_solve(int64_t n, int64_t ld, double *S, double *rhs, int *h_info
         } else {
             for (int64_t k = 0; k < nb; ++k)
                 hipLaunchKernelGGL(k_solve_step, dim3(k + 1 < nb ? cdiv_c(ld - (k + 1) * NB, 256) : 1), dim3(256), 0, st, S,
-                                   ld, k * NB, Linv + k * NB * NB, rhs, tmp, 0, (int64_t)0);
+                                   ld, k * NB, Linv + k * NB * NB, rhs, tmp, 0, (int64_t)0, (int64_t)0);
             e = hipMemcpyAsync(rhs, tmp, sizeof(double) * ld, hipMemcpyDeviceToDevice, st);
         }
-        for (int64_t k = nb - 1; k >= 0; --k) {
-            const int64_t i_begin = (int64_t)row_first[k] * NB;     // L has nothing left of the row's first entry
-            hipLaunchKernelGGL(k_solve_step, dim3(k * NB > i_begin ? cdiv_c(k * NB - i_begin, 256) : 1), dim3(256), 0, st, S, ld,
-                               k * NB, Linv + k * NB * NB, rhs, tmp, 1, i_begin);
+        if (P > 1) {
+            for (int64_t k = nb - 1; k >= B0; --k)      // behind the chains: rows with entries in every chain
+                hipLaunchKernelGGL(k_solve_step, dim3(cdiv_c(k * NB, 256)), dim3(256), 0, st, S, ld, k * NB, Linv + k * NB * NB,
+                                   rhs, tmp, 1, (int64_t)0, (int64_t)0);
+            for (int64_t k = s_blocks - 1; k >= 0; --k) {       // block k of every chain
+                const int64_t i_begin = (int64_t)chain_first[k] * NB;
+                hipLaunchKernelGGL(k_solve_step, dim3(k * NB > i_begin ? cdiv_c(k * NB - i_begin, 256) : 1, P), dim3(256), 0, st,
+                                   S, ld, k * NB, Linv + k * NB * NB, rhs, tmp, 1, i_begin, S_rows);
+            }
+            hipLaunchKernelGGL(k_solution_back, dim3(cdiv_c(ld, 256)), dim3(256), 0, st, tmp, ld, d_newpos, rhs);
+        } else {
+            for (int64_t k = nb - 1; k >= 0; --k) {
+                const int64_t i_begin = (int64_t)row_first[k] * NB;     // L has nothing left of the row's first entry
+                hipLaunchKernelGGL(k_solve_step, dim3(k * NB > i_begin ? cdiv_c(k * NB - i_begin, 256) : 1), dim3(256), 0, st, S,
+                                   ld, k * NB, Linv + k * NB * NB, rhs, tmp, 1, i_begin, (int64_t)0);
+            }
+            if (e == hipSuccess) e = hipMemcpyAsync(rhs, tmp, sizeof(double) * ld, hipMemcpyDeviceToDevice, st);
         }
-        if (e == hipSuccess) e = hipMemcpyAsync(rhs, tmp, sizeof(double) * ld, hipMemcpyDeviceToDevice, st);
         if (e == hipSuccess) e = hipGetLastError();
     }
     int hinfo = 0;
@@ -817,6 +989,7 @@ int ba_cholesky_solve(int64_t n, int64_t ld, double *S, double *rhs, int *h_info
     hipFree(Linv);
     hipFree(tmp);
     hipFree(info);
+    hipFree(d_newpos);
     BA_HIP(e);
     if (h_info) *h_info = hinfo;
     if (hinfo != 0) {

@@ -272,7 +272,12 @@ int ba_resect(int64_t N, int64_t K, const int64_t *col_ptr, const int32_t *oi_by
  *   the factorisation) and does not hold the identity afterwards.  Blocks that are structurally zero are not
  *   computed: the first occupied 64-column block of every 64-row block is read off S before the factorisation
  *   (Cholesky creates no entries left of it), which costs one pass over the lower triangle and one host
- *   synchronisation; the environment variable BA_CHOL_DENSE=1 computes every tile.
+ *   synchronisation; the environment variable BA_CHOL_DENSE=1 computes every tile.  A long narrow band is cut
+ *   into independent chains that are factorised side by side (the 64-blocks of S are reordered in place: chains
+ *   first, then the separators between them, then the border): what S holds on return is then the factor of the
+ *   reordered matrix, and a pivot index in *h_info counts in that order; the solution comes back in the caller's
+ *   order.  The sums into the blocks shared by the chains are atomic, so the last bits of the solution can differ
+ *   from call to call.  BA_CHOL_NO_CHAINS=1 keeps the natural order (S = the factor L on return).
  * ba_backsubstitute: dX[N][3] = V'^-1 (-g_X - W d_cam - Xphi d_phi); dcam_packed (optional, 6K+1)
  *   receives d reordered to [dC (3K) | dTheta (3K) | dphi].  The trial point of the damped step comes out of
  *   the same two launches when asked for: X_trial[N][3] (optional) = X + dX, cam_trial (optional, 6K+1) =
