@@ -41,6 +41,8 @@ SIGNATURES = {
     'ba_schur_dim': (_int, [_i64, C.POINTER(_i64), C.POINTER(_i64)]),
     'ba_schur_build': (_int, [_p, _p, _dbl] + [_p] * 9 + [_int] + [_p] * 3),
     'ba_cholesky_solve': (_int, [_i64, _i64, _p, _p, C.POINTER(_int), _p]),
+    'ba_schur_build_tracked': (_int, [_p, _p, _dbl] + [_p] * 9 + [_int] + [_p] * 3 + [_int, _p]),
+    'ba_cholesky_solve_tracked': (_int, [_i64, _i64, _p, _p, _p, _int, C.POINTER(_int), _p]),
     'ba_backsubstitute': (_int, [_p, _p, _dbl, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'ba_build_camera_table': (_int, [_p, _p, _p, _p, _p]),
     'ba_can_fuse_update': (_int, [_p]),

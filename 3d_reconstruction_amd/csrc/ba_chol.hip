@@ -681,6 +681,17 @@ __global__ void __launch_bounds__(256) k_move_blocks(double *__restrict__ A, int
     }
 }
 
+// Clears runs of 64-blocks: workgroup b the blocks (runs[b].x, runs[b].y .. runs[b].z) of block row runs[b].x.
+__global__ void __launch_bounds__(256) k_clear_runs(double *__restrict__ A, int64_t ld, const int4 *__restrict__ runs) {
+    const int4 r = runs[blockIdx.x];
+    const int width = (r.z - r.y + 1) * NB / 2;     // double2 per row
+    double2 *row0 = (double2 *)(A + (int64_t)r.x * NB * ld + (int64_t)r.y * NB);
+    for (int rr = 0; rr < NB; ++rr) {
+        double2 *row = row0 + (int64_t)rr * (ld / 2);
+        for (int c = threadIdx.x; c < width; c += 256) row[c] = make_double2(0.0, 0.0);
+    }
+}
+
 // One block step of a triangular solve with the stored inverses of the diagonal blocks.
 // forward  (L y = b):   y_k = Linv_k b_k, then b_i -= L_ik y_k for the rows i behind block k
 // backward (L^T x = y): x_k = Linv_k^T b_k, then b_i -= L_ki^T x_k for the rows i before block k
@@ -745,6 +756,11 @@ int ba_schur_dim(int64_t K, int64_t *n, int64_t *ld) {
 }
 
 int ba_cholesky_solve(int64_t n, int64_t ld, double *S, double *rhs, int *h_info, void *stream) {
+    return ba_cholesky_solve_tracked(n, ld, S, rhs, nullptr, 0, h_info, stream);
+}
+
+int ba_cholesky_solve_tracked(int64_t n, int64_t ld, double *S, double *rhs, const int *block_first, int clear_on_return,
+                              int *h_info, void *stream) {
     BA_REQUIRE(S && rhs && n > 0 && ld >= n && ld % NB == 0, "ba_cholesky_solve: bad argument (ld must be a multiple of 64)");
     hipStream_t st = (hipStream_t)stream;
     const int64_t nb = ld / NB;
@@ -782,17 +798,30 @@ int ba_cholesky_solve(int64_t n, int64_t ld, double *S, double *rhs, int *h_info
     std::vector<int> first;
     if (e == hipSuccess && !getenv("BA_CHOL_DENSE") && border > 1) {
         first.resize((size_t)nb);
-        for (int64_t k = 0; k < nb; ++k) first[k] = (int)k;
-        int *d_first = nullptr;
-        e = hipMalloc(&d_first, sizeof(int) * nb);
-        if (e == hipSuccess) e = hipMemcpyAsync(d_first, first.data(), sizeof(int) * nb, hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL(k_block_profile, dim3((unsigned)nb, (unsigned)cdiv_c(nb, PROFILE_CHUNK)), dim3(256), 0, st, S, ld,
-                               d_first);
-            e = hipMemcpyAsync(first.data(), d_first, sizeof(int) * nb, hipMemcpyDeviceToHost, st);
+        if (block_first) {      // the caller knows the profile (a lower bound of every row's first block will do)
+            e = hipMemcpyAsync(first.data(), block_first, sizeof(int) * nb, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            for (int64_t k = 0; k < nb && e == hipSuccess; ++k)
+                if (first[k] < 0 || first[k] > k) {
+                    set_error("ba_cholesky_solve_tracked: block_first[k] must lie in 0 .. k");
+                    hipFree(Linv);
+                    hipFree(tmp);
+                    hipFree(info);
+                    return BA_ERR_ARG;
+                }
+        } else {
+            for (int64_t k = 0; k < nb; ++k) first[k] = (int)k;
+            int *d_first = nullptr;
+            e = hipMalloc(&d_first, sizeof(int) * nb);
+            if (e == hipSuccess) e = hipMemcpyAsync(d_first, first.data(), sizeof(int) * nb, hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(k_block_profile, dim3((unsigned)nb, (unsigned)cdiv_c(nb, PROFILE_CHUNK)), dim3(256), 0, st, S,
+                                   ld, d_first);
+                e = hipMemcpyAsync(first.data(), d_first, sizeof(int) * nb, hipMemcpyDeviceToHost, st);
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            hipFree(d_first);
         }
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        hipFree(d_first);
         if (e == hipSuccess) {
             // The last block rows before the structural border join it when they reach far further back than the
             // typical row does (a closed camera path couples the last cameras with the first): any choice of the
@@ -997,6 +1026,35 @@ int ba_cholesky_solve(int64_t n, int64_t ld, double *S, double *rhs, int *h_info
                                    ld, k * NB, Linv + k * NB * NB, rhs, tmp, 1, i_begin, (int64_t)0);
             }
             if (e == hipSuccess) e = hipMemcpyAsync(rhs, tmp, sizeof(double) * ld, hipMemcpyDeviceToDevice, st);
+        }
+        // The caller keeps S for the next system: every block that can hold anything now - the envelope in the order
+        // the factorisation worked in, whole rows behind the chains, the row that carried the right-hand side - is
+        // cleared, at the cost of the entries of L instead of the n^2 of the whole matrix.
+        if (clear_on_return && e == hipSuccess) {
+            if (first.empty()) {
+                e = hipMemsetAsync(S, 0, sizeof(double) * ld * ld, st);
+            } else {
+                std::vector<int4> runs;
+                auto add_run = [&](int64_t row, int64_t c_begin, int64_t c_last) {
+                    for (int64_t c = c_begin; c <= c_last; c += 32) runs.push_back(make_int4((int)row, (int)c, (int)std::min(c + 31, c_last), 0));
+                };
+                if (P > 1) {
+                    for (int c = 0; c < P; ++c)
+                        for (int64_t l = 0; l < s_blocks; ++l) add_run(c * s_blocks + l, c * s_blocks + chain_first[l], c * s_blocks + l);
+                    for (int64_t r = B0; r < nb; ++r) add_run(r, 0, r);
+                } else {
+                    for (int64_t r = 0; r + 1 < nb; ++r) add_run(r, row_first[r], r);
+                    add_run(nb - 1, 0, nb - 1);
+                }
+                int4 *d_runs = nullptr;
+                e = hipMalloc(&d_runs, sizeof(int4) * runs.size());
+                if (e == hipSuccess) e = hipMemcpyAsync(d_runs, runs.data(), sizeof(int4) * runs.size(), hipMemcpyHostToDevice, st);
+                if (e == hipSuccess) {
+                    hipLaunchKernelGGL(k_clear_runs, dim3((unsigned)runs.size()), dim3(256), 0, st, S, ld, d_runs);
+                    e = hipStreamSynchronize(st);       // `runs` goes out of use
+                }
+                hipFree(d_runs);
+            }
         }
         if (e == hipSuccess) e = hipGetLastError();
     }

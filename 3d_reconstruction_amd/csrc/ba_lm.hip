@@ -470,12 +470,10 @@ __global__ void k_schur_init(int64_t K, int64_t n, int64_t ld, double lambda, co
             for (int q = p; q < 6; ++q) {
                 double v = B[21 * j + idx++];
                 if (p == q) v *= 1.0 + lambda;
-                S[(6 * j + p) * ld + 6 * j + q] = v;
-                S[(6 * j + q) * ld + 6 * j + p] = v;
+                S[(6 * j + q) * ld + 6 * j + p] = v;       // lower triangle only: nothing reads the other one
             }
         for (int p = 0; p < 6; ++p) {
             S[(6 * K) * ld + 6 * j + p] = bphi[6 * j + p];
-            S[(6 * j + p) * ld + 6 * K] = bphi[6 * j + p];
             rhs[6 * j + p] = -(p < 3 ? gC[3 * j + p] : gTheta[3 * j + p - 3]);
         }
     }
@@ -515,6 +513,7 @@ struct SchurArgs {
     double *Xphi;            // N x 3, written: point x phi column
     double *S, *rhs;
     int max_deg;
+    int *first;              // optional: first occupied 64-column block of every 64-row block of S (atomic minimum)
 };
 
 // Tile form of the Schur kernel: a workgroup owns an LDS tile (a few hundred consecutive points
@@ -535,11 +534,32 @@ struct SchurTileArgs {
     const double *V, *gX;
     double *Xphi;            // N x 3, written: point x phi column
     double *S, *rhs;
+    int *first;              // optional: first occupied 64-column block of every 64-row block of S (atomic minimum)
 };
 
 __host__ __device__ inline size_t schur_tile_lds_doubles(int cam_cap, int max_deg) {
     const size_t m = 6 * (size_t)cam_cap;
-    return (size_t)cam_cap * CAM_ROW + 18 * (size_t)cam_cap * (cam_cap + 1) + 2 * m + 2 + (size_t)16 * max_deg * 37;
+    return (size_t)cam_cap * CAM_ROW + 18 * (size_t)cam_cap * (cam_cap + 1) + 2 * m + 2 + (size_t)16 * max_deg * 37 +
+           (size_t)(cam_cap + 1) / 2;
+}
+
+// The block profile of the reduced system before any point has contributed: every row starts at its own camera's
+// first column (a camera's six unknowns can lie across a block boundary), the row of phi_x at column 0, padding
+// rows on the diagonal.
+__global__ void k_schur_first_init(int *__restrict__ first, int64_t nb, int64_t K) {
+    const int64_t ib = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ib >= nb) return;
+    const int64_t row = 64 * ib;
+    if (row > 6 * K) first[ib] = (int)ib;
+    else if (row + 63 >= 6 * K) first[ib] = 0;
+    else first[ib] = (int)((6 * (row / 6)) / 64);
+}
+
+// rows of camera jr have an entry in the columns of camera jc <= jr
+__device__ __forceinline__ void note_block_first(int *__restrict__ first, int64_t jr, int64_t jc) {
+    const int cb = (int)((6 * jc) / 64), rb0 = (int)((6 * jr) / 64), rb1 = (int)((6 * jr + 5) / 64);
+    atomicMin(first + rb0, cb);
+    if (rb1 != rb0) atomicMin(first + rb1, cb);
 }
 
 constexpr int SCHUR_TILE_BLOCK = 1024;   // 16 waves: what a point costs is the latency of its loads
@@ -558,6 +578,8 @@ __global__ void __launch_bounds__(SCHUR_TILE_BLOCK) k_schur_tile(SchurTileArgs a
     double *Wl = sc_t + 2 + (size_t)wid * a.max_deg * 37;
     double *Zl = Wl + (size_t)a.max_deg * 18;
     int *sl = (int *)(Zl + (size_t)a.max_deg * 18);
+    int *low = (int *)(sc_t + 2 + (size_t)16 * a.max_deg * 37);     // per camera slot: the lowest slot it shares a point with
+    for (int idx = tid; idx < a.cam_cap; idx += SCHUR_TILE_BLOCK) low[idx] = 0x7fffffff;
     for (int idx = tid; idx < nc * (CAM_ROW / 2); idx += SCHUR_TILE_BLOCK) {
         const int row = idx / (CAM_ROW / 2), piece = idx - row * (CAM_ROW / 2);
         const int j = tm.j0 >= 0 ? tm.j0 + row : a.cam_list[tm.cb + row];
@@ -650,6 +672,13 @@ __global__ void __launch_bounds__(SCHUR_TILE_BLOCK) k_schur_tile(SchurTileArgs a
         bool ascending = true;
         for (int o = lane; o + 1 < deg; o += 64) ascending = ascending && sl[o] <= sl[o + 1];
         ascending = __all(ascending);
+        if (a.first) {
+            int lowest = 0x7fffffff;
+            for (int o = lane; o < deg; o += 64) lowest = min(lowest, sl[o]);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) lowest = min(lowest, __shfl_xor(lowest, off));
+            for (int o = lane; o < deg; o += 64) atomicMin(low + sl[o], lowest);
+        }
         if (lane < 36) {
             const int al = lane / 6, be = lane - 6 * al;
             for (int o = 0; o < deg; ++o) {
@@ -670,6 +699,14 @@ __global__ void __launch_bounds__(SCHUR_TILE_BLOCK) k_schur_tile(SchurTileArgs a
     }
     __syncthreads();
     const int64_t nphi = 6 * a.K;
+    if (a.first) {      // (the tile's camera slots are in the order of the camera numbers)
+        for (int sr = tid; sr < nc; sr += SCHUR_TILE_BLOCK) {
+            if (low[sr] > sr) continue;
+            const int64_t jr = tm.j0 >= 0 ? tm.j0 + sr : a.cam_list[tm.cb + sr];
+            const int64_t jc = tm.j0 >= 0 ? tm.j0 + low[sr] : a.cam_list[tm.cb + low[sr]];
+            note_block_first(a.first, jr, jc);
+        }
+    }
     for (int idx = tid; idx < n_st; idx += SCHUR_TILE_BLOCK) {
         const double v = St[idx];
         if (v == 0.0) continue;
@@ -678,6 +715,7 @@ __global__ void __launch_bounds__(SCHUR_TILE_BLOCK) k_schur_tile(SchurTileArgs a
         while (sr * (sr + 1) / 2 > blk) --sr;
         while ((sr + 1) * (sr + 2) / 2 <= blk) ++sr;
         const int scn = blk - sr * (sr + 1) / 2;
+        if (sr == scn && ent / 6 < ent % 6) continue;       // a camera's own block: lower triangle only
         const int64_t jr = tm.j0 >= 0 ? tm.j0 + sr : a.cam_list[tm.cb + sr];
         const int64_t jc = tm.j0 >= 0 ? tm.j0 + scn : a.cam_list[tm.cb + scn];
         __hip_atomic_fetch_add(a.S + (6 * jr + ent / 6) * a.ld + 6 * jc + ent % 6, v, __ATOMIC_RELAXED,
@@ -688,7 +726,6 @@ __global__ void __launch_bounds__(SCHUR_TILE_BLOCK) k_schur_tile(SchurTileArgs a
         const int64_t jr = tm.j0 >= 0 ? tm.j0 + sr : a.cam_list[tm.cb + sr];
         const int64_t ra = 6 * jr + (idx - 6 * sr);
         __hip_atomic_fetch_add(a.S + nphi * a.ld + ra, sphi_t[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(a.S + ra * a.ld + nphi, sphi_t[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(a.rhs + ra, rhs_t[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (tid == 0) {
@@ -775,7 +812,6 @@ __global__ void __launch_bounds__(256) k_schur_points(SchurArgs a) {
             const double rr = W[0][al] * zg[0] + W[1][al] * zg[1] + W[2][al] * zg[2];
             const int64_t ra = 6 * (int64_t)j + al;
             __hip_atomic_fetch_add(a.S + nphi * a.ld + ra, -sphi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(a.S + ra * a.ld + nphi, -sphi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_fetch_add(a.rhs + ra, rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         jl[o] = j;
@@ -788,6 +824,13 @@ __global__ void __launch_bounds__(256) k_schur_points(SchurArgs a) {
     }
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
+    if (a.first) {
+        int lowest = 0x7fffffff;
+        for (int o = lane; o < deg; o += 64) lowest = min(lowest, jl[o]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) lowest = min(lowest, __shfl_xor(lowest, off));
+        for (int o = lane; o < deg; o += 64) note_block_first(a.first, jl[o], lowest);
+    }
     // all ordered pairs (o, o') of the point's observations, 36 entries each: S[j, j'] -= W_o^T Z_o'
     const int total = deg * deg * 36;
     for (int w = lane; w < total; w += 64) {
@@ -796,7 +839,7 @@ __global__ void __launch_bounds__(256) k_schur_points(SchurArgs a) {
         const int al = ent / 6, be = ent - al * 6;
         const double v = Wl[o * 18 + al] * Zl[o2 * 18 + be] + Wl[o * 18 + 6 + al] * Zl[o2 * 18 + 6 + be] +
                          Wl[o * 18 + 12 + al] * Zl[o2 * 18 + 12 + be];
-        if (jl[o] < jl[o2]) continue;  // lower block triangle only: the factorisation never reads the rest
+        if (jl[o] < jl[o2] || (jl[o] == jl[o2] && al < be)) continue;  // lower triangle only: nothing reads the rest
         const int64_t ra = 6 * (int64_t)jl[o] + al, cbx = 6 * (int64_t)jl[o2] + be;
         __hip_atomic_fetch_add(a.S + ra * a.ld + cbx, -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -1038,6 +1081,14 @@ static int ensure_row_ptr(ba_problem *p) {
 int ba_schur_build(ba_problem *p, const double *X, double lambda, const double *V, double *Xphi, const double *gX,
                    const double *B, const double *bphi, const double *hphi, const double *gC, const double *gTheta,
                    const double *gphi, int with_camera_blocks, double *S, double *rhs, void *stream) {
+    return ba_schur_build_tracked(p, X, lambda, V, Xphi, gX, B, bphi, hphi, gC, gTheta, gphi, with_camera_blocks, S, rhs,
+                                  nullptr, 0, stream);
+}
+
+int ba_schur_build_tracked(ba_problem *p, const double *X, double lambda, const double *V, double *Xphi, const double *gX,
+                           const double *B, const double *bphi, const double *hphi, const double *gC, const double *gTheta,
+                           const double *gphi, int with_camera_blocks, double *S, double *rhs, int *block_first,
+                           int S_is_zero, void *stream) {
     BA_REQUIRE(p && X && V && Xphi && gX && B && bphi && hphi && gC && gTheta && gphi && S && rhs,
                "ba_schur_build: null pointer");
     if (int rc = ensure_row_ptr(p)) return rc;
@@ -1051,7 +1102,9 @@ int ba_schur_build(ba_problem *p, const double *X, double lambda, const double *
         set_error("ba_schur_build: a point has too many observations for the Schur kernel");
         return BA_ERR_STATE;
     }
-    BA_HIP(hipMemsetAsync(S, 0, sizeof(double) * ld * ld, st));
+    if (!S_is_zero) BA_HIP(hipMemsetAsync(S, 0, sizeof(double) * ld * ld, st));
+    if (block_first)
+        hipLaunchKernelGGL(k_schur_first_init, dim3(cdiv_i(ld / 64, 256)), dim3(256), 0, st, block_first, ld / 64, p->K);
     if (with_camera_blocks)
         hipLaunchKernelGGL(k_schur_init, dim3(cdiv_i(p->K, 256)), dim3(256), 0, st, p->K, n, ld, lambda, B, bphi, hphi,
                            gC, gTheta, gphi, S, rhs);
@@ -1077,6 +1130,7 @@ int ba_schur_build(ba_problem *p, const double *X, double lambda, const double *
         ta.gX = gX;
         ta.S = S;
         ta.rhs = rhs;
+        ta.first = block_first;
         if (lds_tile > 64 * 1024)
             BA_HIP(hipFuncSetAttribute((const void *)k_schur_tile, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tile));
         hipLaunchKernelGGL(k_schur_tile, dim3(p->n_tiles), dim3(SCHUR_TILE_BLOCK), lds_tile, st, ta);
@@ -1100,6 +1154,7 @@ int ba_schur_build(ba_problem *p, const double *X, double lambda, const double *
     a.S = S;
     a.rhs = rhs;
     a.max_deg = p->max_degree;
+    a.first = block_first;
     if (lds > 64 * 1024)
         BA_HIP(hipFuncSetAttribute((const void *)k_schur_points, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_schur_points, dim3(cdiv_i(p->N, 4)), dim3(256), lds, st, a);

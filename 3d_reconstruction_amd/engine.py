@@ -218,6 +218,16 @@ class Shard:
         else:
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM, group=self.group)
 
+    def _min_over_ranks(self, t):
+        """Elementwise minimum of a device tensor over the ranks of the group, in place."""
+        dist = torch.distributed
+        if self._stage_reduce:
+            host = t.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.MIN, group=self.group)
+            t.copy_(host)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+
     def _broadcast_first(self, t):
         """The first rank's values of a device tensor to every rank of the group, in place."""
         dist = torch.distributed
@@ -551,6 +561,10 @@ class Shard:
             # camera-side blocks in one buffer (one cross-GPU sum): [B (21K) | bphi (6K) | hphi]
             self._bind_blocks(z(self.N, 6), z(27 * self.K + 1))
             self.S, self.rhs = z(self.ld_red, self.ld_red), z(self.ld_red)
+            # block profile of S, written while S is built, and whether S holds zeros at the moment (the solver
+            # clears what the factor occupied: at 20 000 cameras S has 115 GB, its band a few)
+            self.S_first = torch.empty(self.ld_red // 64, dtype=torch.int32, device=self.device)
+            self._S_is_zero = True
             self.dX, self.dcam = z(self.N, 3), z(6 * self.K + 1)
             self.X_trial = self.cam_trial = None
             self._spare_evaluation = None
@@ -609,16 +623,20 @@ class Shard:
         first = 1
         if self.distributed:
             first = 1 if torch.distributed.get_rank(self.group) == 0 else 0
-        check(self.lib.ba_schur_build(self.handle, X.data_ptr(), float(lam), ptr(self.V), ptr(self.Xphi),
-                                      ptr(self.gX), ptr(self.B), ptr(self.bphi), ptr(self.hphi), ptr(self.gC),
-                                      ptr(self.gTheta), ptr(self.gphi), first, ptr(self.S), ptr(self.rhs), self.stream))
+        S_is_zero, self._S_is_zero = self._S_is_zero, False
+        check(self.lib.ba_schur_build_tracked(self.handle, X.data_ptr(), float(lam), ptr(self.V), ptr(self.Xphi),
+                                              ptr(self.gX), ptr(self.B), ptr(self.bphi), ptr(self.hphi), ptr(self.gC),
+                                              ptr(self.gTheta), ptr(self.gphi), first, ptr(self.S), ptr(self.rhs),
+                                              ptr(self.S_first), int(S_is_zero), self.stream))
         if self.distributed:
             self._sum_over_ranks(self.S)
             self._sum_over_ranks(self.rhs)
+            self._min_over_ranks(self.S_first)
         if on_system is not None:
             on_system(self.S, self.rhs)
-        status = self.lib.ba_cholesky_solve(self.n_red, self.ld_red, ptr(self.S), ptr(self.rhs), C.byref(info),
-                                            self.stream)
+        status = self.lib.ba_cholesky_solve_tracked(self.n_red, self.ld_red, ptr(self.S), ptr(self.rhs), ptr(self.S_first),
+                                                    1, C.byref(info), self.stream)
+        self._S_is_zero = status in (0, -4)     # the solver ran to its end and cleared S
         if self.distributed:
             # Every rank factorised the same system, but sums inside the factorisation are not ordered (the update
             # kernel adds parts of a tile with atomics): the ranks' solutions can differ in the last bits, and at a

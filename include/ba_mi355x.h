@@ -257,7 +257,7 @@ int ba_resect(int64_t N, int64_t K, const int64_t *col_ptr, const int32_t *oi_by
  *   The cross blocks (point x camera, point x phi_x) are not stored: ba_schur_build and
  *   ba_backsubstitute form them from the observations.
  * ba_schur_dim: n = 6K+1 unknowns of the reduced camera system, ld = n rounded up to 64.
- * ba_schur_build: S (ld x ld, row-major, lower triangle valid) and rhs (ld) of
+ * ba_schur_build: S (ld x ld, row-major; only the lower triangle is written) and rhs (ld) of
  *   (D' - Y^T V'^-1 Y) d = -g_cam + Y^T V'^-1 g_X, primes = diagonal scaled by (1 + lambda);
  *   unknown order: camera j at 6j..6j+5 (C then Theta), phi_x at 6K.  Uses the camera table left by
  *   the last ba_eval_jtj.  Also WRITES Xphi[N][3], the point x phi_x column of J^T J, for
@@ -295,6 +295,20 @@ int ba_schur_build(ba_problem *p, const double *X, double lambda, const double *
                    const double *gC, const double *gTheta, const double *gphi, int with_camera_blocks,
                    double *S, double *rhs, void *stream);
 int ba_cholesky_solve(int64_t n, int64_t ld, double *S, double *rhs, int *h_info, void *stream);
+/* The same two steps for a caller that builds and solves one system after the other in the same S (an LM loop):
+ * at 20 000 cameras S has 115 GB, and clearing it for the next build and reading it for the block profile cost
+ * more than building and factorising the band that it holds.
+ * ba_schur_build_tracked: also writes block_first[ld / 64] (device): a lower bound of the first occupied
+ *   64-column block of every 64-row block of S, collected while S is built (with several GPUs: the minimum over
+ *   the ranks belongs to the summed S); S_is_zero != 0: S holds zeros on entry and is not cleared.
+ * ba_cholesky_solve_tracked: block_first (or NULL) takes the place of the pass over S that reads the profile;
+ *   clear_on_return != 0: S holds zeros again on return (only the blocks the factor occupied are written). */
+int ba_schur_build_tracked(ba_problem *p, const double *X, double lambda, const double *V, double *Xphi,
+                           const double *gX, const double *B, const double *bphi, const double *hphi,
+                           const double *gC, const double *gTheta, const double *gphi, int with_camera_blocks,
+                           double *S, double *rhs, int *block_first, int S_is_zero, void *stream);
+int ba_cholesky_solve_tracked(int64_t n, int64_t ld, double *S, double *rhs, const int *block_first,
+                              int clear_on_return, int *h_info, void *stream);
 int ba_backsubstitute(ba_problem *p, const double *X, double lambda, const double *V, const double *Xphi,
                       const double *gX, const double *d, double *dcam_packed, double *dX, const double *cam,
                       double *X_trial, double *cam_trial, void *stream);

@@ -151,6 +151,50 @@ def test_cholesky_skips_structural_zeros_correctly(ba):
                 assert rel_err(np.tril(Sd.cpu().numpy()[:n, :n]), want_L) < 1e-11, (n, switch)
 
 
+def test_tracked_build_and_solve_keep_S_clean(ba):
+    """The pair of entry points an LM loop uses: the Schur build reports the block profile of S (a lower bound of every
+    block row's first occupied block, exact here), the solver takes it instead of reading S, gives the solution of the
+    plain pair, and leaves S cleared for the next build."""
+    import ctypes as C
+    sc, sh, r, J = _scene(ba, N=900, K=130, seed=4)
+    lib, p = sh.lib, ba.engine._lib.ptr
+    lam = 1e-2
+    sh.eval_jtj()
+    n, ld = sh.n_red, sh.ld_red
+
+    def build(first, is_zero):
+        ba.engine.check(lib.ba_schur_build_tracked(sh.handle, p(sh.X), lam, p(sh.V), p(sh.Xphi), p(sh.gX), p(sh.B),
+                                                   p(sh.bphi), p(sh.hphi), p(sh.gC), p(sh.gTheta), p(sh.gphi), 1, p(sh.S),
+                                                   p(sh.rhs), p(first) if first is not None else None, is_zero, None))
+    first = torch.full((ld // 64,), -7, dtype=torch.int32, device=DEV)
+    build(first, 0)
+    S0, rhs0 = sh.S.clone(), sh.rhs.clone()
+    Sl = torch.tril(S0).cpu().numpy()
+    got = first.cpu().numpy()
+    for ib in range(ld // 64):
+        cols = np.nonzero(np.abs(Sl[64 * ib:64 * ib + 64]).sum(axis=0))[0]
+        assert got[ib] <= cols[0] // 64 and got[ib] >= 0
+        if 64 * ib + 63 < 6 * sc['K']:
+            assert got[ib] == cols[0] // 64       # camera rows: exact
+    info = C.c_int(0)
+    ba.engine.check(lib.ba_cholesky_solve(n, ld, p(sh.S), p(sh.rhs), C.byref(info), None))
+    want = sh.rhs[:n].clone()
+    sh.S.copy_(S0)
+    sh.rhs.copy_(rhs0)
+    ba.engine.check(lib.ba_cholesky_solve_tracked(n, ld, p(sh.S), p(sh.rhs), p(first), 1, C.byref(info), None))
+    assert info.value == 0
+    assert rel_err(sh.rhs[:n].cpu().numpy(), want.cpu().numpy()) < 1e-12
+    assert float(sh.S.abs().max()) == 0.0
+    # the next build into the cleared S, told so, gives the same system as a build that clears S itself
+    build(first, 1)
+    assert torch.equal(torch.tril(sh.S), torch.tril(S0)) or rel_err(torch.tril(sh.S).cpu().numpy(), Sl) < 1e-13
+    # a profile that claims more than the rows can have is refused
+    bad = first.clone()
+    bad[2] = 5
+    assert lib.ba_cholesky_solve_tracked(n, ld, p(sh.S), p(sh.rhs), p(bad), 0, C.byref(info), None) == -1
+    sh.close()
+
+
 def test_lm_step_matches_dense_solve(ba):
     sc, sh, r, J = _scene(ba, N=250, K=60, seed=9)
     N, K = sc['N_local'], sc['K']
