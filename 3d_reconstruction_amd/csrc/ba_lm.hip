@@ -537,9 +537,9 @@ struct SchurTileArgs {
     int *first;              // optional: first occupied 64-column block of every 64-row block of S (atomic minimum)
 };
 
-__host__ __device__ inline size_t schur_tile_lds_doubles(int cam_cap, int max_deg) {
+__host__ __device__ inline size_t schur_tile_lds_doubles(int cam_cap, int max_deg, int waves = 16) {
     const size_t m = 6 * (size_t)cam_cap;
-    return (size_t)cam_cap * CAM_ROW + 18 * (size_t)cam_cap * (cam_cap + 1) + 2 * m + 2 + (size_t)16 * max_deg * 37 +
+    return (size_t)cam_cap * CAM_ROW + 18 * (size_t)cam_cap * (cam_cap + 1) + 2 * m + 2 + (size_t)waves * max_deg * 37 +
            (size_t)(cam_cap + 1) / 2;
 }
 
@@ -562,7 +562,13 @@ __device__ __forceinline__ void note_block_first(int *__restrict__ first, int64_
     if (rb1 != rb0) atomicMin(first + rb1, cb);
 }
 
-constexpr int SCHUR_TILE_BLOCK = 1024;   // 16 waves: what a point costs is the latency of its loads
+// REG_PAIRS: a point's pairs of observations are dealt out one per lane (lane l <-> pair (o, o'), o' <= o, fixed for
+// the whole kernel) and the lane keeps the 6 x 6 block of its pair in registers from one point to the next; it goes
+// to the LDS tile only when the pair's cameras change.  The points of a tile come in the order of their cameras,
+// so most of them see the same cameras as the point before: 36 LDS atomics per pair become 36 per change of the camera
+// set, and the 165 LDS reads of the entry-per-lane loop 36.  Points with more than 10 observations (more pairs than
+// lanes) or with their observations out of the order of the slots take the entry-per-lane loop.
+template <bool REG_PAIRS, int SCHUR_TILE_BLOCK>
 __global__ void __launch_bounds__(SCHUR_TILE_BLOCK) k_schur_tile(SchurTileArgs a) {
     extern __shared__ double lds[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -578,7 +584,7 @@ __global__ void __launch_bounds__(SCHUR_TILE_BLOCK) k_schur_tile(SchurTileArgs a
     double *Wl = sc_t + 2 + (size_t)wid * a.max_deg * 37;
     double *Zl = Wl + (size_t)a.max_deg * 18;
     int *sl = (int *)(Zl + (size_t)a.max_deg * 18);
-    int *low = (int *)(sc_t + 2 + (size_t)16 * a.max_deg * 37);     // per camera slot: the lowest slot it shares a point with
+    int *low = (int *)(sc_t + 2 + (size_t)(SCHUR_TILE_BLOCK / 64) * a.max_deg * 37);     // per camera slot: the lowest slot it shares a point with
     for (int idx = tid; idx < a.cam_cap; idx += SCHUR_TILE_BLOCK) low[idx] = 0x7fffffff;
     for (int idx = tid; idx < nc * (CAM_ROW / 2); idx += SCHUR_TILE_BLOCK) {
         const int row = idx / (CAM_ROW / 2), piece = idx - row * (CAM_ROW / 2);
@@ -591,6 +597,26 @@ __global__ void __launch_bounds__(SCHUR_TILE_BLOCK) k_schur_tile(SchurTileArgs a
     const double f = a.scalars[SC_F], pcx = a.scalars[SC_CX], pcy = a.scalars[SC_CY], dphi = a.scalars[SC_DPHI];
     __syncthreads();
 
+    // lane -> its pair (po, po2 <= po); block of St the lane's registers belong to (-1: none)
+    int po = (int)((sqrtf(8.0f * (float)lane + 1.0f) - 1.0f) * 0.5f);
+    while (po * (po + 1) / 2 > lane) --po;
+    while ((po + 1) * (po + 2) / 2 <= lane) ++po;
+    const int po2 = lane - po * (po + 1) / 2;
+    int held = -1;
+    double acc[36];
+#pragma unroll
+    for (int e = 0; e < 36; ++e) acc[e] = 0.0;
+    auto flush_pairs = [&](bool mine) {      // lanes with `mine` add their block to the tile and let go of it
+        if (mine) {
+            double *dst = St + (size_t)held * 36;
+#pragma unroll
+            for (int e = 0; e < 36; ++e) {
+                __hip_atomic_fetch_add(dst + e, acc[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                acc[e] = 0.0;
+            }
+            held = -1;
+        }
+    };
     for (int pt = wid; pt < np; pt += SCHUR_TILE_BLOCK / 64) {
         const int64_t i = p0 + pt;
         const int64_t eb = a.row_ptr[i];
@@ -679,6 +705,35 @@ __global__ void __launch_bounds__(SCHUR_TILE_BLOCK) k_schur_tile(SchurTileArgs a
             for (int off = 32; off > 0; off >>= 1) lowest = min(lowest, __shfl_xor(lowest, off));
             for (int o = lane; o < deg; o += 64) atomicMin(low + sl[o], lowest);
         }
+        if (REG_PAIRS && deg <= 10 && ascending) {
+            const bool active = po < deg;
+            int blk = -1;
+            if (active) {
+                const int so = sl[po], so2 = sl[po2];
+                blk = so * (so + 1) / 2 + so2;
+            }
+            const bool moved = active && held >= 0 && blk != held;
+            if (__any(moved)) flush_pairs(moved);
+            if (active) {
+                held = blk;
+                const double *wr = Wl + po * 18, *zr = Zl + po2 * 18;
+#pragma unroll
+                for (int mm = 0; mm < 3; ++mm) {
+                    double w[6], z[6];
+#pragma unroll
+                    for (int h = 0; h < 3; ++h) {
+                        const double2 wv = *(const double2 *)(wr + 6 * mm + 2 * h), zv = *(const double2 *)(zr + 6 * mm + 2 * h);
+                        w[2 * h] = wv.x, w[2 * h + 1] = wv.y;
+                        z[2 * h] = zv.x, z[2 * h + 1] = zv.y;
+                    }
+#pragma unroll
+                    for (int al = 0; al < 6; ++al)
+#pragma unroll
+                        for (int be = 0; be < 6; ++be) acc[6 * al + be] = fma(-w[al], z[be], acc[6 * al + be]);
+                }
+            }
+        } else {
+        if (REG_PAIRS && __any(held >= 0)) flush_pairs(held >= 0);
         if (lane < 36) {
             const int al = lane / 6, be = lane - 6 * al;
             for (int o = 0; o < deg; ++o) {
@@ -694,9 +749,11 @@ __global__ void __launch_bounds__(SCHUR_TILE_BLOCK) k_schur_tile(SchurTileArgs a
                 }
             }
         }
+        }
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
     }
+    if (REG_PAIRS) flush_pairs(held >= 0);
     __syncthreads();
     const int64_t nphi = 6 * a.K;
     if (a.first) {      // (the tile's camera slots are in the order of the camera numbers)
@@ -1131,9 +1188,19 @@ int ba_schur_build_tracked(ba_problem *p, const double *X, double lambda, const 
         ta.S = S;
         ta.rhs = rhs;
         ta.first = block_first;
-        if (lds_tile > 64 * 1024)
-            BA_HIP(hipFuncSetAttribute((const void *)k_schur_tile, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tile));
-        hipLaunchKernelGGL(k_schur_tile, dim3(p->n_tiles), dim3(SCHUR_TILE_BLOCK), lds_tile, st, ta);
+        const char *form = getenv("BA_SCHUR_FORM");      // 0: entry-per-lane pair loop; 1: pairs in registers, 16 waves; 2: 8 waves
+        const int which = form ? atoi(form) : 2;
+        auto launch = [&](auto kernel, int block) -> int {
+            if (lds_tile > 64 * 1024)
+                BA_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tile));
+            hipLaunchKernelGGL(kernel, dim3(p->n_tiles), dim3(block), lds_tile, st, ta);
+            return BA_OK;
+        };
+        int rc;
+        if (which == 0) rc = launch(k_schur_tile<false, 1024>, 1024);
+        else if (which == 1) rc = launch(k_schur_tile<true, 1024>, 1024);
+        else rc = launch(k_schur_tile<true, 512>, 512);
+        if (rc) return rc;
         BA_HIP(hipGetLastError());
         return BA_OK;
     }
