@@ -202,6 +202,22 @@ __global__ void k_chunk_bounds(const int32_t *__restrict__ oi, int64_t nV, int n
     chunk_begin[c] = (int32_t)t;
 }
 
+// Tile bounds from a list of nominal offsets: every bound moved forward to the next point's first observation.
+__global__ void k_tile_bounds(const int32_t *__restrict__ oi, int64_t nV, int n_tiles, const int64_t *__restrict__ nominal,
+                              int32_t *__restrict__ tile_begin) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > n_tiles) return;
+    int64_t t = c < n_tiles ? nominal[c] : nV;
+    if (c == n_tiles || t >= nV) {
+        tile_begin[c] = (int32_t)nV;
+        return;
+    }
+    if (t > 0) {
+        while (t < nV && oi[t] == oi[t - 1]) ++t;
+    }
+    tile_begin[c] = (int32_t)t;
+}
+
 // --------------------------------------------------------------------------------------------
 // K1: camera table + scalars
 // --------------------------------------------------------------------------------------------
@@ -2269,7 +2285,7 @@ static int build_runs(ba_problem *p) {
     // whatever the workgroup's LDS allocation leaves unused: the LDS of a CU (160 KB) is handed out in granules of
     // 1280 bytes, so a workgroup can grow to the largest size that keeps the number of workgroups per CU
     const size_t budget = 64 * 1024;
-    auto pick_slots = [&](int ncv, int npv, size_t limit, const char *env_name) {
+    auto pick_slots = [&](int ncv, int npv, size_t limit, const char *env_name, size_t wg_per_cu_regs) {
         int rep = 2;
         if (const char *env = getenv(env_name)) rep = atoi(env);
         if (rep < 1) rep = 1;
@@ -2278,15 +2294,16 @@ static int build_runs(ba_problem *p) {
         int slots = p->cam_cap * rep;
         const size_t lds_cu = 160 * 1024, granule = 1280, fixed = 256;     // fixed: the kernel's static arrays
         const size_t base = sizeof(double) * run_pass_lds_doubles(ncv, npv, p->cam_cap, p->run_pt_stride, slots) + fixed;
-        const size_t per_cu = lds_cu / base;
+        // workgroups a CU holds: by LDS, and by the registers of the kernel (four waves each)
+        const size_t per_cu = std::min(lds_cu / base, wg_per_cu_regs);
         if (per_cu >= 1 && !getenv("BA_NO_LDS_SLACK")) {
             const size_t room = (lds_cu / per_cu) / granule * granule;
             if (room > base) slots += (int)((room - base) / (sizeof(double) * ncv));
         }
         return slots;
     };
-    p->run_slots_grad = pick_slots(6, 3, budget / 2, "BA_CAM_REP");
-    p->run_slots_jtj = pick_slots(28, 9, 78 * 1024, "BA_CAM_REP_JTJ");   // two workgroups per CU at least
+    p->run_slots_grad = pick_slots(6, 3, budget / 2, "BA_CAM_REP", 4);
+    p->run_slots_jtj = pick_slots(28, 9, 78 * 1024, "BA_CAM_REP_JTJ", p->compact ? 3 : 2);   // two workgroups per CU at least
     if (getenv("BA_VERBOSE"))
         fprintf(stderr, "[ba] runs: records=%s total=%lld (%.3f x nV/8) pt_stride=%d accumulator columns grad=%d jtj=%d (largest tile: %d cameras)\n",
                 p->compact ? "i16" : "f64", (long long)p->total_runs, (double)p->total_runs * RUN_LEN / (double)p->nV, p->run_pt_stride,
@@ -2351,7 +2368,33 @@ static int build_tiles(ba_problem *p) {
     int nt = 0;
     for (;; tobs /= 2) {
         if (tobs < 64) return BA_OK;
-        nt = (int)((nV + tobs - 1) / tobs);
+        // Tile sizes are not uniform.  Head (BA_TILE_HEAD="count:size,count:size,..."): the first workgroups of a launch
+        // start together; tiles of different sizes take them apart, so that later one workgroup's set-up and output
+        // phases overlap with the others' main loops.  Tail (BA_TILE_TAIL=fraction of the observations): when the launch
+        // runs out of tiles every CU is left with workgroups nothing overlaps with; the last observations are cut into
+        // tiles of half the size.
+        std::vector<int64_t> nominal;
+        {
+            double tail = 0.15;
+            if (const char *env = getenv("BA_TILE_TAIL")) tail = atof(env);
+            if (!(tail >= 0.0 && tail <= 1.0)) tail = 0.0;
+            const bool graded = nV >= (int64_t)tobs * 1024;       // fewer tiles than workgroup slots: nothing to grade
+            int64_t at = 0;
+            if (graded)
+                if (const char *env = getenv("BA_TILE_HEAD")) {
+                    for (const char *q = env; *q && at < nV;) {
+                        int count = 0, size = 0, used = 0;
+                        if (sscanf(q, "%d:%d%n", &count, &size, &used) < 2 || size < 64 || size > tobs) break;
+                        for (int k = 0; k < count && at < nV; ++k, at += size) nominal.push_back(at);
+                        q += used;
+                        if (*q == ',') ++q;
+                    }
+                }
+            const int64_t tail_obs = graded ? (int64_t)(tail * (double)nV) : 0;
+            for (; at < nV - tail_obs; at += tobs) nominal.push_back(at);
+            for (; at < nV; at += tobs / 2) nominal.push_back(at);
+        }
+        nt = (int)nominal.size();
         hipFree(p->tile_obs);
         hipFree(p->tile_cam_ptr);
         p->tile_obs = nullptr;
@@ -2359,13 +2402,21 @@ static int build_tiles(ba_problem *p) {
         BA_HIP(hipMalloc(&p->tile_obs, sizeof(int32_t) * (nt + 1)));
         BA_HIP(hipMalloc(&p->tile_cam_ptr, sizeof(int64_t) * (nt + 1)));
         BA_HIP(hipMemset(maxima, 0, 8));
-        hipLaunchKernelGGL(k_chunk_bounds, dim3(cdiv(nt + 1, 256)), dim3(256), 0, 0, p->oi, nV, nt, (int64_t)tobs,
+        int64_t *d_nominal = nullptr;
+        BA_HIP(hipMalloc(&d_nominal, sizeof(int64_t) * nominal.size()));
+        if (hipError_t e = hipMemcpy(d_nominal, nominal.data(), sizeof(int64_t) * nominal.size(), hipMemcpyHostToDevice)) {
+            hipFree(d_nominal);
+            BA_HIP(e);
+        }
+        hipLaunchKernelGGL(k_tile_bounds, dim3(cdiv(nt + 1, 256)), dim3(256), 0, 0, p->oi, nV, nt, (const int64_t *)d_nominal,
                            p->tile_obs);
         hipLaunchKernelGGL(k_tile_count, dim3(nt), dim3(TILE_BLOCK), sizeof(unsigned) * n_words, 0, p->oi, p->oj,
                            p->tile_obs, (int)K, p->tile_cam_ptr, maxima);
-        BA_HIP(hipGetLastError());
         int hmax[2];
-        BA_HIP(hipMemcpy(hmax, maxima, 8, hipMemcpyDeviceToHost));
+        hipError_t e_tiles = hipGetLastError();
+        if (e_tiles == hipSuccess) e_tiles = hipMemcpy(hmax, maxima, 8, hipMemcpyDeviceToHost);
+        hipFree(d_nominal);
+        BA_HIP(e_tiles);
         int rep = 16;
         if (const char *env = getenv("BA_CAM_REP")) rep = atoi(env);
         size_t need = 0;

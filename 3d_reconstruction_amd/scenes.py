@@ -41,17 +41,20 @@ def orbit_cameras(K, seed=0):
     return C, Theta, _ryxz(Theta)
 
 
-def orbit_scene(N, K, track_len=10, seed=0, W=1920, H=1080, phi_x=1.2, part=0, parts=1, stride=1):
+def orbit_scene(N, K, track_len=10, seed=0, W=1920, H=1080, phi_x=1.2, part=0, parts=1, stride=1, centres=None):
     """Points `part` of `parts` (contiguous ranges of the N points) of the orbit scene.
 
     Returns a dict with: i (local point index), j, xy (int32 pixels), uv (= xy + 0.5),
     N_local, point_offset, K, W, H, truth (X, C, Theta, phi_x) and a perturbed initial guess
-    (X_0, C_0, Theta_0, phi_x_0)."""
+    (X_0, C_0, Theta_0, phi_x_0).  `centres` (optional, one frame number per point of this part) replaces
+    the random centre frames of the tracks."""
     C, Theta, R = orbit_cameras(K, seed)
     p0, p1 = (N * part) // parts, (N * (part + 1)) // parts
     n = p1 - p0
     rng = np.random.default_rng([seed, 0x9017, part, parts])
     k_c = rng.integers(0, K, n)
+    if centres is not None:
+        k_c = np.asarray(centres, dtype=np.int64) % K
     z = rng.uniform(4.0, 8.0, n)
     t = np.tan(phi_x / 2.0)
     a = rng.uniform(-0.5, 0.5, n) * t

@@ -790,3 +790,33 @@ def test_small_scenes_with_many_cameras(ba, N, K, track):
     assert rel_err(fit.energies(), ref[4]) < TOL
     assert np.abs(sh.points_to_caller(sh.X).cpu().numpy() - ref[0]).max() < 1e-9
     sh.close()
+
+
+def test_graded_tile_list(ba):
+    """Tiles of unequal size (a launch's first tiles graded by BA_TILE_HEAD, its last observations cut into tiles of
+    half the size): both passes and a few fused iterations against the oracle.  The grading starts at 1024 tiles, so
+    the tile is made small enough for a scene the oracle handles in a second."""
+    sc = ba.scenes.orbit_scene(30000, 200, track_len=8, seed=6)
+    i, j, uv, N, K = sc['i'], sc['j'], sc['uv'], 30000, 200
+    assert i.size > 128 * 1024
+    E_ref, gX_r, gC_r, gT_r, gp_r = orc.energy_and_gradients(sc['X_0'], sc['C_0'], sc['Theta_0'], np.array([sc['phi_x_0']]),
+                                                             sc['W'], sc['H'], i, j, uv)
+    ref = orc.fit_scene(i, j, uv, N, K, sc['W'], sc['H'], 1e-3, 8, sc['X_0'], sc['C_0'], sc['Theta_0'], sc['phi_x_0'])
+    for head, tail in (('', '0'), ('', '0.3'), ('5:64,7:96,40:128', '0.15')):
+        os.environ.update(BA_TILE_OBS='128', BA_TILE_HEAD=head, BA_TILE_TAIL=tail)
+        try:
+            sh = ba.engine.Shard(i, j, uv, N, K, sc['W'], sc['H'], DEV)
+        finally:
+            for k in ('BA_TILE_OBS', 'BA_TILE_HEAD', 'BA_TILE_TAIL'):
+                os.environ.pop(k, None)
+        sh.set_params(sc['X_0'], sc['C_0'], sc['Theta_0'], sc['phi_x_0'])
+        E, gX, gC, gT, gp = _eval_all(ba, sh, i.size)
+        assert abs(E - E_ref) / E_ref < TOL, (head, tail)
+        assert rel_err(gX, gX_r) < TOL and rel_err(gC, gC_r) < TOL and rel_err(gT, gT_r) < TOL, (head, tail)
+        sh.eval_jtj()
+        assert rel_err(sh.points_to_caller(sh.gX).cpu().numpy() / i.size, gX_r) < TOL, (head, tail)
+        assert rel_err(sh.gC.cpu().numpy() / i.size, gC_r) < TOL, (head, tail)
+        fit = ba.SceneFit(sh, 1e-3, 8, printer=lambda *a: None).run()
+        assert rel_err(fit.energies(), ref[4]) < TOL, (head, tail)
+        assert np.abs(sh.points_to_caller(sh.X).cpu().numpy() - ref[0]).max() < 1e-9, (head, tail)
+        sh.close()
