@@ -539,7 +539,7 @@ struct SchurTileArgs {
 
 __host__ __device__ inline size_t schur_tile_lds_doubles(int cam_cap, int max_deg, int waves = 16) {
     const size_t m = 6 * (size_t)cam_cap;
-    return (size_t)cam_cap * CAM_ROW + 18 * (size_t)cam_cap * (cam_cap + 1) + 2 * m + 2 + (size_t)waves * max_deg * 37 +
+    return (size_t)cam_cap * (CAM_ROW + 18) + 18 * (size_t)cam_cap * (cam_cap + 1) + 2 * m + 2 + (size_t)waves * max_deg * 37 +
            (size_t)(cam_cap + 1) / 2;
 }
 
@@ -577,7 +577,8 @@ __global__ void __launch_bounds__(SCHUR_TILE_BLOCK) k_schur_tile(SchurTileArgs a
     if (tm.e0 >= tm.e1) return;
     const int m = 6 * nc;
     double *rows = lds;                                   // cam_cap x CAM_ROW
-    double *St = rows + (size_t)a.cam_cap * CAM_ROW;      // lower block triangle: block (sr, sc <= sr) at (sr (sr + 1) / 2 + sc) * 36
+    double *Tt = rows + (size_t)a.cam_cap * CAM_ROW;      // cam_cap x 6 x 3: the three non-zero entries of every column of the frame change
+    double *St = Tt + (size_t)a.cam_cap * 18;             // lower block triangle: block (sr, sc <= sr) at (sr (sr + 1) / 2 + sc) * 36
     double *sphi_t = St + 18 * (size_t)a.cam_cap * (a.cam_cap + 1);   // m
     double *rhs_t = sphi_t + 6 * a.cam_cap;               // m
     double *sc_t = rhs_t + 6 * a.cam_cap;                 // {phi-phi, rhs phi}
@@ -590,6 +591,18 @@ __global__ void __launch_bounds__(SCHUR_TILE_BLOCK) k_schur_tile(SchurTileArgs a
         const int row = idx / (CAM_ROW / 2), piece = idx - row * (CAM_ROW / 2);
         const int j = tm.j0 >= 0 ? tm.j0 + row : a.cam_list[tm.cb + row];
         ((double2 *)rows)[idx] = ((const double2 *)(a.T + (int64_t)j * CAM_ROW))[piece];
+    }
+    // column al of T = blockdiag(R^T, A) (camera_frame_change) has three non-zero entries, in rows 0..2 (al < 3) or 3..5
+    for (int idx = tid; idx < nc * 18; idx += SCHUR_TILE_BLOCK) {
+        const int row = idx / 18, rest = idx - 18 * row, al = rest / 3, k = rest - 3 * al;
+        const int j = tm.j0 >= 0 ? tm.j0 + row : a.cam_list[tm.cb + row];
+        const double *src = a.T + (int64_t)j * CAM_ROW;
+        double v;
+        if (al < 3) v = src[3 * al + k];
+        else if (al == 3) v = k == 0 ? src[12] : (k == 1 ? -src[13] : 0.0);
+        else if (al == 4) v = src[3 + k];
+        else v = k == 2 ? 1.0 : 0.0;
+        Tt[idx] = v;
     }
     const int n_st = 18 * nc * (nc + 1);
     for (int idx = tid; idx < n_st; idx += SCHUR_TILE_BLOCK) St[idx] = 0.0;
@@ -617,6 +630,10 @@ __global__ void __launch_bounds__(SCHUR_TILE_BLOCK) k_schur_tile(SchurTileArgs a
             held = -1;
         }
     };
+    // Six lanes per observation: lane (o, al) forms column al of the observation's 3 x 6 block W = J_X^T J_cam and of
+    // Z = V'^-1 W (ten observations per trip of the wave).
+    const int lo = lane / 6, al = lane - 6 * lo;
+    const bool lane_on = lane < 60;
     for (int pt = wid; pt < np; pt += SCHUR_TILE_BLOCK / 64) {
         const int64_t i = p0 + pt;
         const int64_t eb = a.row_ptr[i];
@@ -629,13 +646,33 @@ __global__ void __launch_bounds__(SCHUR_TILE_BLOCK) k_schur_tile(SchurTileArgs a
         inv_sym3(a.V + 6 * i, a.lambda, Vi);
         const double x[3] = {a.X[3 * i], a.X[3 * i + 1], a.X[3 * i + 2]};
         // point x phi column w = dphi sum_obs J_X^T m (not kept by the J^T J pass: summed here, stored for the back-substitution)
-        double wp[3] = {0.0, 0.0, 0.0};
-        for (int o = lane; o < deg; o += 64) {
+        // what the lane keeps of its observation: the rows of J_X and the three entries of either row of G that meet
+        // the non-zero entries of column al of T (rows 0..2 of T for the centre, rows 3..5 for the angles)
+        double jx0[3] = {0.0, 0.0, 0.0}, jx1[3] = {0.0, 0.0, 0.0}, g0[3] = {0.0, 0.0, 0.0}, g1[3] = {0.0, 0.0, 0.0}, om0 = 0.0, om1 = 0.0;
+        int slot = 0;
+        const bool centre = al < 3;
+        auto load_obs = [&](int o) {
             const int64_t e = eb + o;
-            const int slot = (int)(a.opack[e] & 0xffffu);
+            slot = (int)(a.opack[e] & 0xffffu);
             const ObsJac ob = obs_jacobian(x, (const double2 *)(rows + slot * CAM_ROW), f, pcx, pcy, a.ouv[e]);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) wp[k] += ob.jx0[k] * ob.m0 + ob.jx1[k] * ob.m1;
+            for (int k = 0; k < 3; ++k) {
+                jx0[k] = ob.jx0[k], jx1[k] = ob.jx1[k];
+                g0[k] = centre ? ob.G0[k] : ob.G0[3 + k];
+                g1[k] = centre ? ob.G1[k] : ob.G1[3 + k];
+            }
+            om0 = ob.m0, om1 = ob.m1;
+        };
+        double wp[3] = {0.0, 0.0, 0.0};
+        for (int base = 0; base < deg; base += 10) {
+            const int o = base + lo;
+            if (lane_on && o < deg) {
+                load_obs(o);
+                if (al == 0) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) wp[k] += jx0[k] * om0 + jx1[k] * om1;
+                }
+            }
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k) wp[k] = dphi * wave_sum(wp[k]);
@@ -645,30 +682,18 @@ __global__ void __launch_bounds__(SCHUR_TILE_BLOCK) k_schur_tile(SchurTileArgs a
                               Vi[2] * wp[0] + Vi[4] * wp[1] + Vi[5] * wp[2]};
         const double zg[3] = {Vi[0] * gx[0] + Vi[1] * gx[1] + Vi[2] * gx[2], Vi[1] * gx[0] + Vi[3] * gx[1] + Vi[4] * gx[2],
                               Vi[2] * gx[0] + Vi[4] * gx[1] + Vi[5] * gx[2]};
-        for (int o = lane; o < deg; o += 64) {
-            const int64_t e = eb + o;
-            const int slot = (int)(a.opack[e] & 0xffffu);
-            const double *row = rows + slot * CAM_ROW;
-            ObsJac ob = obs_jacobian(x, (const double2 *)row, f, pcx, pcy, a.ouv[e]);
-            double Tm[6][6];
-            camera_frame_change(row, Tm);
-            double jc0[6], jc1[6];  // rows of J_cam = G T
-#pragma unroll
-            for (int al = 0; al < 6; ++al) {
-                double v0 = 0.0, v1 = 0.0;
-#pragma unroll
-                for (int mu = 0; mu < 6; ++mu) {
-                    v0 += ob.G0[mu] * Tm[mu][al];
-                    v1 += ob.G1[mu] * Tm[mu][al];
-                }
-                jc0[al] = v0;
-                jc1[al] = v1;
-            }
-#pragma unroll
-            for (int al = 0; al < 6; ++al) {
-                const double W0 = ob.jx0[0] * jc0[al] + ob.jx1[0] * jc1[al];
-                const double W1 = ob.jx0[1] * jc0[al] + ob.jx1[1] * jc1[al];
-                const double W2 = ob.jx0[2] * jc0[al] + ob.jx1[2] * jc1[al];
+        for (int base = 0; base < deg; base += 10) {
+            const int o = base + lo;
+            if (lane_on && o < deg) {
+                if (deg > 10) load_obs(o);      // (one trip: the observation of the first loop is still in registers)
+                // column al of J_cam = G T
+                const double *tc = Tt + (slot * 6 + al) * 3;
+                const double t0 = tc[0], t1 = tc[1], t2 = tc[2];
+                const double jc0 = g0[0] * t0 + g0[1] * t1 + g0[2] * t2;
+                const double jc1 = g1[0] * t0 + g1[1] * t1 + g1[2] * t2;
+                const double W0 = jx0[0] * jc0 + jx1[0] * jc1;
+                const double W1 = jx0[1] * jc0 + jx1[1] * jc1;
+                const double W2 = jx0[2] * jc0 + jx1[2] * jc1;
                 Wl[o * 18 + 0 * 6 + al] = W0;
                 Wl[o * 18 + 1 * 6 + al] = W1;
                 Wl[o * 18 + 2 * 6 + al] = W2;
@@ -679,8 +704,8 @@ __global__ void __launch_bounds__(SCHUR_TILE_BLOCK) k_schur_tile(SchurTileArgs a
                 const double rr = W0 * zg[0] + W1 * zg[1] + W2 * zg[2];
                 __hip_atomic_fetch_add(sphi_t + 6 * slot + al, -sphi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_add(rhs_t + 6 * slot + al, rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (al == 0) sl[o] = slot;
             }
-            sl[o] = slot;
         }
         if (lane == 0) {
             __hip_atomic_fetch_add(sc_t + 0, -(wp[0] * zw[0] + wp[1] * zw[1] + wp[2] * zw[2]), __ATOMIC_RELAXED,
@@ -1153,7 +1178,10 @@ int ba_schur_build_tracked(ba_problem *p, const double *X, double lambda, const 
     int64_t n, ld;
     ba_schur_dim(p->K, &n, &ld);
     const size_t lds = (size_t)4 * p->max_degree * 37 * sizeof(double);
-    const size_t lds_tile = p->tiled ? sizeof(double) * schur_tile_lds_doubles(p->cam_cap, p->max_degree) : ~(size_t)0;
+    const char *form = getenv("BA_SCHUR_FORM");      // 0: entry-per-lane pair loop; 1: pairs in registers, 16 waves; 2: 8 waves
+    const int which = form ? atoi(form) : 2;
+    const int tile_waves = which < 2 ? 16 : 8;
+    const size_t lds_tile = p->tiled ? sizeof(double) * schur_tile_lds_doubles(p->cam_cap, p->max_degree, tile_waves) : ~(size_t)0;
     const bool use_tile = p->tiled && p->tiles_worth && lds_tile <= 150 * 1024 && !getenv("BA_SCHUR_POINTS");
     if (!use_tile && lds > 160 * 1024 - 256) {
         set_error("ba_schur_build: a point has too many observations for the Schur kernel");
@@ -1188,8 +1216,8 @@ int ba_schur_build_tracked(ba_problem *p, const double *X, double lambda, const 
         ta.S = S;
         ta.rhs = rhs;
         ta.first = block_first;
-        const char *form = getenv("BA_SCHUR_FORM");      // 0: entry-per-lane pair loop; 1: pairs in registers, 16 waves; 2: 8 waves
-        const int which = form ? atoi(form) : 2;
+        // (the kernel needs about 200 registers: two waves per SIMD, one workgroup of 8 waves per CU whatever the LDS
+        // allows; builds held to 168 or 128 registers spill and run 1.3 to 3.5 times as long)
         auto launch = [&](auto kernel, int block) -> int {
             if (lds_tile > 64 * 1024)
                 BA_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tile));
