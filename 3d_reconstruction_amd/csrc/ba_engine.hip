@@ -833,17 +833,20 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_run_count(const uint32_t *__rest
 
 // Pass 2: every camera of the tile copies its observations, in point order, into its runs (order of
 // the runs and of the observations inside a run: see ba_runpass.h).
-// LDS: runs per camera (nc), first run of every batch of 8 cameras, then the tile's packed records.
+// Batches: full batches of 8 cameras, then the remaining cameras in batches of 4, 2 and 1 (binary_rest) - the point
+// records' bank pairs are distinct over the 16 lanes served together when those hold 8, 4, 2 or 1 cameras times 2, 4, 8
+// or 16 consecutive rounds, and not for 3, 5, 6 or 7 (a tile of 11 cameras as one batch of 8 and one of 3: the
+// J^T J pass 7 % slower than with 10 or 12 cameras).
+// LDS: runs per camera (cam_cap), runs before every camera (cam_cap + 1), then the tile's packed records.
 __global__ void __launch_bounds__(TILE_BLOCK) k_run_fill(const uint32_t *__restrict__ opack,
                                                          const double2 *__restrict__ ouv,
                                                          const TileMeta *__restrict__ meta,
                                                          const int64_t *__restrict__ run_ptr, int cam_cap, int pt_stride,
-                                                         uint32_t *__restrict__ rpack, double2 *__restrict__ ruv,
-                                                         uint2 *__restrict__ rrec) {
+                                                         int binary_rest, uint32_t *__restrict__ rpack,
+                                                         double2 *__restrict__ ruv, uint2 *__restrict__ rrec) {
     extern __shared__ int sm[];
-    int *hist = sm, *batch_first = sm + cam_cap;
-    const int n_batches_cap = (cam_cap + 7) / 8;
-    uint32_t *spack = (uint32_t *)(sm + cam_cap + n_batches_cap + 1);
+    int *hist = sm, *cam_first = sm + cam_cap;
+    uint32_t *spack = (uint32_t *)(sm + 2 * cam_cap + 1);
     const TileMeta tm = meta[blockIdx.x];
     const int n = tm.e1 - tm.e0, nc = tm.nc;
     const int64_t rb = run_ptr[blockIdx.x];
@@ -860,18 +863,31 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_run_fill(const uint32_t *__restr
     __syncthreads();
     if (threadIdx.x == 0) {
         int acc = 0;
-        for (int b = 0; 8 * b < nc; ++b) {
-            batch_first[b] = acc;
-            for (int c = 8 * b; c < nc && c < 8 * b + 8; ++c) acc += hist[c];
+        for (int c = 0; c < nc; ++c) {
+            cam_first[c] = acc;
+            acc += hist[c];
         }
+        cam_first[nc] = acc;
     }
     __syncthreads();
     for (int c = threadIdx.x; c < nc; c += TILE_BLOCK) {
-        const int b = c >> 3, c_lo = 8 * b, c_hi = min(nc, c_lo + 8);
+        int c_lo = c & ~7, c_hi = min(nc, c_lo + 8);
+        if (binary_rest && c_hi - c_lo < 8) {
+            int start = c_lo;
+            const int rest = nc - c_lo;
+            for (int sz = 4; sz >= 1; sz >>= 1)
+                if (rest & sz) {
+                    if (c < start + sz) {
+                        c_lo = start, c_hi = start + sz;
+                        break;
+                    }
+                    start += sz;
+                }
+        }
         const int my_runs = hist[c];
         // position of (c, rho): runs of the batch in earlier rounds + cameras before c still running in rho
         auto run_index = [&](int rho) {
-            int pos = batch_first[b];
+            int pos = cam_first[c_lo];
             for (int o = c_lo; o < c_hi; ++o) pos += min(hist[o], rho) + ((o < c && hist[o] > rho) ? 1 : 0);
             return pos;
         };
@@ -2262,7 +2278,7 @@ static int build_runs(ba_problem *p) {
     hipError_t e = hipMemcpy(&p->total_runs, p->run_ptr + nt, sizeof(int64_t), hipMemcpyDeviceToHost);
     hipFree(tile_sums);
     BA_HIP(e);
-    const size_t fill_lds = sizeof(int) * ((size_t)p->cam_cap + (p->cam_cap + 7) / 8 + 1) + sizeof(uint32_t) * (size_t)h_max_obs;
+    const size_t fill_lds = sizeof(int) * (2 * (size_t)p->cam_cap + 1) + sizeof(uint32_t) * (size_t)h_max_obs;
     if (fill_lds > 64 * 1024 || p->total_runs == 0 || p->cam_cap > RUN_MAX_CAMS || p->pt_cap > 65000) {   // leave the point-major tiles in charge
         hipFree(p->run_ptr);
         p->run_ptr = nullptr;
@@ -2279,7 +2295,8 @@ static int build_runs(ba_problem *p) {
     p->run_pt_stride = (p->pt_cap + RUN_LEN - 1) / RUN_LEN;
     while ((p->run_pt_stride & 3) != 2) ++p->run_pt_stride;   // 2 * odd, see pt_swz
     hipLaunchKernelGGL(k_run_fill, dim3(nt), dim3(TILE_BLOCK), fill_lds, 0, p->opack, p->ouv,
-                       (const TileMeta *)p->tile_meta, p->run_ptr, p->cam_cap, p->run_pt_stride, p->rpack, p->ruv, p->rrec);
+                       (const TileMeta *)p->tile_meta, p->run_ptr, p->cam_cap, p->run_pt_stride,
+                       getenv("BA_RUN_BATCHES_OF_8") ? 0 : 1, p->rpack, p->ruv, p->rrec);
     BA_HIP(hipGetLastError());
     // LDS accumulator space for the camera sums: two copies at the largest tile (one if that is too much), plus
     // whatever the workgroup's LDS allocation leaves unused: the LDS of a CU (160 KB) is handed out in granules of
