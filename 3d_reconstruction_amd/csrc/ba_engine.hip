@@ -2320,7 +2320,7 @@ static int build_runs(ba_problem *p) {
         return slots;
     };
     p->run_slots_grad = pick_slots(6, 3, budget / 2, "BA_CAM_REP", 1000);      // by LDS alone: more copies than that measured slower
-    p->run_slots_jtj = pick_slots(28, 9, 78 * 1024, "BA_CAM_REP_JTJ", p->compact ? 3 : 2);   // two workgroups per CU at least
+    p->run_slots_jtj = pick_slots(27, 9, 78 * 1024, "BA_CAM_REP_JTJ", p->compact ? 3 : 2);   // two workgroups per CU at least
     if (getenv("BA_VERBOSE"))
         fprintf(stderr, "[ba] runs: records=%s total=%lld (%.3f x nV/8) pt_stride=%d accumulator columns grad=%d jtj=%d (largest tile: %d cameras)\n",
                 p->compact ? "i16" : "f64", (long long)p->total_runs, (double)p->total_runs * RUN_LEN / (double)p->nV, p->run_pt_stride,

@@ -237,14 +237,14 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_jtj_tiled(JtjArgs a) {
 // with a = m0, b = m1, s = a^2 + b^2 and fi = f / q2 the rows of the camera-frame Jacobian are
 //   G0 = fi (-1, 0, a, q2 a b, -q2 (a^2 + 1), q2 b),   G1 = fi (0, -1, b, q2 (1 + b^2), -q2 a b, -q2 a),
 // and fi q2 = f, so every entry of G^T G, G^T r and G^T m is a constant (1, f, f^2) times a sum of monomials in
-// a, b weighted by 1, fi or fi^2.  The pass accumulates those 28 sums (CAMV_C) and k_jtj_finalize expands them
-// to the 33 classic ones: 46 instead of 61 instructions per observation on the camera side, 5 fewer registers.
+// a, b weighted by 1, fi or fi^2.  The pass accumulates those 27 sums (CAMV_C) and k_jtj_finalize expands them
+// to the 33 classic ones: 45 instead of 61 instructions per observation on the camera side, 6 fewer registers.
 //   0..5   fi r0, fi r1, -fi m.r, b m.r + r1, a m.r + r0, a r1 - b r0        (force; torque / (-f, f, f))
 //   6..9   w, w a, w b, w s                      with w = fi^2                 (centre x centre block)
 //   10..17 u, u a, u b, u a b, u a^2, u b^2, u b (s + 1), u a (s + 1)   with u = fi   (centre x angle, / f)
 //   18..24 a, b, s, a b (s + 2), a^2 b^2, (1 + b^2)^2, (1 + a^2)^2       (angle x angle, / f^2)
-//   25..27 fi s, b (s + 1), a (s + 1)                                      (camera x phi_x column)
-constexpr int CAMV_C = 28;
+//   25..26 b (s + 1), a (s + 1)                 (camera x phi_x column; its third entry fi s is sums 14 + 15)
+constexpr int CAMV_C = 27;
 struct JtjOp {
     // register budget: three waves per SIMD with the 8-byte records, two with the long ones
     static constexpr int NCV = CAMV_C, NPV = PTV, NPART = 3, NOUT = 2, WAVES_PER_EU = 2, WAVES_PER_EU_COMPACT = 3;
@@ -296,9 +296,8 @@ struct JtjOp {
         cv[22] += a2b2;
         cv[23] = fma(b1, b1, cv[23]);
         cv[24] = fma(a1, a1, cv[24]);
-        cv[25] = fma(fi, s, cv[25]);
-        cv[26] = fma(b, s1, cv[26]);
-        cv[27] = fma(a, s1, cv[27]);
+        cv[25] = fma(b, s1, cv[25]);
+        cv[26] = fma(a, s1, cv[26]);
 #pragma unroll
         for (int k = 0; k < 3; ++k) pv[k] = fma(o.jx0[k], r0, o.jx1[k] * r1);
         pv[3] = fma(o.jx0[0], o.jx0[0], o.jx1[0] * o.jx1[0]);
@@ -364,7 +363,7 @@ __global__ void __launch_bounds__(256) k_jtj_finalize(int64_t K, int n_partials,
     double Tm[6][6];
     camera_frame_change(row, Tm);
     double c[CAMV];
-    if (compact) {      // the 28 sums of JtjOp -> force, torque, upper triangle of the camera-frame block, phi column
+    if (compact) {      // the 27 sums of JtjOp -> force, torque, upper triangle of the camera-frame block, phi column
         double t[CAMV_C];
 #pragma unroll
         for (int k = 0; k < CAMV_C; ++k) t[k] = cam_sums[(int64_t)k * K + j];
@@ -398,9 +397,9 @@ __global__ void __launch_bounds__(256) k_jtj_finalize(int64_t K, int n_partials,
         c[26] = f2 * t[20];             // (5,5)
         c[27] = -t[11];
         c[28] = -t[12];
-        c[29] = t[25];
-        c[30] = f * t[26];
-        c[31] = -f * t[27];
+        c[29] = t[14] + t[15];
+        c[30] = f * t[25];
+        c[31] = -f * t[26];
         c[32] = 0.0;
     } else {
 #pragma unroll

@@ -4,12 +4,12 @@
 // points and camera rows staged in LDS.  Inside the tile the observations are regrouped by camera
 // and cut into RUNS of up to 8 observations of ONE camera; a thread owns a run.  That choice
 // decides where the two reductions of the pass happen:
-//   * per camera (6 sums for the gradient, 33 with the J^T J blocks): in the owning thread's
+//   * per camera (6 sums for the gradient, 27 with the J^T J blocks): in the owning thread's
 //     registers over the run, flushed once per run to the tile's LDS accumulators;
-//   * per point (3 / 12 sums): LDS atomics straight from the lanes.  Lanes of a wave hold
+//   * per point (3 / 9 sums): LDS atomics straight from the lanes.  Lanes of a wave hold
 //     different points of (mostly) the same camera, so the addresses differ and the atomics do not
 //     serialise - the opposite of the point-major order, where the lanes of a wave share cameras
-//     and the 6 / 33 camera sums collide.
+//     and the 6 / 27 camera sums collide.
 // Records are stored per tile as 8 planes of n_runs entries (plane k holds one observation of
 // every run), so lane r of a wave reads consecutive addresses in every plane: the record stream
 // stays fully coalesced although each thread walks its own run.  A camera's last run is padded
