@@ -8,10 +8,31 @@ namespace ba {
 // --------------------------------------------------------------------------------------------
 // small device helpers
 // --------------------------------------------------------------------------------------------
+// value of the lane N positions lower in the same 16-lane row (0.0 / 0 where there is none)
+template <int N>
+__device__ __forceinline__ int row_shr(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, 0x110 + N, 0xf, 0xf, true);
+}
+template <int N>
+__device__ __forceinline__ double row_shr(double v) {
+    const int lo = row_shr<N>(__double2loint(v)), hi = row_shr<N>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+// Sum over the 64 lanes of a wave (all of them active), the same value in every lane: running sums inside the four
+// 16-lane rows by DPP shifts, then the four row totals through scalar registers.  (Butterfly exchanges of doubles
+// go through the LDS crossbar, twelve dependent trips per sum.)
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
+    v += row_shr<1>(v);
+    v += row_shr<2>(v);
+    v += row_shr<4>(v);
+    v += row_shr<8>(v);
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 15), __builtin_amdgcn_readlane(lo, 15));
+    const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 31), __builtin_amdgcn_readlane(lo, 31));
+    const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 47), __builtin_amdgcn_readlane(lo, 47));
+    const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 63), __builtin_amdgcn_readlane(lo, 63));
+    return (r0 + r1) + (r2 + r3);
 }
 
 // 1 / x without the range scaling and fix-up of the IEEE division sequence (x is a depth along the
@@ -31,17 +52,6 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
     r = fma(0.5 * r, fma(-(x * r), r, 1.0), r);
     r = fma(0.5 * r, fma(-(x * r), r, 1.0), r);
     return r;
-}
-
-// value of the lane N positions lower in the same 16-lane row (0.0 / 0 where there is none)
-template <int N>
-__device__ __forceinline__ int row_shr(int v) {
-    return __builtin_amdgcn_update_dpp(0, v, 0x110 + N, 0xf, 0xf, true);
-}
-template <int N>
-__device__ __forceinline__ double row_shr(double v) {
-    const int lo = row_shr<N>(__double2loint(v)), hi = row_shr<N>(__double2hiint(v));
-    return __hiloint2double(hi, lo);
 }
 
 // R = Ry(ty) Rx(tx) Rz(tz), row-major (p2w:114-140)

@@ -492,7 +492,7 @@ __device__ __forceinline__ void inv_sym3(const double *V6, double lambda, double
                  g = V6[5] * (1.0 + lambda);
     const double A = d * g - e * e, Bc = c * e - b * g, Cc = b * e - c * d;
     const double det = a * A + b * Bc + c * Cc;
-    const double id = 1.0 / det;
+    const double id = fast_rcp(det);
     inv[0] = A * id;
     inv[1] = Bc * id;
     inv[2] = Cc * id;
@@ -719,23 +719,34 @@ __global__ void __launch_bounds__(SCHUR_TILE_BLOCK) k_schur_tile(SchurTileArgs a
         // with divisions inside the loop)
         // a point's observations usually come in the order of the camera slots: the pairs with slot >= slot' are then
         // the pairs o' <= o, and the inner loop needs no test (half its trips would fail it)
+        // (up to ten observations: the lanes' own pairs (po, po2 <= po) cover every neighbouring pair, and the slots
+        // they read for themselves answer the question; the lowest slot is then the first observation's)
         bool ascending = true;
-        for (int o = lane; o + 1 < deg; o += 64) ascending = ascending && sl[o] <= sl[o + 1];
+        const bool pair_on = po < deg;
+        int so = 0, so2 = 0;
+        if (deg <= 10) {
+            if (pair_on) so = sl[po], so2 = sl[po2];
+            ascending = !pair_on || so2 <= so;
+        } else {
+            for (int o = lane; o + 1 < deg; o += 64) ascending = ascending && sl[o] <= sl[o + 1];
+        }
         ascending = __all(ascending);
         if (a.first) {
-            int lowest = 0x7fffffff;
-            for (int o = lane; o < deg; o += 64) lowest = min(lowest, sl[o]);
+            if (deg <= 10 && ascending) {
+                const int lowest = __builtin_amdgcn_readfirstlane(so2);      // lane 0 holds the pair (0, 0)
+                if (pair_on && po2 == 0) atomicMin(low + so, lowest);
+            } else {
+                int lowest = 0x7fffffff;
+                for (int o = lane; o < deg; o += 64) lowest = min(lowest, sl[o]);
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) lowest = min(lowest, __shfl_xor(lowest, off));
-            for (int o = lane; o < deg; o += 64) atomicMin(low + sl[o], lowest);
+                for (int off = 32; off > 0; off >>= 1) lowest = min(lowest, __shfl_xor(lowest, off));
+                for (int o = lane; o < deg; o += 64) atomicMin(low + sl[o], lowest);
+            }
         }
         if (REG_PAIRS && deg <= 10 && ascending) {
-            const bool active = po < deg;
+            const bool active = pair_on;
             int blk = -1;
-            if (active) {
-                const int so = sl[po], so2 = sl[po2];
-                blk = so * (so + 1) / 2 + so2;
-            }
+            if (active) blk = so * (so + 1) / 2 + so2;
             const bool moved = active && held >= 0 && blk != held;
             if (__any(moved)) flush_pairs(moved);
             if (active) {
