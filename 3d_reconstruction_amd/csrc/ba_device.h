@@ -54,6 +54,20 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
     return r;
 }
 
+// the same over the lanes of one half of the wave (half 0: lanes 0..31, half 1: lanes 32..63; all 64 lanes active)
+__device__ __forceinline__ double half_wave_sum(double v, int half) {
+    v += row_shr<1>(v);
+    v += row_shr<2>(v);
+    v += row_shr<4>(v);
+    v += row_shr<8>(v);
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 15), __builtin_amdgcn_readlane(lo, 15));
+    const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 31), __builtin_amdgcn_readlane(lo, 31));
+    const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 47), __builtin_amdgcn_readlane(lo, 47));
+    const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 63), __builtin_amdgcn_readlane(lo, 63));
+    return half ? r2 + r3 : r0 + r1;
+}
+
 // R = Ry(ty) Rx(tx) Rz(tz), row-major (p2w:114-140)
 __device__ __forceinline__ void rotation_yxz(double tx, double ty, double tz, double *R, double *cz_out,
                                              double *sz_out) {

@@ -538,7 +538,7 @@ struct SchurTileArgs {
 
 __host__ __device__ inline size_t schur_tile_lds_doubles(int cam_cap, int max_deg, int waves = 16) {
     const size_t m = 6 * (size_t)cam_cap;
-    return (size_t)cam_cap * (CAM_ROW + 18) + 18 * (size_t)cam_cap * (cam_cap + 1) + 2 * m + 2 + (size_t)waves * max_deg * 37 +
+    return (size_t)cam_cap * (CAM_ROW + 18) + 18 * (size_t)cam_cap * (cam_cap + 1) + 2 * m + 2 + (size_t)waves * 2 * max_deg * 37 +
            (size_t)(cam_cap + 1) / 2;
 }
 
@@ -581,10 +581,10 @@ __global__ void __launch_bounds__(SCHUR_TILE_BLOCK) k_schur_tile(SchurTileArgs a
     double *sphi_t = St + 18 * (size_t)a.cam_cap * (a.cam_cap + 1);   // m
     double *rhs_t = sphi_t + 6 * a.cam_cap;               // m
     double *sc_t = rhs_t + 6 * a.cam_cap;                 // {phi-phi, rhs phi}
-    double *Wl = sc_t + 2 + (size_t)wid * a.max_deg * 37;
-    double *Zl = Wl + (size_t)a.max_deg * 18;
-    int *sl = (int *)(Zl + (size_t)a.max_deg * 18);
-    int *low = (int *)(sc_t + 2 + (size_t)(SCHUR_TILE_BLOCK / 64) * a.max_deg * 37);     // per camera slot: the lowest slot it shares a point with
+    // per wave: W (deg x 18), Z (deg x 18) and the slots (deg) of two points
+    const int scratch = a.max_deg * 37;
+    double *scratch0 = sc_t + 2 + (size_t)wid * 2 * scratch;
+    int *low = (int *)(sc_t + 2 + (size_t)(SCHUR_TILE_BLOCK / 64) * 2 * scratch);     // per camera slot: the lowest slot it shares a point with
     for (int idx = tid; idx < a.cam_cap; idx += SCHUR_TILE_BLOCK) low[idx] = 0x7fffffff;
     for (int idx = tid; idx < nc * (CAM_ROW / 2); idx += SCHUR_TILE_BLOCK) {
         const int row = idx / (CAM_ROW / 2), piece = idx - row * (CAM_ROW / 2);
@@ -629,164 +629,293 @@ __global__ void __launch_bounds__(SCHUR_TILE_BLOCK) k_schur_tile(SchurTileArgs a
             held = -1;
         }
     };
-    // Six lanes per observation: lane (o, al) forms column al of the observation's 3 x 6 block W = J_X^T J_cam and of
-    // Z = V'^-1 W (ten observations per trip of the wave).
+    // ---- first phase, one point per trip of the wave.  Six lanes per observation: lane (o, al) forms column al of the
+    // observation's 3 x 6 block W = J_X^T J_cam and of Z = V'^-1 W (ten observations per trip).
     const int lo = lane / 6, al = lane - 6 * lo;
     const bool lane_on = lane < 60;
-    for (int pt = wid; pt < np; pt += SCHUR_TILE_BLOCK / 64) {
-        const int64_t i = p0 + pt;
-        const int64_t eb = a.row_ptr[i];
-        const int deg = (int)(a.row_ptr[i + 1] - eb);
-        if (deg == 0) {
-            if (lane < 3) a.Xphi[3 * i + lane] = 0.0;
-            continue;
-        }
-        double Vi[6];
-        inv_sym3(a.V + 6 * i, a.lambda, Vi);
-        const double x[3] = {a.X[3 * i], a.X[3 * i + 1], a.X[3 * i + 2]};
-        // point x phi column w = dphi sum_obs J_X^T m (not kept by the J^T J pass: summed here, stored for the back-substitution)
-        // what the lane keeps of its observation: the rows of J_X and the three entries of either row of G that meet
-        // the non-zero entries of column al of T (rows 0..2 of T for the centre, rows 3..5 for the angles)
-        double jx0[3] = {0.0, 0.0, 0.0}, jx1[3] = {0.0, 0.0, 0.0}, g0[3] = {0.0, 0.0, 0.0}, g1[3] = {0.0, 0.0, 0.0}, om0 = 0.0, om1 = 0.0;
-        int slot = 0;
-        const bool centre = al < 3;
-        auto load_obs = [&](int o) {
-            const int64_t e = eb + o;
-            slot = (int)(a.opack[e] & 0xffffu);
-            const ObsJac ob = obs_jacobian(x, (const double2 *)(rows + slot * CAM_ROW), f, pcx, pcy, a.ouv[e]);
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                jx0[k] = ob.jx0[k], jx1[k] = ob.jx1[k];
-                g0[k] = centre ? ob.G0[k] : ob.G0[3 + k];
-                g1[k] = centre ? ob.G1[k] : ob.G1[3 + k];
-            }
-            om0 = ob.m0, om1 = ob.m1;
-        };
-        double wp[3] = {0.0, 0.0, 0.0};
-        for (int base = 0; base < deg; base += 10) {
-            const int o = base + lo;
-            if (lane_on && o < deg) {
-                load_obs(o);
-                if (al == 0) {
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) wp[k] += jx0[k] * om0 + jx1[k] * om1;
+    auto phase1_single = [&](int64_t i, int64_t eb, int deg, double *Wl, double *Zl, int *sl) {
+            double Vi[6];
+            inv_sym3(a.V + 6 * i, a.lambda, Vi);
+            const double x[3] = {a.X[3 * i], a.X[3 * i + 1], a.X[3 * i + 2]};
+            // point x phi column w = dphi sum_obs J_X^T m (not kept by the J^T J pass: summed here, stored for the back-substitution)
+            // what the lane keeps of its observation: the rows of J_X and the three entries of either row of G that meet
+            // the non-zero entries of column al of T (rows 0..2 of T for the centre, rows 3..5 for the angles)
+            double jx0[3] = {0.0, 0.0, 0.0}, jx1[3] = {0.0, 0.0, 0.0}, g0[3] = {0.0, 0.0, 0.0}, g1[3] = {0.0, 0.0, 0.0}, om0 = 0.0, om1 = 0.0;
+            int slot = 0;
+            const bool centre = al < 3;
+            auto load_obs = [&](int o) {
+                const int64_t e = eb + o;
+                slot = (int)(a.opack[e] & 0xffffu);
+                const ObsJac ob = obs_jacobian(x, (const double2 *)(rows + slot * CAM_ROW), f, pcx, pcy, a.ouv[e]);
+    #pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    jx0[k] = ob.jx0[k], jx1[k] = ob.jx1[k];
+                    g0[k] = centre ? ob.G0[k] : ob.G0[3 + k];
+                    g1[k] = centre ? ob.G1[k] : ob.G1[3 + k];
                 }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) wp[k] = dphi * wave_sum(wp[k]);
-        if (lane < 3) a.Xphi[3 * i + lane] = lane == 0 ? wp[0] : (lane == 1 ? wp[1] : wp[2]);
-        const double gx[3] = {a.gX[3 * i], a.gX[3 * i + 1], a.gX[3 * i + 2]};
-        const double zw[3] = {Vi[0] * wp[0] + Vi[1] * wp[1] + Vi[2] * wp[2], Vi[1] * wp[0] + Vi[3] * wp[1] + Vi[4] * wp[2],
-                              Vi[2] * wp[0] + Vi[4] * wp[1] + Vi[5] * wp[2]};
-        const double zg[3] = {Vi[0] * gx[0] + Vi[1] * gx[1] + Vi[2] * gx[2], Vi[1] * gx[0] + Vi[3] * gx[1] + Vi[4] * gx[2],
-                              Vi[2] * gx[0] + Vi[4] * gx[1] + Vi[5] * gx[2]};
-        for (int base = 0; base < deg; base += 10) {
-            const int o = base + lo;
-            if (lane_on && o < deg) {
-                if (deg > 10) load_obs(o);      // (one trip: the observation of the first loop is still in registers)
-                // column al of J_cam = G T
-                const double *tc = Tt + (slot * 6 + al) * 3;
+                om0 = ob.m0, om1 = ob.m1;
+            };
+            const double gx[3] = {a.gX[3 * i], a.gX[3 * i + 1], a.gX[3 * i + 2]};
+            const double zg[3] = {Vi[0] * gx[0] + Vi[1] * gx[1] + Vi[2] * gx[2], Vi[1] * gx[0] + Vi[3] * gx[1] + Vi[4] * gx[2],
+                                  Vi[2] * gx[0] + Vi[4] * gx[1] + Vi[5] * gx[2]};
+            // column al of W and Z of observation o into the wave's scratch, its share of the right-hand side
+            auto form_w = [&](int o, double &W0, double &W1, double &W2) {
+                const double *tc = Tt + (slot * 6 + al) * 3;        // column al of J_cam = G T
                 const double t0 = tc[0], t1 = tc[1], t2 = tc[2];
                 const double jc0 = g0[0] * t0 + g0[1] * t1 + g0[2] * t2;
                 const double jc1 = g1[0] * t0 + g1[1] * t1 + g1[2] * t2;
-                const double W0 = jx0[0] * jc0 + jx1[0] * jc1;
-                const double W1 = jx0[1] * jc0 + jx1[1] * jc1;
-                const double W2 = jx0[2] * jc0 + jx1[2] * jc1;
+                W0 = jx0[0] * jc0 + jx1[0] * jc1;
+                W1 = jx0[1] * jc0 + jx1[1] * jc1;
+                W2 = jx0[2] * jc0 + jx1[2] * jc1;
                 Wl[o * 18 + 0 * 6 + al] = W0;
                 Wl[o * 18 + 1 * 6 + al] = W1;
                 Wl[o * 18 + 2 * 6 + al] = W2;
                 Zl[o * 18 + 0 * 6 + al] = Vi[0] * W0 + Vi[1] * W1 + Vi[2] * W2;
                 Zl[o * 18 + 1 * 6 + al] = Vi[1] * W0 + Vi[3] * W1 + Vi[4] * W2;
                 Zl[o * 18 + 2 * 6 + al] = Vi[2] * W0 + Vi[4] * W1 + Vi[5] * W2;
-                const double sphi = W0 * zw[0] + W1 * zw[1] + W2 * zw[2];
                 const double rr = W0 * zg[0] + W1 * zg[1] + W2 * zg[2];
-                __hip_atomic_fetch_add(sphi_t + 6 * slot + al, -sphi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_add(rhs_t + 6 * slot + al, rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (al == 0) sl[o] = slot;
+            };
+            double wp[3] = {0.0, 0.0, 0.0}, zw[3];
+            auto finish_wp = [&]() {
+    #pragma unroll
+                for (int k = 0; k < 3; ++k) wp[k] = dphi * wave_sum(wp[k]);
+                if (lane < 3) a.Xphi[3 * i + lane] = lane == 0 ? wp[0] : (lane == 1 ? wp[1] : wp[2]);
+                zw[0] = Vi[0] * wp[0] + Vi[1] * wp[1] + Vi[2] * wp[2];
+                zw[1] = Vi[1] * wp[0] + Vi[3] * wp[1] + Vi[4] * wp[2];
+                zw[2] = Vi[2] * wp[0] + Vi[4] * wp[1] + Vi[5] * wp[2];
+            };
+            auto add_sphi = [&](double W0, double W1, double W2) {
+                const double sphi = W0 * zw[0] + W1 * zw[1] + W2 * zw[2];
+                __hip_atomic_fetch_add(sphi_t + 6 * slot + al, -sphi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            };
+            if (deg <= 10) {
+                // one trip: W and Z do not depend on the sums over the wave, so they are formed (and written) ahead of them
+                // and the sums' latency passes behind that work; only the phi column's entry waits for them
+                const bool on = lane_on && lo < deg;
+                double W0 = 0.0, W1 = 0.0, W2 = 0.0;
+                if (on) {
+                    load_obs(lo);
+                    if (al == 0) {
+    #pragma unroll
+                        for (int k = 0; k < 3; ++k) wp[k] = jx0[k] * om0 + jx1[k] * om1;
+                    }
+                    form_w(lo, W0, W1, W2);
+                }
+                finish_wp();
+                if (on) add_sphi(W0, W1, W2);
+            } else {
+                for (int base = 0; base < deg; base += 10) {
+                    const int o = base + lo;
+                    if (lane_on && o < deg) {
+                        load_obs(o);
+                        if (al == 0) {
+    #pragma unroll
+                            for (int k = 0; k < 3; ++k) wp[k] += jx0[k] * om0 + jx1[k] * om1;
+                        }
+                    }
+                }
+                finish_wp();
+                for (int base = 0; base < deg; base += 10) {
+                    const int o = base + lo;
+                    if (lane_on && o < deg) {
+                        load_obs(o);
+                        double W0, W1, W2;
+                        form_w(o, W0, W1, W2);
+                        add_sphi(W0, W1, W2);
+                    }
+                }
+            }
+            if (lane == 0) {
+                __hip_atomic_fetch_add(sc_t + 0, -(wp[0] * zw[0] + wp[1] * zw[1] + wp[2] * zw[2]), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(sc_t + 1, wp[0] * zg[0] + wp[1] * zg[1] + wp[2] * zg[2], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+    };
+    // ---- first phase, two points per trip (neither with more than ten observations): the chain of dependent steps a
+    // point costs - its data, the Jacobians, the sums over its observations, W and Z - is what the kernel waits for
+    // (two waves per SIMD, the pair blocks take the registers), so one pass through it serves points pt and pt + 1
+    // in the two halves of the wave: three lanes per observation, each forming two columns.
+    const int half = lane >> 5, l32 = lane & 31, lo3 = l32 / 3, ac = l32 - 3 * lo3;
+    auto phase1_pair = [&](int64_t iA, bool hasB, int64_t ebA, int degA, int64_t ebB, int degB) {
+        const int64_t i = iA + half;
+        const int64_t eb = half ? ebB : ebA;
+        const int deg = half ? degB : degA;
+        const bool exists = half == 0 || hasB;
+        double *Wl = scratch0 + half * scratch, *Zl = Wl + (size_t)a.max_deg * 18;
+        int *sl = (int *)(Zl + (size_t)a.max_deg * 18);
+        double V6[6] = {1.0, 0.0, 0.0, 1.0, 0.0, 1.0}, x[3] = {0.0, 0.0, 0.0}, gx[3] = {0.0, 0.0, 0.0};
+        if (deg > 0) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) V6[k] = a.V[6 * i + k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) x[k] = a.X[3 * i + k], gx[k] = a.gX[3 * i + k];
+        }
+        double Vi[6];
+        inv_sym3(V6, a.lambda, Vi);
+        const double zg[3] = {Vi[0] * gx[0] + Vi[1] * gx[1] + Vi[2] * gx[2], Vi[1] * gx[0] + Vi[3] * gx[1] + Vi[4] * gx[2],
+                              Vi[2] * gx[0] + Vi[4] * gx[1] + Vi[5] * gx[2]};
+        const bool on = l32 < 30 && lo3 < deg;
+        double wp[3] = {0.0, 0.0, 0.0}, W[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+        int slot = 0;
+        if (on) {
+            const int64_t e = eb + lo3;
+            slot = (int)(a.opack[e] & 0xffffu);
+            const ObsJac ob = obs_jacobian(x, (const double2 *)(rows + slot * CAM_ROW), f, pcx, pcy, a.ouv[e]);
+            if (ac == 0) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) wp[k] = ob.jx0[k] * ob.m0 + ob.jx1[k] * ob.m1;
+            }
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                const int c = 2 * ac + cc;
+                const bool centre = c < 3;
+                const double *tc = Tt + (slot * 6 + c) * 3;        // column c of J_cam = G T
+                const double t0 = tc[0], t1 = tc[1], t2 = tc[2];
+                const double jc0 = (centre ? ob.G0[0] : ob.G0[3]) * t0 + (centre ? ob.G0[1] : ob.G0[4]) * t1 +
+                                   (centre ? ob.G0[2] : ob.G0[5]) * t2;
+                const double jc1 = (centre ? ob.G1[0] : ob.G1[3]) * t0 + (centre ? ob.G1[1] : ob.G1[4]) * t1 +
+                                   (centre ? ob.G1[2] : ob.G1[5]) * t2;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) W[cc][k] = ob.jx0[k] * jc0 + ob.jx1[k] * jc1;
+                Wl[lo3 * 18 + 0 * 6 + c] = W[cc][0];
+                Wl[lo3 * 18 + 1 * 6 + c] = W[cc][1];
+                Wl[lo3 * 18 + 2 * 6 + c] = W[cc][2];
+                Zl[lo3 * 18 + 0 * 6 + c] = Vi[0] * W[cc][0] + Vi[1] * W[cc][1] + Vi[2] * W[cc][2];
+                Zl[lo3 * 18 + 1 * 6 + c] = Vi[1] * W[cc][0] + Vi[3] * W[cc][1] + Vi[4] * W[cc][2];
+                Zl[lo3 * 18 + 2 * 6 + c] = Vi[2] * W[cc][0] + Vi[4] * W[cc][1] + Vi[5] * W[cc][2];
+                const double rr = W[cc][0] * zg[0] + W[cc][1] * zg[1] + W[cc][2] * zg[2];
+                __hip_atomic_fetch_add(rhs_t + 6 * slot + c, rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (ac == 0) sl[lo3] = slot;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) wp[k] = dphi * half_wave_sum(wp[k], half);
+        if (exists && l32 < 3) a.Xphi[3 * i + l32] = l32 == 0 ? wp[0] : (l32 == 1 ? wp[1] : wp[2]);
+        const double zw[3] = {Vi[0] * wp[0] + Vi[1] * wp[1] + Vi[2] * wp[2], Vi[1] * wp[0] + Vi[3] * wp[1] + Vi[4] * wp[2],
+                              Vi[2] * wp[0] + Vi[4] * wp[1] + Vi[5] * wp[2]};
+        if (on) {
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                const double sphi = W[cc][0] * zw[0] + W[cc][1] * zw[1] + W[cc][2] * zw[2];
+                __hip_atomic_fetch_add(sphi_t + 6 * slot + 2 * ac + cc, -sphi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
-        if (lane == 0) {
+        if (l32 == 0 && deg > 0) {
             __hip_atomic_fetch_add(sc_t + 0, -(wp[0] * zw[0] + wp[1] * zw[1] + wp[2] * zw[2]), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_fetch_add(sc_t + 1, wp[0] * zg[0] + wp[1] * zg[1] + wp[2] * zg[2], __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
-        // all ordered pairs (o, o') of the point's observations with slot >= slot': the pair loop is
-        // wave-uniform, lane (al, be) < 36 owns one entry of the 6 x 6 block (no index arithmetic
-        // with divisions inside the loop)
-        // a point's observations usually come in the order of the camera slots: the pairs with slot >= slot' are then
-        // the pairs o' <= o, and the inner loop needs no test (half its trips would fail it)
-        // (up to ten observations: the lanes' own pairs (po, po2 <= po) cover every neighbouring pair, and the slots
-        // they read for themselves answer the question; the lowest slot is then the first observation's)
-        bool ascending = true;
-        const bool pair_on = po < deg;
-        int so = 0, so2 = 0;
-        if (deg <= 10) {
-            if (pair_on) so = sl[po], so2 = sl[po2];
-            ascending = !pair_on || so2 <= so;
-        } else {
-            for (int o = lane; o + 1 < deg; o += 64) ascending = ascending && sl[o] <= sl[o + 1];
-        }
-        ascending = __all(ascending);
-        if (a.first) {
-            if (deg <= 10 && ascending) {
-                const int lowest = __builtin_amdgcn_readfirstlane(so2);      // lane 0 holds the pair (0, 0)
-                if (pair_on && po2 == 0) atomicMin(low + so, lowest);
+    };
+    // ---- second phase: the pairs of one point's observations
+    auto pair_phase = [&](int deg, const double *Wl, const double *Zl, const int *sl) {
+            // all ordered pairs (o, o') of the point's observations with slot >= slot': the pair loop is
+            // wave-uniform, lane (al, be) < 36 owns one entry of the 6 x 6 block (no index arithmetic
+            // with divisions inside the loop)
+            // a point's observations usually come in the order of the camera slots: the pairs with slot >= slot' are then
+            // the pairs o' <= o, and the inner loop needs no test (half its trips would fail it)
+            // (up to ten observations: the lanes' own pairs (po, po2 <= po) cover every neighbouring pair, and the slots
+            // they read for themselves answer the question; the lowest slot is then the first observation's)
+            bool ascending = true;
+            const bool pair_on = po < deg;
+            int so = 0, so2 = 0;
+            if (deg <= 10) {
+                if (pair_on) so = sl[po], so2 = sl[po2];
+                ascending = !pair_on || so2 <= so;
             } else {
-                int lowest = 0x7fffffff;
-                for (int o = lane; o < deg; o += 64) lowest = min(lowest, sl[o]);
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) lowest = min(lowest, __shfl_xor(lowest, off));
-                for (int o = lane; o < deg; o += 64) atomicMin(low + sl[o], lowest);
+                for (int o = lane; o + 1 < deg; o += 64) ascending = ascending && sl[o] <= sl[o + 1];
             }
-        }
-        if (REG_PAIRS && deg <= 10 && ascending) {
-            const bool active = pair_on;
-            int blk = -1;
-            if (active) blk = so * (so + 1) / 2 + so2;
-            const bool moved = active && held >= 0 && blk != held;
-            if (__any(moved)) flush_pairs(moved);
-            if (active) {
-                held = blk;
-                const double *wr = Wl + po * 18, *zr = Zl + po2 * 18;
-#pragma unroll
-                for (int mm = 0; mm < 3; ++mm) {
-                    double w[6], z[6];
-#pragma unroll
-                    for (int h = 0; h < 3; ++h) {
-                        const double2 wv = *(const double2 *)(wr + 6 * mm + 2 * h), zv = *(const double2 *)(zr + 6 * mm + 2 * h);
-                        w[2 * h] = wv.x, w[2 * h + 1] = wv.y;
-                        z[2 * h] = zv.x, z[2 * h + 1] = zv.y;
+            ascending = __all(ascending);
+            if (a.first) {
+                if (deg <= 10 && ascending) {
+                    const int lowest = __builtin_amdgcn_readfirstlane(so2);      // lane 0 holds the pair (0, 0)
+                    if (pair_on && po2 == 0) atomicMin(low + so, lowest);
+                } else {
+                    int lowest = 0x7fffffff;
+                    for (int o = lane; o < deg; o += 64) lowest = min(lowest, sl[o]);
+    #pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) lowest = min(lowest, __shfl_xor(lowest, off));
+                    for (int o = lane; o < deg; o += 64) atomicMin(low + sl[o], lowest);
+                }
+            }
+            if (REG_PAIRS && deg <= 10 && ascending) {
+                const bool active = pair_on;
+                int blk = -1;
+                if (active) blk = so * (so + 1) / 2 + so2;
+                const bool moved = active && held >= 0 && blk != held;
+                if (__any(moved)) flush_pairs(moved);
+                if (active) {
+                    held = blk;
+                    const double *wr = Wl + po * 18, *zr = Zl + po2 * 18;
+    #pragma unroll
+                    for (int mm = 0; mm < 3; ++mm) {
+                        double w[6], z[6];
+    #pragma unroll
+                        for (int h = 0; h < 3; ++h) {
+                            const double2 wv = *(const double2 *)(wr + 6 * mm + 2 * h), zv = *(const double2 *)(zr + 6 * mm + 2 * h);
+                            w[2 * h] = wv.x, w[2 * h + 1] = wv.y;
+                            z[2 * h] = zv.x, z[2 * h + 1] = zv.y;
+                        }
+    #pragma unroll
+                        for (int al = 0; al < 6; ++al)
+    #pragma unroll
+                            for (int be = 0; be < 6; ++be) acc[6 * al + be] = fma(-w[al], z[be], acc[6 * al + be]);
                     }
-#pragma unroll
-                    for (int al = 0; al < 6; ++al)
-#pragma unroll
-                        for (int be = 0; be < 6; ++be) acc[6 * al + be] = fma(-w[al], z[be], acc[6 * al + be]);
+                }
+            } else {
+            if (REG_PAIRS && __any(held >= 0)) flush_pairs(held >= 0);
+            if (lane < 36) {
+                const int al = lane / 6, be = lane - 6 * al;
+                for (int o = 0; o < deg; ++o) {
+                    const int so = sl[o];
+                    const double w0 = Wl[o * 18 + al], w1 = Wl[o * 18 + 6 + al], w2 = Wl[o * 18 + 12 + al];
+                    double *dst = St + (size_t)(so * (so + 1) / 2) * 36 + lane;
+                    const int o2_end = ascending ? o + 1 : deg;
+                    for (int o2 = 0; o2 < o2_end; ++o2) {
+                        const int so2 = sl[o2];
+                        if (so < so2) continue;
+                        const double v = w0 * Zl[o2 * 18 + be] + w1 * Zl[o2 * 18 + 6 + be] + w2 * Zl[o2 * 18 + 12 + be];
+                        __hip_atomic_fetch_add(dst + 36 * so2, -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
                 }
             }
-        } else {
-        if (REG_PAIRS && __any(held >= 0)) flush_pairs(held >= 0);
-        if (lane < 36) {
-            const int al = lane / 6, be = lane - 6 * al;
-            for (int o = 0; o < deg; ++o) {
-                const int so = sl[o];
-                const double w0 = Wl[o * 18 + al], w1 = Wl[o * 18 + 6 + al], w2 = Wl[o * 18 + 12 + al];
-                double *dst = St + (size_t)(so * (so + 1) / 2) * 36 + lane;
-                const int o2_end = ascending ? o + 1 : deg;
-                for (int o2 = 0; o2 < o2_end; ++o2) {
-                    const int so2 = sl[o2];
-                    if (so < so2) continue;
-                    const double v = w0 * Zl[o2 * 18 + be] + w1 * Zl[o2 * 18 + 6 + be] + w2 * Zl[o2 * 18 + 12 + be];
-                    __hip_atomic_fetch_add(dst + 36 * so2, -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
             }
-        }
-        }
+    };
+    auto lanes_sync = [&]() {
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
+    };
+    constexpr int PT_STEP = SCHUR_TILE_BLOCK / 64;
+    for (int pt = 2 * wid; pt < np; pt += 2 * PT_STEP) {
+        const int64_t iA = p0 + pt;
+        const bool hasB = pt + 1 < np;
+        const int64_t ebA = a.row_ptr[iA], ebB = a.row_ptr[iA + 1];
+        const int degA = (int)(ebB - ebA), degB = hasB ? (int)(a.row_ptr[iA + 2] - ebB) : 0;
+        double *W0 = scratch0, *Z0 = W0 + (size_t)a.max_deg * 18, *W1 = scratch0 + scratch, *Z1 = W1 + (size_t)a.max_deg * 18;
+        int *s0 = (int *)(Z0 + (size_t)a.max_deg * 18), *s1 = (int *)(Z1 + (size_t)a.max_deg * 18);
+        if (degA <= 10 && degB <= 10) {
+            phase1_pair(iA, hasB, ebA, degA, ebB, degB);
+            lanes_sync();
+            if (degA > 0) pair_phase(degA, W0, Z0, s0);
+            if (degB > 0) pair_phase(degB, W1, Z1, s1);
+            lanes_sync();
+        } else {
+            for (int q = 0; q < (hasB ? 2 : 1); ++q) {
+                const int64_t i = iA + q, eb = q ? ebB : ebA;
+                const int deg = q ? degB : degA;
+                if (deg == 0) {
+                    if (lane < 3) a.Xphi[3 * i + lane] = 0.0;
+                    continue;
+                }
+                phase1_single(i, eb, deg, W0, Z0, s0);
+                lanes_sync();
+                pair_phase(deg, W0, Z0, s0);
+                lanes_sync();
+            }
+        }
     }
     if (REG_PAIRS) flush_pairs(held >= 0);
     __syncthreads();

@@ -272,6 +272,59 @@ def test_schur_tile_kernel_matches_point_kernel_and_dense(ba):
     sh.close()
 
 
+def test_schur_tile_kernel_mixed_track_lengths(ba):
+    """Tracks of 0 to 14 observations side by side: the tile kernel takes two points per trip when neither has more than
+    ten observations and one at a time otherwise; a point nobody sees contributes nothing.  Same S, rhs and
+    point x phi column as the one-wave-per-point kernel, and as the dense normal equations."""
+    import os
+    sc = ba.scenes.orbit_scene(N=500, K=300, track_len=14, seed=3)
+    rng = np.random.default_rng(8)
+    keep = rng.random(sc['i'].size) < rng.choice([1.0, 0.8, 0.45, 0.0], size=500, p=[0.4, 0.3, 0.25, 0.05])[sc['i']]
+    keep |= sc['i'] < 3          # the first points keep all 14
+    i, j, uv = sc['i'][keep], sc['j'][keep], sc['uv'][keep]
+    deg = np.bincount(i, minlength=500)
+    assert deg.max() == 14 and (deg == 0).any() and ((deg > 0) & (deg <= 10)).any() and (deg > 10).sum() > 20
+    N, K = 500, 300
+    os.environ['BA_TILE_OBS'] = '256'
+    try:
+        sh = ba.engine.Shard(i, j, uv, N, K, sc['W'], sc['H'], DEV)
+    finally:
+        os.environ.pop('BA_TILE_OBS', None)
+    sh.set_params(sc['X_0'], sc['C_0'], sc['Theta_0'], sc['phi_x_0'])
+    sh.eval_jtj()
+    lam = 1e-2
+    lib, p = sh.lib, ba.engine.ptr
+    def build():
+        ba.engine.check(lib.ba_schur_build(sh.handle, p(sh.X), lam, p(sh.V), p(sh.Xphi), p(sh.gX), p(sh.B), p(sh.bphi),
+                                           p(sh.hphi), p(sh.gC), p(sh.gTheta), p(sh.gphi), 1, p(sh.S), p(sh.rhs), None))
+        n = sh.n_red
+        return torch.tril(sh.S[:n, :n]).cpu().numpy(), sh.rhs[:n].cpu().numpy(), sh.Xphi.cpu().numpy().copy()
+    S_tile, rhs_tile, xphi_tile = build()
+    os.environ['BA_SCHUR_POINTS'] = '1'
+    try:
+        S_pts, rhs_pts, xphi_pts = build()
+    finally:
+        os.environ.pop('BA_SCHUR_POINTS', None)
+    assert np.abs(S_tile - S_pts).max() <= 1e-11 * np.abs(S_pts).max()
+    assert np.abs(rhs_tile - rhs_pts).max() <= 1e-11 * np.abs(rhs_pts).max()
+    assert np.abs(xphi_tile - xphi_pts).max() <= 1e-11 * np.abs(xphi_pts).max()
+    # the reduced system against the dense normal equations (points nobody sees have no unknowns there)
+    seen = deg > 0
+    r, J = orc.dense_jacobian(sc['X_0'], sc['C_0'], sc['Theta_0'], sc['phi_x_0'], sc['W'], sc['H'], i, j, uv)
+    H, g = J.T @ J, J.T @ r
+    H = H + lam * np.diag(np.diag(H))
+    pts = np.repeat(seen, 3)
+    Hpp, Hpc, Hcc = H[:3 * N][:, :3 * N][np.ix_(pts, pts)], H[:3 * N][pts][:, 3 * N:], H[3 * N:, 3 * N:]
+    S_ref = Hcc - Hpc.T @ np.linalg.solve(Hpp, Hpc)
+    rhs_ref = -(g[3 * N:] - Hpc.T @ np.linalg.solve(Hpp, g[:3 * N][pts]))
+    # the library orders the camera unknowns [C_j | Theta_j] per camera, the dense system [all C | all Theta | phi]
+    perm = np.r_[[3 * jj + k if k < 3 else 3 * K + 3 * jj + k - 3 for jj in range(K) for k in range(6)], 6 * K]
+    S_ref, rhs_ref = S_ref[np.ix_(perm, perm)], rhs_ref[perm]
+    assert np.abs(S_tile - np.tril(S_ref)).max() <= 1e-9 * np.abs(S_ref).max()
+    assert np.abs(rhs_tile - rhs_ref).max() <= 1e-9 * np.abs(rhs_ref).max()
+    sh.close()
+
+
 def _numpy_lm(sc, iters, lam):
     """The same LM loop with dense NumPy normal equations (reference for the trajectory)."""
     X, C, Th = orc.align_scene(sc['X_0'], sc['C_0'], Theta=sc['Theta_0'])
