@@ -54,7 +54,21 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
     return r;
 }
 
-// the same over the lanes of one half of the wave (half 0: lanes 0..31, half 1: lanes 32..63; all 64 lanes active)
+// maximum over the 64 lanes of a wave of values >= 0 (lanes a row shift has no source for contribute 0)
+__device__ __forceinline__ double wave_max_nonneg(double v) {
+    v = fmax(v, row_shr<1>(v));
+    v = fmax(v, row_shr<2>(v));
+    v = fmax(v, row_shr<4>(v));
+    v = fmax(v, row_shr<8>(v));
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 15), __builtin_amdgcn_readlane(lo, 15));
+    const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 31), __builtin_amdgcn_readlane(lo, 31));
+    const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 47), __builtin_amdgcn_readlane(lo, 47));
+    const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 63), __builtin_amdgcn_readlane(lo, 63));
+    return fmax(fmax(r0, r1), fmax(r2, r3));
+}
+
+// wave_sum over the lanes of one half of the wave (half 0: lanes 0..31, half 1: lanes 32..63; all 64 lanes active)
 __device__ __forceinline__ double half_wave_sum(double v, int half) {
     v += row_shr<1>(v);
     v += row_shr<2>(v);

@@ -2154,9 +2154,7 @@ __global__ void __launch_bounds__(256) k_camera_step_free(CameraStep a, Finalize
     // ---- longest baseline from camera 0 (p2w:322-326): maximum of the squared lengths, one atomic per workgroup
     // (atomics on one address are served one after the other at the memory side, some 16 ns each: one per wave is
     // 2 us at 2 000 cameras and was 20 us at 20 000)
-    double best = (own && cc == 0) ? n0 * n0 + n1 * n1 + n2 * n2 : 0.0;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) best = fmax(best, __shfl_xor(best, off));
+    double best = wave_max_nonneg((own && cc == 0) ? n0 * n0 + n1 * n1 + n2 * n2 : 0.0);
     if ((tid & 63) == 0) red_best[tid >> 6] = best;
     __syncthreads();
     if (tid == 0) {
