@@ -36,9 +36,18 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // 1 / x without the range scaling and fix-up of the IEEE division sequence (x is a depth along the
-// optical axis: far from the ends of the exponent range): hardware estimate and two Newton steps,
-// relative error of a few 1e-16
+// optical axis, a determinant, a moment's root: within the range of a float): single-precision hardware estimate
+// (2^-23; the double-precision estimate is no better than that for the two steps that follow, and slower: the
+// J^T J pass -2 %) and two Newton steps, relative error of a few 1e-16
 __device__ __forceinline__ double fast_rcp(double x) {
+    double r = (double)__builtin_amdgcn_rcpf((float)x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+// the same with the double-precision estimate: for arguments that may leave the range of a float (a determinant)
+__device__ __forceinline__ double fast_rcp_wide(double x) {
     double r = __builtin_amdgcn_rcp(x);
     r = fma(fma(-x, r, 1.0), r, r);
     r = fma(fma(-x, r, 1.0), r, r);

@@ -492,7 +492,7 @@ __device__ __forceinline__ void inv_sym3(const double *V6, double lambda, double
                  g = V6[5] * (1.0 + lambda);
     const double A = d * g - e * e, Bc = c * e - b * g, Cc = b * e - c * d;
     const double det = a * A + b * Bc + c * Cc;
-    const double id = fast_rcp(det);
+    const double id = fast_rcp_wide(det);
     inv[0] = A * id;
     inv[1] = Bc * id;
     inv[2] = Cc * id;
