@@ -2120,9 +2120,15 @@ __global__ void __launch_bounds__(256) k_camera_step_free(CameraStep a, Finalize
     for (int p = 0; p < 3; ++p)
 #pragma unroll
         for (int q = 0; q < 3; ++q) Rn[3 * p + q] = R0[p] * R[q] + R0[3 + p] * R[3 + q] + R0[6 + p] * R[6 + q];
-    const double Cx = sqrt(Rn[3] * Rn[3] + Rn[4] * Rn[4]);   // get_rotations (p2w:260-266)
-    const double ay = cc == 0 ? -Rn[5] : (cc == 1 ? Rn[2] / Cx : Rn[3] / Cx);
-    const double ax = cc == 0 ? Cx : (cc == 1 ? Rn[8] / Cx : Rn[4] / Cx);
+    // get_rotations (p2w:260-266): theta_x = atan2(-R12, Cx), theta_y = atan2(R02 / Cx, R22 / Cx), theta_z =
+    // atan2(R10 / Cx, R11 / Cx) with Cx = cos(theta_x) = |(R10, R11)| > 0.  The common factor 1 / Cx does not change
+    // an angle, so the two quotients per angle are left out, and Cx comes from the Newton reciprocal square root
+    // (this kernel is one chain of dependent fp64 routines per camera: the square root and the four divisions were
+    // 100 instructions of it)
+    const double c2 = Rn[3] * Rn[3] + Rn[4] * Rn[4];
+    const double iCx = fast_rsqrt(c2), Cx = c2 * iCx;
+    const double ay = cc == 0 ? -Rn[5] : (cc == 1 ? Rn[2] : Rn[3]);
+    const double ax = cc == 0 ? Cx : (cc == 1 ? Rn[8] : Rn[4]);
     const double th_g = atan2(ay, ax);
     const double n_own = cc == 0 ? n0 : (cc == 1 ? n1 : n2);
     if (writes) {
@@ -2136,8 +2142,8 @@ __global__ void __launch_bounds__(256) k_camera_step_free(CameraStep a, Finalize
 #pragma unroll
         for (int k = 0; k < 3; ++k) row[3 * cc + k] = Rn[3 * cc + k];
         if (cc == 0) {
-            row[12] = Rn[4] / Cx;  // cos(theta_z), p2w:674
-            row[13] = Rn[3] / Cx;  // sin(theta_z), p2w:675
+            row[12] = Rn[4] * iCx;  // cos(theta_z), p2w:674
+            row[13] = Rn[3] * iCx;  // sin(theta_z), p2w:675
         }
     }
     if (own0 && cc == 0) {
