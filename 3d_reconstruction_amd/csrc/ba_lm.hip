@@ -538,8 +538,9 @@ struct SchurTileArgs {
 
 __host__ __device__ inline size_t schur_tile_lds_doubles(int cam_cap, int max_deg, int waves = 16) {
     const size_t m = 6 * (size_t)cam_cap;
-    return (size_t)cam_cap * (CAM_ROW + 18) + 18 * (size_t)cam_cap * (cam_cap + 1) + 2 * m + 2 + (size_t)waves * 2 * max_deg * 37 +
-           (size_t)(cam_cap + 1) / 2;
+    // per wave: W, Z and the slots of one point of any degree and of a second one of at most ten observations
+    return (size_t)cam_cap * (CAM_ROW + 18) + 18 * (size_t)cam_cap * (cam_cap + 1) + 2 * m + 2 +
+           (size_t)waves * (max_deg + (max_deg < 10 ? max_deg : 10)) * 37 + (size_t)(cam_cap + 1) / 2;
 }
 
 // The block profile of the reduced system before any point has contributed: every row starts at its own camera's
@@ -581,10 +582,12 @@ __global__ void __launch_bounds__(SCHUR_TILE_BLOCK) k_schur_tile(SchurTileArgs a
     double *sphi_t = St + 18 * (size_t)a.cam_cap * (a.cam_cap + 1);   // m
     double *rhs_t = sphi_t + 6 * a.cam_cap;               // m
     double *sc_t = rhs_t + 6 * a.cam_cap;                 // {phi-phi, rhs phi}
-    // per wave: W (deg x 18), Z (deg x 18) and the slots (deg) of two points
-    const int scratch = a.max_deg * 37;
-    double *scratch0 = sc_t + 2 + (size_t)wid * 2 * scratch;
-    int *low = (int *)(sc_t + 2 + (size_t)(SCHUR_TILE_BLOCK / 64) * 2 * scratch);     // per camera slot: the lowest slot it shares a point with
+    // per wave: W (deg x 18), Z (deg x 18) and the slots (deg) of one point of any degree, then the same for a second
+    // point of at most ten observations (the layout of either: W | Z | slots with max_deg resp. deg2 rows)
+    const int deg2 = a.max_deg < 10 ? a.max_deg : 10;
+    const int scratch = a.max_deg * 37, scratch_wave = scratch + deg2 * 37;
+    double *scratch0 = sc_t + 2 + (size_t)wid * scratch_wave;
+    int *low = (int *)(sc_t + 2 + (size_t)(SCHUR_TILE_BLOCK / 64) * scratch_wave);     // per camera slot: the lowest slot it shares a point with
     for (int idx = tid; idx < a.cam_cap; idx += SCHUR_TILE_BLOCK) low[idx] = 0x7fffffff;
     for (int idx = tid; idx < nc * (CAM_ROW / 2); idx += SCHUR_TILE_BLOCK) {
         const int row = idx / (CAM_ROW / 2), piece = idx - row * (CAM_ROW / 2);
@@ -744,8 +747,9 @@ __global__ void __launch_bounds__(SCHUR_TILE_BLOCK) k_schur_tile(SchurTileArgs a
         const int64_t eb = half ? ebB : ebA;
         const int deg = half ? degB : degA;
         const bool exists = half == 0 || hasB;
-        double *Wl = scratch0 + half * scratch, *Zl = Wl + (size_t)a.max_deg * 18;
-        int *sl = (int *)(Zl + (size_t)a.max_deg * 18);
+        const int n_rows = half ? deg2 : a.max_deg;
+        double *Wl = scratch0 + half * scratch, *Zl = Wl + (size_t)n_rows * 18;
+        int *sl = (int *)(Zl + (size_t)n_rows * 18);
         double V6[6] = {1.0, 0.0, 0.0, 1.0, 0.0, 1.0}, x[3] = {0.0, 0.0, 0.0}, gx[3] = {0.0, 0.0, 0.0};
         if (deg > 0) {
 #pragma unroll
@@ -894,8 +898,8 @@ __global__ void __launch_bounds__(SCHUR_TILE_BLOCK) k_schur_tile(SchurTileArgs a
         const bool hasB = pt + 1 < np;
         const int64_t ebA = a.row_ptr[iA], ebB = a.row_ptr[iA + 1];
         const int degA = (int)(ebB - ebA), degB = hasB ? (int)(a.row_ptr[iA + 2] - ebB) : 0;
-        double *W0 = scratch0, *Z0 = W0 + (size_t)a.max_deg * 18, *W1 = scratch0 + scratch, *Z1 = W1 + (size_t)a.max_deg * 18;
-        int *s0 = (int *)(Z0 + (size_t)a.max_deg * 18), *s1 = (int *)(Z1 + (size_t)a.max_deg * 18);
+        double *W0 = scratch0, *Z0 = W0 + (size_t)a.max_deg * 18, *W1 = scratch0 + scratch, *Z1 = W1 + (size_t)deg2 * 18;
+        int *s0 = (int *)(Z0 + (size_t)a.max_deg * 18), *s1 = (int *)(Z1 + (size_t)deg2 * 18);
         if (degA <= 10 && degB <= 10) {
             phase1_pair(iA, hasB, ebA, degA, ebB, degB);
             lanes_sync();
