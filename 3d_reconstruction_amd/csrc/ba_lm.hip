@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(TILE_BLOCK) k_jtj_tiled(JtjArgs a) {
 constexpr int CAMV_C = 27;
 struct JtjOp {
     // register budget: three waves per SIMD with the 8-byte records, two with the long ones
-    static constexpr int NCV = CAMV_C, NPV = PTV, NPART = 3, NOUT = 2, WAVES_PER_EU = 2, WAVES_PER_EU_COMPACT = 3;
+    static constexpr int NCV = CAMV_C, NPV = PTV, NPART = 2, NOUT = 2, WAVES_PER_EU = 2, WAVES_PER_EU_COMPACT = 3;
     static constexpr int MOMENT_PREFETCH = 0;      // this pass never carries the point update
     // per-point sums: gradient (3) -> gX, V upper triangle (6) -> V
     __host__ __device__ static constexpr int out_width(int o) { return o == 1 ? 6 : 3; }
@@ -261,7 +261,7 @@ struct JtjOp {
         : f(scalars[SC_F]), pcx(scalars[SC_CX] - pix_shift), pcy(scalars[SC_CY] - pix_shift) {}
     __device__ __forceinline__ double cv_flush(int, double v) const { return v; }
     __device__ __forceinline__ void obs(bool valid, const double (&x)[3], const double2 (&rw)[6], double2 uv,
-                                        double (&cv)[CAMV_C], double (&pv)[PTV], double (&part)[3]) const {
+                                        double (&cv)[CAMV_C], double (&pv)[PTV], double (&part)[2]) const {
         const ObsJac o = obs_jacobian<true>(x, rw, f, pcx, pcy, uv, valid);    // m = 0, fi = 0 for a zero-weight record
         const double r0 = valid ? o.r0 : 0.0, r1 = valid ? o.r1 : 0.0, vm = valid ? 1.0 : 0.0;
         const double a = o.m0, b = o.m1, fi = o.fi;
@@ -269,8 +269,7 @@ struct JtjOp {
         const double a1 = vm + a2, b1 = vm + b2, a2b2 = a2 * b2, w = fi * fi, ua = fi * a, ub = fi * b;
         const double mr = fma(a, r0, b * r1);
         part[0] = fma(r0, r0, fma(r1, r1, part[0]));
-        part[1] += mr;
-        part[2] += s;
+        part[1] += mr;      // (the phi x phi entry, sum of m.m, is the sum over the cameras of sum 20)
         cv[0] = fma(fi, r0, cv[0]);
         cv[1] = fma(fi, r1, cv[1]);
         cv[2] = fma(-fi, mr, cv[2]);
@@ -342,9 +341,17 @@ __global__ void __launch_bounds__(256) k_jtj_finalize(int64_t K, int n_partials,
     if (blockIdx.x == 0) {
         __shared__ double red[3][4];
         double acc[3] = {0.0, 0.0, 0.0};
-        for (int t = threadIdx.x; t < n_partials; t += 256)
+        if (compact) {      // tile sums {r.r, m.r}; m.m from the cameras' sums of s
+            for (int t = threadIdx.x; t < n_partials; t += 256) {
+                acc[0] += partials[2 * t];
+                acc[1] += partials[2 * t + 1];
+            }
+            for (int64_t jj = threadIdx.x; jj < K; jj += 256) acc[2] += cam_sums[20 * K + jj];
+        } else {
+            for (int t = threadIdx.x; t < n_partials; t += 256)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) acc[k] += partials[3 * t + k];
+                for (int k = 0; k < 3; ++k) acc[k] += partials[3 * t + k];
+        }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             acc[k] = wave_sum(acc[k]);
