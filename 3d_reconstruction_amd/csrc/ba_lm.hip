@@ -644,105 +644,105 @@ __global__ void __launch_bounds__(SCHUR_TILE_BLOCK) k_schur_tile(SchurTileArgs a
     const int lo = lane / 6, al = lane - 6 * lo;
     const bool lane_on = lane < 60;
     auto phase1_single = [&](int64_t i, int64_t eb, int deg, double *Wl, double *Zl, int *sl) {
-            double Vi[6];
-            inv_sym3(a.V + 6 * i, a.lambda, Vi);
-            const double x[3] = {a.X[3 * i], a.X[3 * i + 1], a.X[3 * i + 2]};
-            // point x phi column w = dphi sum_obs J_X^T m (not kept by the J^T J pass: summed here, stored for the back-substitution)
-            // what the lane keeps of its observation: the rows of J_X and the three entries of either row of G that meet
-            // the non-zero entries of column al of T (rows 0..2 of T for the centre, rows 3..5 for the angles)
-            double jx0[3] = {0.0, 0.0, 0.0}, jx1[3] = {0.0, 0.0, 0.0}, g0[3] = {0.0, 0.0, 0.0}, g1[3] = {0.0, 0.0, 0.0}, om0 = 0.0, om1 = 0.0;
-            int slot = 0;
-            const bool centre = al < 3;
-            auto load_obs = [&](int o) {
-                const int64_t e = eb + o;
-                slot = (int)(a.opack[e] & 0xffffu);
-                const ObsJac ob = obs_jacobian(x, (const double2 *)(rows + slot * CAM_ROW), f, pcx, pcy, a.ouv[e]);
-    #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    jx0[k] = ob.jx0[k], jx1[k] = ob.jx1[k];
-                    g0[k] = centre ? ob.G0[k] : ob.G0[3 + k];
-                    g1[k] = centre ? ob.G1[k] : ob.G1[3 + k];
+        double Vi[6];
+        inv_sym3(a.V + 6 * i, a.lambda, Vi);
+        const double x[3] = {a.X[3 * i], a.X[3 * i + 1], a.X[3 * i + 2]};
+        // point x phi column w = dphi sum_obs J_X^T m (not kept by the J^T J pass: summed here, stored for the back-substitution)
+        // what the lane keeps of its observation: the rows of J_X and the three entries of either row of G that meet
+        // the non-zero entries of column al of T (rows 0..2 of T for the centre, rows 3..5 for the angles)
+        double jx0[3] = {0.0, 0.0, 0.0}, jx1[3] = {0.0, 0.0, 0.0}, g0[3] = {0.0, 0.0, 0.0}, g1[3] = {0.0, 0.0, 0.0}, om0 = 0.0, om1 = 0.0;
+        int slot = 0;
+        const bool centre = al < 3;
+        auto load_obs = [&](int o) {
+            const int64_t e = eb + o;
+            slot = (int)(a.opack[e] & 0xffffu);
+            const ObsJac ob = obs_jacobian(x, (const double2 *)(rows + slot * CAM_ROW), f, pcx, pcy, a.ouv[e]);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                jx0[k] = ob.jx0[k], jx1[k] = ob.jx1[k];
+                g0[k] = centre ? ob.G0[k] : ob.G0[3 + k];
+                g1[k] = centre ? ob.G1[k] : ob.G1[3 + k];
+            }
+            om0 = ob.m0, om1 = ob.m1;
+        };
+        const double gx[3] = {a.gX[3 * i], a.gX[3 * i + 1], a.gX[3 * i + 2]};
+        const double zg[3] = {Vi[0] * gx[0] + Vi[1] * gx[1] + Vi[2] * gx[2], Vi[1] * gx[0] + Vi[3] * gx[1] + Vi[4] * gx[2],
+                              Vi[2] * gx[0] + Vi[4] * gx[1] + Vi[5] * gx[2]};
+        // column al of W and Z of observation o into the wave's scratch, its share of the right-hand side
+        auto form_w = [&](int o, double &W0, double &W1, double &W2) {
+            const double *tc = Tt + (slot * 6 + al) * 3;        // column al of J_cam = G T
+            const double t0 = tc[0], t1 = tc[1], t2 = tc[2];
+            const double jc0 = g0[0] * t0 + g0[1] * t1 + g0[2] * t2;
+            const double jc1 = g1[0] * t0 + g1[1] * t1 + g1[2] * t2;
+            W0 = jx0[0] * jc0 + jx1[0] * jc1;
+            W1 = jx0[1] * jc0 + jx1[1] * jc1;
+            W2 = jx0[2] * jc0 + jx1[2] * jc1;
+            Wl[o * 18 + 0 * 6 + al] = W0;
+            Wl[o * 18 + 1 * 6 + al] = W1;
+            Wl[o * 18 + 2 * 6 + al] = W2;
+            Zl[o * 18 + 0 * 6 + al] = Vi[0] * W0 + Vi[1] * W1 + Vi[2] * W2;
+            Zl[o * 18 + 1 * 6 + al] = Vi[1] * W0 + Vi[3] * W1 + Vi[4] * W2;
+            Zl[o * 18 + 2 * 6 + al] = Vi[2] * W0 + Vi[4] * W1 + Vi[5] * W2;
+            const double rr = W0 * zg[0] + W1 * zg[1] + W2 * zg[2];
+            __hip_atomic_fetch_add(rhs_t + 6 * slot + al, rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (al == 0) sl[o] = slot;
+        };
+        double wp[3] = {0.0, 0.0, 0.0}, zw[3];
+        auto finish_wp = [&]() {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) wp[k] = dphi * wave_sum(wp[k]);
+            if (lane < 3) a.Xphi[3 * i + lane] = lane == 0 ? wp[0] : (lane == 1 ? wp[1] : wp[2]);
+            zw[0] = Vi[0] * wp[0] + Vi[1] * wp[1] + Vi[2] * wp[2];
+            zw[1] = Vi[1] * wp[0] + Vi[3] * wp[1] + Vi[4] * wp[2];
+            zw[2] = Vi[2] * wp[0] + Vi[4] * wp[1] + Vi[5] * wp[2];
+        };
+        auto add_sphi = [&](double W0, double W1, double W2) {
+            const double sphi = W0 * zw[0] + W1 * zw[1] + W2 * zw[2];
+            __hip_atomic_fetch_add(sphi_t + 6 * slot + al, -sphi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        if (deg <= 10) {
+            // one trip: W and Z do not depend on the sums over the wave, so they are formed (and written) ahead of them
+            // and the sums' latency passes behind that work; only the phi column's entry waits for them
+            const bool on = lane_on && lo < deg;
+            double W0 = 0.0, W1 = 0.0, W2 = 0.0;
+            if (on) {
+                load_obs(lo);
+                if (al == 0) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) wp[k] = jx0[k] * om0 + jx1[k] * om1;
                 }
-                om0 = ob.m0, om1 = ob.m1;
-            };
-            const double gx[3] = {a.gX[3 * i], a.gX[3 * i + 1], a.gX[3 * i + 2]};
-            const double zg[3] = {Vi[0] * gx[0] + Vi[1] * gx[1] + Vi[2] * gx[2], Vi[1] * gx[0] + Vi[3] * gx[1] + Vi[4] * gx[2],
-                                  Vi[2] * gx[0] + Vi[4] * gx[1] + Vi[5] * gx[2]};
-            // column al of W and Z of observation o into the wave's scratch, its share of the right-hand side
-            auto form_w = [&](int o, double &W0, double &W1, double &W2) {
-                const double *tc = Tt + (slot * 6 + al) * 3;        // column al of J_cam = G T
-                const double t0 = tc[0], t1 = tc[1], t2 = tc[2];
-                const double jc0 = g0[0] * t0 + g0[1] * t1 + g0[2] * t2;
-                const double jc1 = g1[0] * t0 + g1[1] * t1 + g1[2] * t2;
-                W0 = jx0[0] * jc0 + jx1[0] * jc1;
-                W1 = jx0[1] * jc0 + jx1[1] * jc1;
-                W2 = jx0[2] * jc0 + jx1[2] * jc1;
-                Wl[o * 18 + 0 * 6 + al] = W0;
-                Wl[o * 18 + 1 * 6 + al] = W1;
-                Wl[o * 18 + 2 * 6 + al] = W2;
-                Zl[o * 18 + 0 * 6 + al] = Vi[0] * W0 + Vi[1] * W1 + Vi[2] * W2;
-                Zl[o * 18 + 1 * 6 + al] = Vi[1] * W0 + Vi[3] * W1 + Vi[4] * W2;
-                Zl[o * 18 + 2 * 6 + al] = Vi[2] * W0 + Vi[4] * W1 + Vi[5] * W2;
-                const double rr = W0 * zg[0] + W1 * zg[1] + W2 * zg[2];
-                __hip_atomic_fetch_add(rhs_t + 6 * slot + al, rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (al == 0) sl[o] = slot;
-            };
-            double wp[3] = {0.0, 0.0, 0.0}, zw[3];
-            auto finish_wp = [&]() {
-    #pragma unroll
-                for (int k = 0; k < 3; ++k) wp[k] = dphi * wave_sum(wp[k]);
-                if (lane < 3) a.Xphi[3 * i + lane] = lane == 0 ? wp[0] : (lane == 1 ? wp[1] : wp[2]);
-                zw[0] = Vi[0] * wp[0] + Vi[1] * wp[1] + Vi[2] * wp[2];
-                zw[1] = Vi[1] * wp[0] + Vi[3] * wp[1] + Vi[4] * wp[2];
-                zw[2] = Vi[2] * wp[0] + Vi[4] * wp[1] + Vi[5] * wp[2];
-            };
-            auto add_sphi = [&](double W0, double W1, double W2) {
-                const double sphi = W0 * zw[0] + W1 * zw[1] + W2 * zw[2];
-                __hip_atomic_fetch_add(sphi_t + 6 * slot + al, -sphi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            };
-            if (deg <= 10) {
-                // one trip: W and Z do not depend on the sums over the wave, so they are formed (and written) ahead of them
-                // and the sums' latency passes behind that work; only the phi column's entry waits for them
-                const bool on = lane_on && lo < deg;
-                double W0 = 0.0, W1 = 0.0, W2 = 0.0;
-                if (on) {
-                    load_obs(lo);
+                form_w(lo, W0, W1, W2);
+            }
+            finish_wp();
+            if (on) add_sphi(W0, W1, W2);
+        } else {
+            for (int base = 0; base < deg; base += 10) {
+                const int o = base + lo;
+                if (lane_on && o < deg) {
+                    load_obs(o);
                     if (al == 0) {
-    #pragma unroll
-                        for (int k = 0; k < 3; ++k) wp[k] = jx0[k] * om0 + jx1[k] * om1;
-                    }
-                    form_w(lo, W0, W1, W2);
-                }
-                finish_wp();
-                if (on) add_sphi(W0, W1, W2);
-            } else {
-                for (int base = 0; base < deg; base += 10) {
-                    const int o = base + lo;
-                    if (lane_on && o < deg) {
-                        load_obs(o);
-                        if (al == 0) {
-    #pragma unroll
-                            for (int k = 0; k < 3; ++k) wp[k] += jx0[k] * om0 + jx1[k] * om1;
-                        }
-                    }
-                }
-                finish_wp();
-                for (int base = 0; base < deg; base += 10) {
-                    const int o = base + lo;
-                    if (lane_on && o < deg) {
-                        load_obs(o);
-                        double W0, W1, W2;
-                        form_w(o, W0, W1, W2);
-                        add_sphi(W0, W1, W2);
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) wp[k] += jx0[k] * om0 + jx1[k] * om1;
                     }
                 }
             }
-            if (lane == 0) {
-                __hip_atomic_fetch_add(sc_t + 0, -(wp[0] * zw[0] + wp[1] * zw[1] + wp[2] * zw[2]), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(sc_t + 1, wp[0] * zg[0] + wp[1] * zg[1] + wp[2] * zg[2], __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+            finish_wp();
+            for (int base = 0; base < deg; base += 10) {
+                const int o = base + lo;
+                if (lane_on && o < deg) {
+                    load_obs(o);
+                    double W0, W1, W2;
+                    form_w(o, W0, W1, W2);
+                    add_sphi(W0, W1, W2);
+                }
             }
+        }
+        if (lane == 0) {
+            __hip_atomic_fetch_add(sc_t + 0, -(wp[0] * zw[0] + wp[1] * zw[1] + wp[2] * zw[2]), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(sc_t + 1, wp[0] * zg[0] + wp[1] * zg[1] + wp[2] * zg[2], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
     };
     // ---- first phase, two points per trip (neither with more than ten observations): the chain of dependent steps a
     // point costs - its data, the Jacobians, the sums over its observations, W and Z - is what the kernel waits for
@@ -823,77 +823,77 @@ __global__ void __launch_bounds__(SCHUR_TILE_BLOCK) k_schur_tile(SchurTileArgs a
     };
     // ---- second phase: the pairs of one point's observations
     auto pair_phase = [&](int deg, const double *Wl, const double *Zl, const int *sl) {
-            // all ordered pairs (o, o') of the point's observations with slot >= slot': the pair loop is
-            // wave-uniform, lane (al, be) < 36 owns one entry of the 6 x 6 block (no index arithmetic
-            // with divisions inside the loop)
-            // a point's observations usually come in the order of the camera slots: the pairs with slot >= slot' are then
-            // the pairs o' <= o, and the inner loop needs no test (half its trips would fail it)
-            // (up to ten observations: the lanes' own pairs (po, po2 <= po) cover every neighbouring pair, and the slots
-            // they read for themselves answer the question; the lowest slot is then the first observation's)
-            bool ascending = true;
-            const bool pair_on = po < deg;
-            int so = 0, so2 = 0;
-            if (deg <= 10) {
-                if (pair_on) so = sl[po], so2 = sl[po2];
-                ascending = !pair_on || so2 <= so;
+        // all ordered pairs (o, o') of the point's observations with slot >= slot': the pair loop is
+        // wave-uniform, lane (al, be) < 36 owns one entry of the 6 x 6 block (no index arithmetic
+        // with divisions inside the loop)
+        // a point's observations usually come in the order of the camera slots: the pairs with slot >= slot' are then
+        // the pairs o' <= o, and the inner loop needs no test (half its trips would fail it)
+        // (up to ten observations: the lanes' own pairs (po, po2 <= po) cover every neighbouring pair, and the slots
+        // they read for themselves answer the question; the lowest slot is then the first observation's)
+        bool ascending = true;
+        const bool pair_on = po < deg;
+        int so = 0, so2 = 0;
+        if (deg <= 10) {
+            if (pair_on) so = sl[po], so2 = sl[po2];
+            ascending = !pair_on || so2 <= so;
+        } else {
+            for (int o = lane; o + 1 < deg; o += 64) ascending = ascending && sl[o] <= sl[o + 1];
+        }
+        ascending = __all(ascending);
+        if (a.first) {
+            if (deg <= 10 && ascending) {
+                const int lowest = __builtin_amdgcn_readfirstlane(so2);      // lane 0 holds the pair (0, 0)
+                if (pair_on && po2 == 0) atomicMin(low + so, lowest);
             } else {
-                for (int o = lane; o + 1 < deg; o += 64) ascending = ascending && sl[o] <= sl[o + 1];
+                int lowest = 0x7fffffff;
+                for (int o = lane; o < deg; o += 64) lowest = min(lowest, sl[o]);
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) lowest = min(lowest, __shfl_xor(lowest, off));
+                for (int o = lane; o < deg; o += 64) atomicMin(low + sl[o], lowest);
             }
-            ascending = __all(ascending);
-            if (a.first) {
-                if (deg <= 10 && ascending) {
-                    const int lowest = __builtin_amdgcn_readfirstlane(so2);      // lane 0 holds the pair (0, 0)
-                    if (pair_on && po2 == 0) atomicMin(low + so, lowest);
-                } else {
-                    int lowest = 0x7fffffff;
-                    for (int o = lane; o < deg; o += 64) lowest = min(lowest, sl[o]);
-    #pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) lowest = min(lowest, __shfl_xor(lowest, off));
-                    for (int o = lane; o < deg; o += 64) atomicMin(low + sl[o], lowest);
-                }
-            }
-            if (REG_PAIRS && deg <= 10 && ascending) {
-                const bool active = pair_on;
-                int blk = -1;
-                if (active) blk = so * (so + 1) / 2 + so2;
-                const bool moved = active && held >= 0 && blk != held;
-                if (__any(moved)) flush_pairs(moved);
-                if (active) {
-                    held = blk;
-                    const double *wr = Wl + po * 18, *zr = Zl + po2 * 18;
-    #pragma unroll
-                    for (int mm = 0; mm < 3; ++mm) {
-                        double w[6], z[6];
-    #pragma unroll
-                        for (int h = 0; h < 3; ++h) {
-                            const double2 wv = *(const double2 *)(wr + 6 * mm + 2 * h), zv = *(const double2 *)(zr + 6 * mm + 2 * h);
-                            w[2 * h] = wv.x, w[2 * h + 1] = wv.y;
-                            z[2 * h] = zv.x, z[2 * h + 1] = zv.y;
-                        }
-    #pragma unroll
-                        for (int al = 0; al < 6; ++al)
-    #pragma unroll
-                            for (int be = 0; be < 6; ++be) acc[6 * al + be] = fma(-w[al], z[be], acc[6 * al + be]);
+        }
+        if (REG_PAIRS && deg <= 10 && ascending) {
+            const bool active = pair_on;
+            int blk = -1;
+            if (active) blk = so * (so + 1) / 2 + so2;
+            const bool moved = active && held >= 0 && blk != held;
+            if (__any(moved)) flush_pairs(moved);
+            if (active) {
+                held = blk;
+                const double *wr = Wl + po * 18, *zr = Zl + po2 * 18;
+#pragma unroll
+                for (int mm = 0; mm < 3; ++mm) {
+                    double w[6], z[6];
+#pragma unroll
+                    for (int h = 0; h < 3; ++h) {
+                        const double2 wv = *(const double2 *)(wr + 6 * mm + 2 * h), zv = *(const double2 *)(zr + 6 * mm + 2 * h);
+                        w[2 * h] = wv.x, w[2 * h + 1] = wv.y;
+                        z[2 * h] = zv.x, z[2 * h + 1] = zv.y;
                     }
-                }
-            } else {
-            if (REG_PAIRS && __any(held >= 0)) flush_pairs(held >= 0);
-            if (lane < 36) {
-                const int al = lane / 6, be = lane - 6 * al;
-                for (int o = 0; o < deg; ++o) {
-                    const int so = sl[o];
-                    const double w0 = Wl[o * 18 + al], w1 = Wl[o * 18 + 6 + al], w2 = Wl[o * 18 + 12 + al];
-                    double *dst = St + (size_t)(so * (so + 1) / 2) * 36 + lane;
-                    const int o2_end = ascending ? o + 1 : deg;
-                    for (int o2 = 0; o2 < o2_end; ++o2) {
-                        const int so2 = sl[o2];
-                        if (so < so2) continue;
-                        const double v = w0 * Zl[o2 * 18 + be] + w1 * Zl[o2 * 18 + 6 + be] + w2 * Zl[o2 * 18 + 12 + be];
-                        __hip_atomic_fetch_add(dst + 36 * so2, -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
+#pragma unroll
+                    for (int al = 0; al < 6; ++al)
+#pragma unroll
+                        for (int be = 0; be < 6; ++be) acc[6 * al + be] = fma(-w[al], z[be], acc[6 * al + be]);
                 }
             }
+        } else {
+        if (REG_PAIRS && __any(held >= 0)) flush_pairs(held >= 0);
+        if (lane < 36) {
+            const int al = lane / 6, be = lane - 6 * al;
+            for (int o = 0; o < deg; ++o) {
+                const int so = sl[o];
+                const double w0 = Wl[o * 18 + al], w1 = Wl[o * 18 + 6 + al], w2 = Wl[o * 18 + 12 + al];
+                double *dst = St + (size_t)(so * (so + 1) / 2) * 36 + lane;
+                const int o2_end = ascending ? o + 1 : deg;
+                for (int o2 = 0; o2 < o2_end; ++o2) {
+                    const int so2 = sl[o2];
+                    if (so < so2) continue;
+                    const double v = w0 * Zl[o2 * 18 + be] + w1 * Zl[o2 * 18 + 6 + be] + w2 * Zl[o2 * 18 + 12 + be];
+                    __hip_atomic_fetch_add(dst + 36 * so2, -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
+        }
+        }
     };
     auto lanes_sync = [&]() {
         __builtin_amdgcn_wave_barrier();
