@@ -172,6 +172,7 @@ class StreamAllReduce:
             b = a.clone()
             with torch.cuda.device(device):
                 obj(a, torch.cuda.current_stream().cuda_stream)
+                torch.cuda.synchronize()        # never two collectives of two communicators in flight on one GPU
             dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group)
             same = torch.tensor([1.0 if torch.equal(a, b) else 0.0], dtype=torch.float64, device=device)
             dist.all_reduce(same, op=dist.ReduceOp.MIN, group=group)
