@@ -51,10 +51,42 @@
 
 #include <stdlib.h>
 #include <algorithm>
+#include <mutex>
 #include <string>
 #include <vector>
 
 namespace ba {
+
+// What a call needs beyond S and rhs - the inverses of the diagonal blocks, the solution vector, the lists that steer
+// the block moves and the clearing - lives in a workspace per device that grows on demand and is kept until the process
+// ends (at n = 120 001: 61 MB of inverses, 123 MB of gathered blocks): a Levenberg-Marquardt loop calls once per
+// iteration with the same matrix, and allocating and freeing each time cost more than the short launches in between.
+// The lists are uploaded again only when the block profile they were built from has changed.
+// (Replaying the launches of a call - some 130 at n = 12 001, 340 at n = 120 001 - as a captured HIP graph was
+// measured too: 4.0 against 3.8 ms and 13.7 against 13.4 ms per iteration, slower than launching them one by one.)
+struct CholCache {
+    struct Buf {
+        void *p = nullptr;
+        size_t bytes = 0;
+    };
+    std::mutex mu;
+    Buf linv, tmp, info, newpos, moves, T, runs, first;
+    // what the lists in `newpos`, `moves` and `runs` were built for
+    bool lists_valid = false;
+    int64_t n = 0, ld = 0;
+    int clear = 0;
+    std::vector<int> profile;
+    hipError_t grow(Buf &b, size_t bytes) {
+        if (b.bytes >= bytes) return hipSuccess;
+        lists_valid = false;
+        hipFree(b.p);
+        b.p = nullptr, b.bytes = 0;
+        const hipError_t e = hipMalloc(&b.p, bytes);
+        if (e == hipSuccess) b.bytes = bytes;
+        return e;
+    }
+};
+static CholCache g_chol_cache[16];
 
 constexpr int NB = 64;    // block of the panel factorisation
 constexpr int PB = 256;   // panel width
@@ -746,6 +778,12 @@ __global__ void __launch_bounds__(256) k_solve_step(const double *__restrict__ A
 
 using namespace ba;
 
+// (kernels instead of memset commands: the sequence they belong to is captured into a graph)
+__global__ void k_zero_int(int *p) { *p = 0; }
+__global__ void k_zero_doubles(double *__restrict__ p, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0.0;
+}
+
 extern "C" {
 
 int ba_schur_dim(int64_t K, int64_t *n, int64_t *ld) {
@@ -764,12 +802,17 @@ int ba_cholesky_solve_tracked(int64_t n, int64_t ld, double *S, double *rhs, con
     BA_REQUIRE(S && rhs && n > 0 && ld >= n && ld % NB == 0, "ba_cholesky_solve: bad argument (ld must be a multiple of 64)");
     hipStream_t st = (hipStream_t)stream;
     const int64_t nb = ld / NB;
-    double *Linv = nullptr, *tmp = nullptr;   // inverse of every diagonal block; solution vector
-    int *info = nullptr;
-    BA_HIP(hipMalloc(&Linv, sizeof(double) * NB * NB * nb));
-    hipError_t e = hipMalloc(&tmp, sizeof(double) * ld);
-    if (e == hipSuccess) e = hipMalloc(&info, sizeof(int));
-    if (e == hipSuccess) e = hipMemsetAsync(info, 0, sizeof(int), st);
+    int device = 0;
+    BA_HIP(hipGetDevice(&device));
+    BA_REQUIRE(device >= 0 && device < 16, "ba_cholesky_solve: device number out of range");
+    CholCache &ws = g_chol_cache[device];
+    std::lock_guard<std::mutex> lock(ws.mu);     // one call at a time per device: the workspace is shared
+    hipError_t e = ws.grow(ws.linv, sizeof(double) * NB * NB * nb);
+    if (e == hipSuccess) e = ws.grow(ws.tmp, sizeof(double) * ld);
+    if (e == hipSuccess) e = ws.grow(ws.info, sizeof(int));
+    BA_HIP(e);
+    double *Linv = (double *)ws.linv.p, *tmp = (double *)ws.tmp.p;   // inverse of every diagonal block; solution vector
+    int *info = (int *)ws.info.p;
     const size_t lds_trailing = sizeof(double) * 2 * KC * LDT;
     if (e == hipSuccess && lds_trailing > 64 * 1024)
         e = hipFuncSetAttribute((const void *)k_syrk_trailing, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_trailing);
@@ -804,15 +847,12 @@ int ba_cholesky_solve_tracked(int64_t n, int64_t ld, double *S, double *rhs, con
             for (int64_t k = 0; k < nb && e == hipSuccess; ++k)
                 if (first[k] < 0 || first[k] > k) {
                     set_error("ba_cholesky_solve_tracked: block_first[k] must lie in 0 .. k");
-                    hipFree(Linv);
-                    hipFree(tmp);
-                    hipFree(info);
                     return BA_ERR_ARG;
                 }
         } else {
             for (int64_t k = 0; k < nb; ++k) first[k] = (int)k;
-            int *d_first = nullptr;
-            e = hipMalloc(&d_first, sizeof(int) * nb);
+            e = ws.grow(ws.first, sizeof(int) * nb);
+            int *d_first = (int *)ws.first.p;
             if (e == hipSuccess) e = hipMemcpyAsync(d_first, first.data(), sizeof(int) * nb, hipMemcpyHostToDevice, st);
             if (e == hipSuccess) {
                 hipLaunchKernelGGL(k_block_profile, dim3((unsigned)nb, (unsigned)cdiv_c(nb, PROFILE_CHUNK)), dim3(256), 0, st, S,
@@ -820,7 +860,6 @@ int ba_cholesky_solve_tracked(int64_t n, int64_t ld, double *S, double *rhs, con
                 e = hipMemcpyAsync(first.data(), d_first, sizeof(int) * nb, hipMemcpyDeviceToHost, st);
             }
             if (e == hipSuccess) e = hipStreamSynchronize(st);
-            hipFree(d_first);
         }
         if (e == hipSuccess) {
             // The last block rows before the structural border join it when they reach far further back than the
@@ -857,36 +896,29 @@ int ba_cholesky_solve_tracked(int64_t n, int64_t ld, double *S, double *rhs, con
     const int64_t B0 = (int64_t)P * s_blocks;                // first block behind the chains (P > 1)
     const int64_t T0 = B0 + (int64_t)P * bw;                 // first block behind the separators
     int *d_newpos = nullptr;
+    int4 *d_moves = nullptr;
+    double *T = nullptr;
+    std::vector<int> newpos;
+    std::vector<int4> moves;
     std::vector<int> chain_reach, chain_first;               // per block of a chain: reach and first column, over all chains
     if (P > 1 && e == hipSuccess) {
-        std::vector<int> newpos((size_t)nb);
+        newpos.resize((size_t)nb);
         for (int64_t ib = 0; ib < nb; ++ib) {
             const int64_t c = ib / (s_blocks + bw), l = ib % (s_blocks + bw);
             if (c >= P) newpos[ib] = (int)ib;                                   // rest of the band, border: where they were
             else if (l < s_blocks) newpos[ib] = (int)(c * s_blocks + l);
             else newpos[ib] = (int)(B0 + c * bw + (l - s_blocks));
         }
-        // the occupied blocks (from the profile), gathered, cleared, stored at their new places
-        std::vector<int4> moves;
+        // the occupied blocks (from the profile), gathered, cleared, stored at their new places (k_move_blocks, below)
         for (int64_t ib = 0; ib < nb; ++ib)
             for (int64_t jb = first[ib]; jb <= ib; ++jb) {
                 const int a = newpos[ib], bcol = newpos[jb];
                 moves.push_back(a >= bcol ? make_int4((int)ib, (int)jb, a, bcol) : make_int4((int)ib, (int)jb, -bcol - 1, a));
             }
-        int4 *d_moves = nullptr;
-        double *T = nullptr;
-        e = hipMalloc(&d_moves, sizeof(int4) * moves.size());
-        if (e == hipSuccess) e = hipMalloc(&T, sizeof(double) * NB * NB * moves.size());
-        if (e == hipSuccess) e = hipMalloc(&d_newpos, sizeof(int) * nb);
-        if (e == hipSuccess) e = hipMemcpyAsync(d_moves, moves.data(), sizeof(int4) * moves.size(), hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(d_newpos, newpos.data(), sizeof(int) * nb, hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) {
-            for (int mode = 0; mode < 3; ++mode)
-                hipLaunchKernelGGL(k_move_blocks, dim3((unsigned)moves.size()), dim3(256), 0, st, S, ld, d_moves, T, mode);
-            e = hipStreamSynchronize(st);       // the host vectors and T go out of use here
-        }
-        hipFree(d_moves);
-        hipFree(T);
+        e = ws.grow(ws.moves, sizeof(int4) * moves.size());
+        if (e == hipSuccess) e = ws.grow(ws.T, sizeof(double) * NB * NB * moves.size());
+        if (e == hipSuccess) e = ws.grow(ws.newpos, sizeof(int) * nb);
+        d_moves = (int4 *)ws.moves.p, T = (double *)ws.T.p, d_newpos = (int *)ws.newpos.p;
         // structure of a chain, over all chains: the first column block of local row l and from it the reach
         chain_first.assign((size_t)s_blocks, 0x7fffffff);
         for (int c = 0; c < P; ++c)
@@ -940,8 +972,35 @@ int ba_cholesky_solve_tracked(int64_t n, int64_t ld, double *S, double *rhs, con
         sel.tail_rows = (border_u - start_u) * unit_rows;
         return band + (total - border_u);
     };
-    if (e == hipSuccess) {
-        if (ride_along) hipLaunchKernelGGL(k_rhs_into_row, dim3(cdiv_c(ld, 256)), dim3(256), 0, st, S, ld, n, rhs, d_newpos);
+    // the blocks cleared on return: every block that can hold anything after the factorisation - the envelope in the
+    // order the factorisation worked in, whole rows behind the chains, the row that carried the right-hand side
+    std::vector<int4> runs;
+    int4 *d_runs = nullptr;
+    if (clear_on_return && !first.empty() && e == hipSuccess) {
+        auto add_run = [&](int64_t row, int64_t c_begin, int64_t c_last) {
+            for (int64_t c = c_begin; c <= c_last; c += 32) runs.push_back(make_int4((int)row, (int)c, (int)std::min(c + 31, c_last), 0));
+        };
+        if (P > 1) {
+            for (int c = 0; c < P; ++c)
+                for (int64_t l = 0; l < s_blocks; ++l) add_run(c * s_blocks + l, c * s_blocks + chain_first[l], c * s_blocks + l);
+            for (int64_t r = B0; r < nb; ++r) add_run(r, 0, r);
+        } else {
+            for (int64_t r = 0; r + 1 < nb; ++r) add_run(r, row_first[r], r);
+            add_run(nb - 1, 0, nb - 1);
+        }
+        e = ws.grow(ws.runs, sizeof(int4) * runs.size());
+        d_runs = (int4 *)ws.runs.p;
+    }
+    BA_HIP(e);
+
+    // Everything the device does for this call, on stream q.
+    auto issue = [&](hipStream_t q) -> hipError_t {
+        hipError_t e = hipSuccess;
+        hipLaunchKernelGGL(k_zero_int, dim3(1), dim3(1), 0, q, info);
+        if (P > 1)
+            for (int mode = 0; mode < 3; ++mode)
+                hipLaunchKernelGGL(k_move_blocks, dim3((unsigned)moves.size()), dim3(256), 0, q, S, ld, d_moves, T, mode);
+        if (ride_along) hipLaunchKernelGGL(k_rhs_into_row, dim3(cdiv_c(ld, 256)), dim3(256), 0, q, S, ld, n, rhs, d_newpos);
         // Factorisation of the columns [begin, end) - of every chain at once when n_chains > 1 (begin, end inside the
         // chain then) - and update of everything behind them.
         auto factor = [&](int64_t begin, int64_t end, int n_chains, bool dense) {
@@ -959,7 +1018,7 @@ int ba_cholesky_solve_tracked(int64_t n, int64_t ld, double *S, double *rhs, con
                 int split = 1;      // workgroups per tile: as long as the launch stays within one round of the chip
                 while (tiles * n_chains * split * 2 <= 256 && kw % (split * 2 * NB) == 0) split *= 2;
                 hipLaunchKernelGGL(k_syrk_trailing, dim3((unsigned)tiles, (unsigned)split, (unsigned)n_chains), dim3(256),
-                                   lds_trailing, st, S, ld, k_first, (int)(kw / split), c0, nct, sel);
+                                   lds_trailing, q, S, ld, k_first, (int)(kw / split), c0, nct, sel);
             };
             for (int64_t o0 = begin; o0 < end; o0 += OB) {
                 const int64_t o_end = (end - o0 < OB) ? end : o0 + OB;
@@ -968,13 +1027,13 @@ int ba_cholesky_solve_tracked(int64_t n, int64_t ld, double *S, double *rhs, con
                     const int nbk = (int)(pw / NB);
                     double *Li = Linv + (p0 / NB) * NB * NB;
                     for (int kb = 0; kb < nbk; ++kb) {
-                        hipLaunchKernelGGL(k_potrf64, dim3(1, n_chains), dim3(256), sizeof(double) * POTRF_LDS_DOUBLES, st, S, ld,
+                        hipLaunchKernelGGL(k_potrf64, dim3(1, n_chains), dim3(256), sizeof(double) * POTRF_LDS_DOUBLES, q, S, ld,
                                            p0 + NB * kb, Li + (int64_t)kb * NB * NB, info, chain_rows);
                         const int below = nbk - 1 - kb;
                         if (below > 0) {
-                            hipLaunchKernelGGL(k_diag_trsm, dim3(below, n_chains), dim3(256), lds_diag, st, S, ld, p0, kb,
+                            hipLaunchKernelGGL(k_diag_trsm, dim3(below, n_chains), dim3(256), lds_diag, q, S, ld, p0, kb,
                                                Li + (int64_t)kb * NB * NB, chain_rows);
-                            hipLaunchKernelGGL(k_diag_syrk, dim3(below * (below + 1) / 2, n_chains), dim3(256), lds_diag, st, S, ld,
+                            hipLaunchKernelGGL(k_diag_syrk, dim3(below * (below + 1) / 2, n_chains), dim3(256), lds_diag, q, S, ld,
                                                p0, kb, chain_rows);
                         }
                     }
@@ -982,10 +1041,10 @@ int ba_cholesky_solve_tracked(int64_t n, int64_t ld, double *S, double *rhs, con
                         RowSel sel;
                         const int slabs = (int)select_rows((p0 + pw - 1) / NB, (p0 + pw) / NB, 1, chains, dense, sel);
                         const dim3 grid(slabs, n_chains);
-                        if (nbk == 4) hipLaunchKernelGGL(k_panel_rows<4>, grid, dim3(256), lds_rows, st, S, ld, p0, Li, sel);
-                        else if (nbk == 3) hipLaunchKernelGGL(k_panel_rows<3>, grid, dim3(256), lds_rows, st, S, ld, p0, Li, sel);
-                        else if (nbk == 2) hipLaunchKernelGGL(k_panel_rows<2>, grid, dim3(256), lds_rows, st, S, ld, p0, Li, sel);
-                        else hipLaunchKernelGGL(k_panel_rows<1>, grid, dim3(256), lds_rows, st, S, ld, p0, Li, sel);
+                        if (nbk == 4) hipLaunchKernelGGL(k_panel_rows<4>, grid, dim3(256), lds_rows, q, S, ld, p0, Li, sel);
+                        else if (nbk == 3) hipLaunchKernelGGL(k_panel_rows<3>, grid, dim3(256), lds_rows, q, S, ld, p0, Li, sel);
+                        else if (nbk == 2) hipLaunchKernelGGL(k_panel_rows<2>, grid, dim3(256), lds_rows, q, S, ld, p0, Li, sel);
+                        else hipLaunchKernelGGL(k_panel_rows<1>, grid, dim3(256), lds_rows, q, S, ld, p0, Li, sel);
                     }
                     // inside the outer panel: only its remaining columns see this 256-wide panel now
                     trailing(p0, pw, p0 + pw, o_end);
@@ -1002,69 +1061,59 @@ int ba_cholesky_solve_tracked(int64_t n, int64_t ld, double *S, double *rhs, con
         }
         // L y = b (unless it rode along), then L^T x = y; the result of every block step lands in tmp
         if (ride_along) {
-            hipLaunchKernelGGL(k_row_to_rhs, dim3(cdiv_c(ld, 256)), dim3(256), 0, st, S, ld, n, rhs);
+            hipLaunchKernelGGL(k_row_to_rhs, dim3(cdiv_c(ld, 256)), dim3(256), 0, q, S, ld, n, rhs);
         } else {
             for (int64_t k = 0; k < nb; ++k)
-                hipLaunchKernelGGL(k_solve_step, dim3(k + 1 < nb ? cdiv_c(ld - (k + 1) * NB, 256) : 1), dim3(256), 0, st, S,
+                hipLaunchKernelGGL(k_solve_step, dim3(k + 1 < nb ? cdiv_c(ld - (k + 1) * NB, 256) : 1), dim3(256), 0, q, S,
                                    ld, k * NB, Linv + k * NB * NB, rhs, tmp, 0, (int64_t)0, (int64_t)0);
-            e = hipMemcpyAsync(rhs, tmp, sizeof(double) * ld, hipMemcpyDeviceToDevice, st);
+            e = hipMemcpyAsync(rhs, tmp, sizeof(double) * ld, hipMemcpyDeviceToDevice, q);
         }
         if (P > 1) {
             for (int64_t k = nb - 1; k >= B0; --k)      // behind the chains: rows with entries in every chain
-                hipLaunchKernelGGL(k_solve_step, dim3(cdiv_c(k * NB, 256)), dim3(256), 0, st, S, ld, k * NB, Linv + k * NB * NB,
+                hipLaunchKernelGGL(k_solve_step, dim3(cdiv_c(k * NB, 256)), dim3(256), 0, q, S, ld, k * NB, Linv + k * NB * NB,
                                    rhs, tmp, 1, (int64_t)0, (int64_t)0);
             for (int64_t k = s_blocks - 1; k >= 0; --k) {       // block k of every chain
                 const int64_t i_begin = (int64_t)chain_first[k] * NB;
-                hipLaunchKernelGGL(k_solve_step, dim3(k * NB > i_begin ? cdiv_c(k * NB - i_begin, 256) : 1, P), dim3(256), 0, st,
+                hipLaunchKernelGGL(k_solve_step, dim3(k * NB > i_begin ? cdiv_c(k * NB - i_begin, 256) : 1, P), dim3(256), 0, q,
                                    S, ld, k * NB, Linv + k * NB * NB, rhs, tmp, 1, i_begin, S_rows);
             }
-            hipLaunchKernelGGL(k_solution_back, dim3(cdiv_c(ld, 256)), dim3(256), 0, st, tmp, ld, d_newpos, rhs);
+            hipLaunchKernelGGL(k_solution_back, dim3(cdiv_c(ld, 256)), dim3(256), 0, q, tmp, ld, d_newpos, rhs);
         } else {
             for (int64_t k = nb - 1; k >= 0; --k) {
                 const int64_t i_begin = (int64_t)row_first[k] * NB;     // L has nothing left of the row's first entry
-                hipLaunchKernelGGL(k_solve_step, dim3(k * NB > i_begin ? cdiv_c(k * NB - i_begin, 256) : 1), dim3(256), 0, st, S,
+                hipLaunchKernelGGL(k_solve_step, dim3(k * NB > i_begin ? cdiv_c(k * NB - i_begin, 256) : 1), dim3(256), 0, q, S,
                                    ld, k * NB, Linv + k * NB * NB, rhs, tmp, 1, i_begin, (int64_t)0);
             }
-            if (e == hipSuccess) e = hipMemcpyAsync(rhs, tmp, sizeof(double) * ld, hipMemcpyDeviceToDevice, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(rhs, tmp, sizeof(double) * ld, hipMemcpyDeviceToDevice, q);
         }
-        // The caller keeps S for the next system: every block that can hold anything now - the envelope in the order
-        // the factorisation worked in, whole rows behind the chains, the row that carried the right-hand side - is
-        // cleared, at the cost of the entries of L instead of the n^2 of the whole matrix.
+        // The caller keeps S for the next system: what the factor occupied is cleared, at the cost of the entries of L
+        // instead of the n^2 of the whole matrix.
         if (clear_on_return && e == hipSuccess) {
-            if (first.empty()) {
-                e = hipMemsetAsync(S, 0, sizeof(double) * ld * ld, st);
-            } else {
-                std::vector<int4> runs;
-                auto add_run = [&](int64_t row, int64_t c_begin, int64_t c_last) {
-                    for (int64_t c = c_begin; c <= c_last; c += 32) runs.push_back(make_int4((int)row, (int)c, (int)std::min(c + 31, c_last), 0));
-                };
-                if (P > 1) {
-                    for (int c = 0; c < P; ++c)
-                        for (int64_t l = 0; l < s_blocks; ++l) add_run(c * s_blocks + l, c * s_blocks + chain_first[l], c * s_blocks + l);
-                    for (int64_t r = B0; r < nb; ++r) add_run(r, 0, r);
-                } else {
-                    for (int64_t r = 0; r + 1 < nb; ++r) add_run(r, row_first[r], r);
-                    add_run(nb - 1, 0, nb - 1);
-                }
-                int4 *d_runs = nullptr;
-                e = hipMalloc(&d_runs, sizeof(int4) * runs.size());
-                if (e == hipSuccess) e = hipMemcpyAsync(d_runs, runs.data(), sizeof(int4) * runs.size(), hipMemcpyHostToDevice, st);
-                if (e == hipSuccess) {
-                    hipLaunchKernelGGL(k_clear_runs, dim3((unsigned)runs.size()), dim3(256), 0, st, S, ld, d_runs);
-                    e = hipStreamSynchronize(st);       // `runs` goes out of use
-                }
-                hipFree(d_runs);
-            }
+            if (first.empty()) hipLaunchKernelGGL(k_zero_doubles, dim3(4096), dim3(256), 0, q, S, ld * ld);
+            else hipLaunchKernelGGL(k_clear_runs, dim3((unsigned)runs.size()), dim3(256), 0, q, S, ld, d_runs);
         }
-        if (e == hipSuccess) e = hipGetLastError();
+        return e;
+    };
+
+    // the lists that steer the moves and the clearing: uploaded when the profile they follow is not the last call's
+    // (waited for: the host vectors are this call's)
+    const bool same = ws.lists_valid && ws.n == n && ws.ld == ld && ws.clear == clear_on_return && ws.profile == first;
+    if (!same) {
+        ws.lists_valid = false;
+        if (P > 1) {
+            e = hipMemcpy(d_moves, moves.data(), sizeof(int4) * moves.size(), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(d_newpos, newpos.data(), sizeof(int) * nb, hipMemcpyHostToDevice);
+        }
+        if (e == hipSuccess && !runs.empty())
+            e = hipMemcpy(d_runs, runs.data(), sizeof(int4) * runs.size(), hipMemcpyHostToDevice);
+        BA_HIP(e);
+        ws.n = n, ws.ld = ld, ws.clear = clear_on_return, ws.profile = first, ws.lists_valid = true;
     }
+    e = issue(st);
+    if (e == hipSuccess) e = hipGetLastError();
     int hinfo = 0;
     if (e == hipSuccess) e = hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    hipFree(Linv);
-    hipFree(tmp);
-    hipFree(info);
-    hipFree(d_newpos);
     BA_HIP(e);
     if (h_info) *h_info = hinfo;
     if (hinfo != 0) {
