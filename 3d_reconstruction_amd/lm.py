@@ -25,6 +25,8 @@ own ones agree only to rounding), and the loop below runs identically on all ran
 branches on is the cross-GPU sum)."""
 from __future__ import annotations
 
+import time
+
 import numpy as np
 
 
@@ -37,15 +39,18 @@ class LMFit:
         self.E = np.zeros(self.max_iters)
         self.iters = 0
         self.accepted = self.rejected = 0
+        self.stamps = []        # host clock after every energy read-back (which waits for the GPU): [start, E_0, E_1, ...]
 
     def energies(self):
         return self.E[:self.iters + 1].copy()
 
     def run(self):
         sh = self.sh
+        self.stamps = [time.perf_counter()]
         sh.gauge_fix()
         sh.eval_jtj()
         E = sh.energy()
+        self.stamps.append(time.perf_counter())
         self.E[0] = E
         it = 0
         while it < self.max_iters - 1:
@@ -66,6 +71,7 @@ class LMFit:
             sh.swap_evaluation()
             sh.eval_jtj()
             E_new = sh.energy()
+            self.stamps.append(time.perf_counter())
             it += 1
             if np.isfinite(E_new) and E_new < E:
                 self.accepted += 1

@@ -15,5 +15,8 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 fit.run()
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 E = fit.energies()
-print(f'K={K} N={N} |V|={sc["i"].size}: {fit.iters} LM iterations ({fit.accepted} accepted, {fit.rejected} rejected) in {dt*1e3:.1f} ms '
-      f'= {dt/max(fit.iters,1)*1e3:.1f} ms each; E ' + ' '.join(f'{e:.5g}' for e in E), flush=True)
+st = np.diff(np.array(fit.stamps)) * 1e3      # [first evaluation, iteration 1 (allocates and zeroes S, ...), iteration 2, ...]
+later = st[2:] if len(st) > 2 else st[1:]
+print(f'K={K} N={N} |V|={sc["i"].size}: {fit.iters} LM iterations ({fit.accepted} accepted, {fit.rejected} rejected) in {dt*1e3:.1f} ms; '
+      f'first evaluation {st[0]:.1f} ms, first iteration {st[1]:.1f} ms (with the set-up of S), the others {later.mean():.2f} ms each '
+      f'(min {later.min():.2f}, max {later.max():.2f}); E ' + ' '.join(f'{e:.5g}' for e in E), flush=True)
