@@ -135,6 +135,9 @@ struct ba_problem {
         const double *s_in = nullptr, *r_in = nullptr;
         double *s_out = nullptr, *r_out = nullptr, *X_out = nullptr, *X_out_alt = nullptr;
     } armed_update;
+    // second stream of the Schur build (tiles with many cameras beside the others), created on first use
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t aux_fork = nullptr, aux_join = nullptr;
 };
 
 namespace ba {

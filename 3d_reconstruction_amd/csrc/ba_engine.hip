@@ -2577,6 +2577,11 @@ int ba_problem_destroy(ba_problem *p) {
     hipFree(p->row_ptr);
     hipFree(p->flag);
     if (p->mailbox_host) hipHostFree((void *)p->mailbox_host);
+    if (p->aux_stream) {
+        hipStreamDestroy(p->aux_stream);
+        hipEventDestroy(p->aux_fork);
+        hipEventDestroy(p->aux_join);
+    }
     for (auto e : p->ev_begin) hipEventDestroy(e);
     for (auto e : p->ev_end) hipEventDestroy(e);
     delete p;

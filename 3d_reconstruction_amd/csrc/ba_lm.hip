@@ -541,6 +541,7 @@ struct SchurTileArgs {
     double *Xphi;            // N x 3, written: point x phi column
     double *S, *rhs;
     int *first;              // optional: first occupied 64-column block of every 64-row block of S (atomic minimum)
+    int nc_min = 0, nc_max = 0x7fffffff;    // the launch deals with the tiles of nc_min .. nc_max cameras
 };
 
 __host__ __device__ inline size_t schur_tile_lds_doubles(int cam_cap, int max_deg, int waves = 16) {
@@ -581,7 +582,7 @@ __global__ void __launch_bounds__(SCHUR_TILE_BLOCK) k_schur_tile(SchurTileArgs a
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const TileMeta tm = a.meta[blockIdx.x];
     const int nc = tm.nc, np = tm.np, p0 = tm.p0;
-    if (tm.e0 >= tm.e1) return;
+    if (tm.e0 >= tm.e1 || nc < a.nc_min || nc > a.nc_max) return;
     const int m = 6 * nc;
     double *rows = lds;                                   // cam_cap x CAM_ROW
     double *Tt = rows + (size_t)a.cam_cap * CAM_ROW;      // cam_cap x 6 x 3: the three non-zero entries of every column of the frame change
@@ -963,6 +964,269 @@ __global__ void __launch_bounds__(SCHUR_TILE_BLOCK) k_schur_tile(SchurTileArgs a
     if (tid == 0) {
         __hip_atomic_fetch_add(a.S + nphi * a.ld + nphi, sc_t[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(a.rhs + nphi, sc_t[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// The same on the matrix cores.  With V'^-1 = L^-T L^-1 (V' = L L^T, 3 x 3) a point's contribution is a Gram matrix:
+// let Yt = L^-1 [ W(slot 0) | ... | W(slot nc-1) | w_phi | g ]  (3 x (6 nc + 2); W = 0 for the cameras that do not see
+// the point), then  Yt^T Yt  holds  W^T V'^-1 W  (subtracted from the camera blocks),  W^T V'^-1 w_phi  (from the row of
+// phi_x),  w_phi^T V'^-1 w_phi,  and in its last row  W^T V'^-1 g,  w_phi^T V'^-1 g  (added to the right-hand side).
+// Summed over the points of a tile that is  A^T A  with the 3 np rows of all points stacked: a product of a
+// (6 nc + 2) x 3 np matrix with its transpose, nine tenths of it non-zero in the tracks of a video.
+//
+// A wave takes four points at a time: one lane per observation forms the Jacobians and the six columns of L^-1 W
+// (instead of six lanes per observation, each with the observation's Jacobians), the rows go to the wave's own
+// 12 x Mp patch of LDS, and three steps of v_mfma_f64_4x4x4_4b_f64 (lane layout: see k_syrk_trailing in ba_chol.hip)
+// add the patch's Gram matrix to the lower 16 x 16 tiles the wave keeps in registers for the whole tile of points:
+// per step NBT column-operand registers and 4 NBT row-operand registers from LDS for 2 NBT (NBT + 1) instructions.
+// No barrier between waves until the end, where the waves' sums meet in LDS and leave for S as in k_schur_tile.
+// NBT = ceil((6 cam_cap + 2) / 16) <= 6, i.e. tiles of up to 15 cameras: beyond that the accumulators do not fit
+// the registers and k_schur_tile is used.
+// --------------------------------------------------------------------------------------------
+constexpr int SCHUR_GEMM_BLOCK = 512;
+constexpr int SCHUR_GEMM_PTS = 4;       // points per trip of a wave: 12 rows = three steps of four
+
+__host__ __device__ inline int schur_gemm_nbt(int cam_cap) { return (6 * cam_cap + 2 + 15) / 16; }
+__host__ __device__ inline size_t schur_gemm_lds_doubles(int cam_cap) {
+    const int nbt = schur_gemm_nbt(cam_cap) < 4 ? 4 : schur_gemm_nbt(cam_cap), mp = 16 * nbt;      // (the smallest kernel has NBT = 4)
+    return (size_t)cam_cap * (CAM_ROW + 18) + (size_t)(SCHUR_GEMM_BLOCK / 64) * (3 * SCHUR_GEMM_PTS * (mp + 1)) +
+           (size_t)nbt * (nbt + 1) / 2 * 256 + (size_t)(cam_cap + 1) / 2;
+}
+
+template <int NBT>
+__global__ void __launch_bounds__(SCHUR_GEMM_BLOCK) k_schur_gemm(SchurTileArgs a) {
+    extern __shared__ double lds[];
+    constexpr int MP = 16 * NBT, NT = NBT * (NBT + 1) / 2, ROWS = 3 * SCHUR_GEMM_PTS, PITCH = MP;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const TileMeta tm = a.meta[blockIdx.x];
+    const int nc = tm.nc, np = tm.np, p0 = tm.p0;
+    if (tm.e0 >= tm.e1 || nc < a.nc_min || nc > a.nc_max) return;
+    const int m = 6 * nc;       // columns: 6 per camera slot, then phi_x (m), then g (m + 1)
+    double *rows = lds;                                   // cam_cap x CAM_ROW
+    double *Tt = rows + (size_t)a.cam_cap * CAM_ROW;      // cam_cap x 6 x 3 (see k_schur_tile)
+    double *patch = Tt + (size_t)a.cam_cap * 18 + (size_t)wid * (ROWS * (PITCH + 1));   // ROWS x PITCH, then ROWS sums for w_phi
+    double *wsum = patch + ROWS * PITCH;
+    double *Gt = Tt + (size_t)a.cam_cap * 18 + (size_t)(SCHUR_GEMM_BLOCK / 64) * (ROWS * (PITCH + 1));   // NT tiles of 16 x 16
+    int *low = (int *)(Gt + (size_t)NT * 256);
+    for (int idx = tid; idx < a.cam_cap; idx += SCHUR_GEMM_BLOCK) low[idx] = 0x7fffffff;
+    for (int idx = tid; idx < nc * (CAM_ROW / 2); idx += SCHUR_GEMM_BLOCK) {
+        const int row = idx / (CAM_ROW / 2), piece = idx - row * (CAM_ROW / 2);
+        const int j = tm.j0 >= 0 ? tm.j0 + row : a.cam_list[tm.cb + row];
+        ((double2 *)rows)[idx] = ((const double2 *)(a.T + (int64_t)j * CAM_ROW))[piece];
+    }
+    for (int idx = tid; idx < nc * 18; idx += SCHUR_GEMM_BLOCK) {
+        const int row = idx / 18, rest = idx - 18 * row, al = rest / 3, k = rest - 3 * al;
+        const int j = tm.j0 >= 0 ? tm.j0 + row : a.cam_list[tm.cb + row];
+        const double *src = a.T + (int64_t)j * CAM_ROW;
+        double v;
+        if (al < 3) v = src[3 * al + k];
+        else if (al == 3) v = k == 0 ? src[12] : (k == 1 ? -src[13] : 0.0);
+        else if (al == 4) v = src[3 + k];
+        else v = k == 2 ? 1.0 : 0.0;
+        Tt[idx] = v;
+    }
+    for (int idx = tid; idx < NT * 256; idx += SCHUR_GEMM_BLOCK) Gt[idx] = 0.0;
+    const double f = a.scalars[SC_F], pcx = a.scalars[SC_CX], pcy = a.scalars[SC_CY], dphi = a.scalars[SC_DPHI];
+    __syncthreads();
+
+    double acc[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int I = 0; I < 4; ++I) acc[t][I] = 0.0;
+    // L^-1 of the damped point block (V6: upper triangle of V, row-major)
+    auto inverse_factor = [&](const double *V6, double *li /* i00 i10 i11 i20 i21 i22 */) {
+        const double va = V6[0] * (1.0 + a.lambda), vb = V6[1], vc = V6[2], vd = V6[3] * (1.0 + a.lambda), ve = V6[4],
+                     vg = V6[5] * (1.0 + a.lambda);
+        const double i00 = fast_rsqrt(va);
+        const double l10 = vb * i00, l20 = vc * i00;
+        const double i11 = fast_rsqrt(vd - l10 * l10);
+        const double l21 = (ve - l20 * l10) * i11;
+        const double i22 = fast_rsqrt(vg - l20 * l20 - l21 * l21);
+        li[0] = i00;
+        li[1] = -l10 * i00 * i11;
+        li[2] = i11;
+        li[4] = -l21 * i11 * i22;
+        li[3] = -(li[4] * l10 + i22 * l20) * i00;
+        li[5] = i22;
+    };
+    // The lanes of a wave hand data to each other through the wave's patch of LDS.  The LDS serves a wave's
+    // instructions in order, so all that is needed is that the compiler keeps them in order too - a fence would also
+    // wait for the loads of the next trip that are in flight on purpose.
+    auto lanes_sync = [&]() {
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+    };
+    const int nbt_tile = (m + 2 + 15) / 16;     // tile rows of this tile of points
+    // Sixteen lanes per point, lane o16 of them for the point's observation o16 (more than sixteen: further trips).
+    // What a trip reads from memory is requested one trip ahead, the observation ranges it needs for that two trips
+    // ahead: with two waves per SIMD nothing else would cover the two dependent trips to memory per group of points.
+    constexpr int GSTEP = SCHUR_GEMM_PTS * (SCHUR_GEMM_BLOCK / 64);
+    const int pl = lane >> 4, o16 = lane & 15;
+    struct GroupIn {
+        uint32_t pk;
+        double2 uv;
+        double V6[6], x[3], g[3];
+    };
+    auto range_of = [&](int first_pt, int64_t &eb, int &deg) {
+        eb = 0, deg = 0;
+        if (first_pt + pl < np) {
+            eb = a.row_ptr[p0 + first_pt + pl];
+            deg = (int)(a.row_ptr[p0 + first_pt + pl + 1] - eb);
+        }
+    };
+    auto fetch = [&](int first_pt, int64_t eb, int deg, GroupIn &q) {
+        q.pk = 0;
+        q.uv = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) q.V6[k] = k == 0 || k == 3 || k == 5 ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) q.x[k] = q.g[k] = 0.0;
+        if (deg > 0) {
+            const int64_t i = (int64_t)p0 + first_pt + pl;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) q.V6[k] = a.V[6 * i + k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) q.x[k] = a.X[3 * i + k];
+            if (o16 == 0) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) q.g[k] = a.gX[3 * i + k];
+            }
+            if (o16 < deg) {
+                q.pk = a.opack[eb + o16];
+                q.uv = a.ouv[eb + o16];
+            }
+        }
+    };
+    for (int pt0 = SCHUR_GEMM_PTS * wid; pt0 < np; pt0 += GSTEP) {
+        int64_t eb_c;
+        int deg_c;
+        GroupIn cur;
+        range_of(pt0, eb_c, deg_c);
+        fetch(pt0, eb_c, deg_c, cur);
+        for (int idx = lane; idx < ROWS * (PITCH + 1); idx += 64) patch[idx] = 0.0;
+        lanes_sync();
+        double li[6];
+        inverse_factor(cur.V6, li);
+        const int64_t i = (int64_t)p0 + pt0 + pl;
+        auto one_observation = [&](uint32_t pk, double2 uv) {
+            const int slot = (int)(pk & 0xffffu);
+            const ObsJac ob = obs_jacobian(cur.x, (const double2 *)(rows + slot * CAM_ROW), f, pcx, pcy, uv);
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                __hip_atomic_fetch_add(wsum + 3 * pl + k, dphi * (ob.jx0[k] * ob.m0 + ob.jx1[k] * ob.m1), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+            double *dst = patch + (3 * pl) * PITCH + 6 * slot;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const double *tc = Tt + (slot * 6 + c) * 3;         // column c of J_cam = G T
+                const double jc0 = ob.G0[c < 3 ? 0 : 3] * tc[0] + ob.G0[c < 3 ? 1 : 4] * tc[1] + ob.G0[c < 3 ? 2 : 5] * tc[2];
+                const double jc1 = ob.G1[c < 3 ? 0 : 3] * tc[0] + ob.G1[c < 3 ? 1 : 4] * tc[1] + ob.G1[c < 3 ? 2 : 5] * tc[2];
+                const double W0 = ob.jx0[0] * jc0 + ob.jx1[0] * jc1, W1 = ob.jx0[1] * jc0 + ob.jx1[1] * jc1,
+                             W2 = ob.jx0[2] * jc0 + ob.jx1[2] * jc1;
+                // (added, not stored: a point seen twice by one camera contributes the sum of both blocks)
+                __hip_atomic_fetch_add(dst + c, li[0] * W0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(dst + PITCH + c, li[1] * W0 + li[2] * W1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(dst + 2 * PITCH + c, li[3] * W0 + li[4] * W1 + li[5] * W2, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        };
+        if (o16 < deg_c) one_observation(cur.pk, cur.uv);
+        for (int o = o16 + 16; o < deg_c; o += 16) one_observation(a.opack[eb_c + o], a.ouv[eb_c + o]);
+        lanes_sync();
+        if (o16 == 0 && pt0 + pl < np) {       // the point's own two columns: phi_x and g
+            const bool seen = deg_c > 0;
+            const double wp[3] = {wsum[3 * pl], wsum[3 * pl + 1], wsum[3 * pl + 2]};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) a.Xphi[3 * i + k] = seen ? wp[k] : 0.0;
+            if (seen) {
+                double *dst = patch + (3 * pl) * PITCH + m;
+                dst[0] = li[0] * wp[0];
+                dst[PITCH] = li[1] * wp[0] + li[2] * wp[1];
+                dst[2 * PITCH] = li[3] * wp[0] + li[4] * wp[1] + li[5] * wp[2];
+                dst[1] = li[0] * cur.g[0];
+                dst[PITCH + 1] = li[1] * cur.g[0] + li[2] * cur.g[1];
+                dst[2 * PITCH + 1] = li[3] * cur.g[0] + li[4] * cur.g[1] + li[5] * cur.g[2];
+            }
+        }
+        lanes_sync();
+#pragma unroll
+        for (int ks = 0; ks < ROWS / 4; ++ks) {
+            const double *src = patch + (4 * ks + (lane >> 4)) * PITCH;
+            double bop[NBT], aop[NBT][4];
+#pragma unroll
+            for (int t = 0; t < NBT; ++t) {
+                bop[t] = src[16 * t + (lane & 15)];
+#pragma unroll
+                for (int I = 0; I < 4; ++I) aop[t][I] = src[16 * t + 4 * I + (lane & 3)];
+            }
+#pragma unroll
+            for (int tr = 0; tr < NBT; ++tr) {
+                if (tr < nbt_tile) {
+#pragma unroll
+                    for (int I = 0; I < 4; ++I) {
+                        if (16 * tr + 4 * I >= m + 2) continue;      // rows of the Gram matrix beyond the tile's last column
+#pragma unroll
+                        for (int tc = 0; tc <= tr; ++tc)
+                            acc[tr * (tr + 1) / 2 + tc][I] =
+                                __builtin_amdgcn_mfma_f64_4x4x4f64(aop[tr][I], bop[tc], acc[tr * (tr + 1) / 2 + tc][I], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        lanes_sync();
+    }
+    // the waves' sums meet in LDS: entry (16 tr + 4 I + (lane >> 4), 16 tc + (lane & 15)) of the Gram matrix
+#pragma unroll
+    for (int tr = 0; tr < NBT; ++tr)
+#pragma unroll
+        for (int tc = 0; tc <= tr; ++tc)
+#pragma unroll
+            for (int I = 0; I < 4; ++I)
+                __hip_atomic_fetch_add(Gt + (tr * (tr + 1) / 2 + tc) * 256 + (4 * I + (lane >> 4)) * 16 + (lane & 15),
+                                       acc[tr * (tr + 1) / 2 + tc][I], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __syncthreads();
+    const int64_t nphi = 6 * a.K;
+    if (a.first) {      // (the tile's camera slots are in the order of the camera numbers)
+        // two cameras share a point exactly when their block of the Gram matrix is not zero
+        for (int idx = tid; idx < NT * 256; idx += SCHUR_GEMM_BLOCK) {
+            if (Gt[idx] == 0.0) continue;
+            const int t = idx >> 8, within = idx & 255;
+            int tr = 0;
+            while ((tr + 1) * (tr + 2) / 2 <= t) ++tr;
+            const int r = 16 * tr + (within >> 4), c = 16 * (t - tr * (tr + 1) / 2) + (within & 15);
+            if (c <= r && r < m) atomicMin(low + r / 6, c / 6);
+        }
+        __syncthreads();
+        for (int sr = tid; sr < nc; sr += SCHUR_GEMM_BLOCK) {
+            if (low[sr] > sr) continue;
+            const int64_t jr = tm.j0 >= 0 ? tm.j0 + sr : a.cam_list[tm.cb + sr];
+            const int64_t jc = tm.j0 >= 0 ? tm.j0 + low[sr] : a.cam_list[tm.cb + low[sr]];
+            note_block_first(a.first, jr, jc);
+        }
+    }
+    // global row of local row / column r <= m: a camera's unknown or phi_x
+    auto global_index = [&](int r) -> int64_t {
+        if (r == m) return nphi;
+        const int sr = r / 6;
+        const int64_t j = tm.j0 >= 0 ? tm.j0 + sr : a.cam_list[tm.cb + sr];
+        return 6 * j + (r - 6 * sr);
+    };
+    for (int idx = tid; idx < NT * 256; idx += SCHUR_GEMM_BLOCK) {
+        const double v = Gt[idx];
+        if (v == 0.0) continue;
+        const int t = idx >> 8, within = idx & 255;
+        int tr = 0;
+        while ((tr + 1) * (tr + 2) / 2 <= t) ++tr;
+        const int tc = t - tr * (tr + 1) / 2;
+        const int r = 16 * tr + (within >> 4), c = 16 * tc + (within & 15);
+        if (c > r || r > m + 1 || c > m) continue;
+        if (r == m + 1) {       // the row of g: right-hand side
+            __hip_atomic_fetch_add(a.rhs + global_index(c), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            __hip_atomic_fetch_add(a.S + global_index(r) * a.ld + global_index(c), -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -1374,6 +1638,51 @@ int ba_schur_build_tracked(ba_problem *p, const double *X, double lambda, const 
             hipLaunchKernelGGL(kernel, dim3(p->n_tiles), dim3(block), lds_tile, st, ta);
             return BA_OK;
         };
+        // tiles of up to 15 cameras: the Gram-matrix form on the matrix cores; the others (if any: in a closed camera
+        // path the tiles that hold its first and last cameras) in a launch of the pair kernel on a second stream beside
+        // it - a few workgroups that each run for the length of a tenth of the other launch.  Either kernel returns at
+        // once from a tile that is not its own; both add to S with atomics.
+        constexpr int GEMM_MAX_CAMS = 15;
+        if (!form && !getenv("BA_SCHUR_NO_MFMA")) {
+            const bool rest = p->cam_cap > GEMM_MAX_CAMS;
+            if (rest) {
+                if (!p->aux_stream) {
+                    BA_HIP(hipStreamCreateWithFlags(&p->aux_stream, hipStreamNonBlocking));
+                    BA_HIP(hipEventCreateWithFlags(&p->aux_fork, hipEventDisableTiming));
+                    BA_HIP(hipEventCreateWithFlags(&p->aux_join, hipEventDisableTiming));
+                }
+                BA_HIP(hipEventRecord(p->aux_fork, st));
+                BA_HIP(hipStreamWaitEvent(p->aux_stream, p->aux_fork, 0));
+                SchurTileArgs tr = ta;
+                tr.nc_min = GEMM_MAX_CAMS + 1;
+                if (lds_tile > 64 * 1024)
+                    BA_HIP(hipFuncSetAttribute((const void *)k_schur_tile<true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tile));
+                hipLaunchKernelGGL((k_schur_tile<true, 512>), dim3(p->n_tiles), dim3(512), lds_tile, p->aux_stream, tr);
+                BA_HIP(hipEventRecord(p->aux_join, p->aux_stream));
+            }
+            // one launch per accumulator size: tiles of up to 13 and of 14 .. 15 cameras (5, 6 tile rows of 16; 4 when
+            // no tile of the scene has more than 10: a launch of its own for the small tiles of a scene with larger
+            // ones does not pay)
+            const int caps[3] = {p->cam_cap <= 10 ? 10 : 0, 13, GEMM_MAX_CAMS};
+            int done_up_to = 0;
+            for (int v = 0; v < 3 && done_up_to < p->cam_cap; ++v) {
+                if (caps[v] <= done_up_to) continue;
+                SchurTileArgs tg = ta;
+                tg.nc_min = done_up_to + 1;
+                tg.nc_max = caps[v] < p->cam_cap ? caps[v] : p->cam_cap;
+                tg.cam_cap = tg.nc_max;
+                const size_t lds_gemm = sizeof(double) * schur_gemm_lds_doubles(tg.cam_cap);
+                const void *fn = v == 0 ? (const void *)k_schur_gemm<4> : (v == 1 ? (const void *)k_schur_gemm<5> : (const void *)k_schur_gemm<6>);
+                if (lds_gemm > 64 * 1024) BA_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_gemm));
+                if (v == 0) hipLaunchKernelGGL(k_schur_gemm<4>, dim3(p->n_tiles), dim3(SCHUR_GEMM_BLOCK), lds_gemm, st, tg);
+                else if (v == 1) hipLaunchKernelGGL(k_schur_gemm<5>, dim3(p->n_tiles), dim3(SCHUR_GEMM_BLOCK), lds_gemm, st, tg);
+                else hipLaunchKernelGGL(k_schur_gemm<6>, dim3(p->n_tiles), dim3(SCHUR_GEMM_BLOCK), lds_gemm, st, tg);
+                done_up_to = tg.nc_max;
+            }
+            if (rest) BA_HIP(hipStreamWaitEvent(st, p->aux_join, 0));
+            BA_HIP(hipGetLastError());
+            return BA_OK;
+        }
         int rc;
         if (which == 0) rc = launch(k_schur_tile<false, 1024>, 1024);
         else if (which == 1) rc = launch(k_schur_tile<true, 1024>, 1024);

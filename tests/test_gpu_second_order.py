@@ -325,6 +325,51 @@ def test_schur_tile_kernel_mixed_track_lengths(ba):
     sh.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,K,track,tile_obs', [(8000, 40, 10, None), (8000, 40, 4, None), (6800, 80, 10, None),
+                                                (3000, 300, 10, '512'), (20000, 100, 10, None)])
+def test_schur_gram_kernel_equals_pair_kernel(ba, N, K, track, tile_obs):
+    """Tiles of up to 15 cameras go through the Gram-matrix kernel on the matrix cores, the others through the pair
+    kernel beside it (a closed orbit has both kinds: the tiles at its seam hold the first and the last cameras).
+    Same S, right-hand side, point x phi column and block profile as with the pair kernel alone; some points lose
+    observations at random, some all of them."""
+    import os
+    sc = ba.scenes.orbit_scene(N=N, K=K, track_len=track, seed=5)
+    rng = np.random.default_rng(N + K)
+    keep = rng.random(sc['i'].size) < rng.choice([1.0, 0.7, 0.0], size=N, p=[0.7, 0.27, 0.03])[sc['i']]
+    i, j, uv = sc['i'][keep], sc['j'][keep], sc['uv'][keep]
+    if tile_obs:
+        os.environ['BA_TILE_OBS'] = tile_obs
+    try:
+        sh = ba.engine.Shard(i, j, uv, N, K, sc['W'], sc['H'], DEV)
+    finally:
+        os.environ.pop('BA_TILE_OBS', None)
+    sh.set_params(sc['X_0'], sc['C_0'], sc['Theta_0'], sc['phi_x_0'])
+    sh.eval_jtj()
+    lib, p = sh.lib, ba.engine.ptr
+    first = torch.zeros(sh.ld_red // 64 + 1, dtype=torch.int32, device=DEV)
+
+    def build():
+        sh.S.zero_()
+        ba.engine.check(lib.ba_schur_build_tracked(sh.handle, p(sh.X), 1e-3, p(sh.V), p(sh.Xphi), p(sh.gX), p(sh.B),
+                                                   p(sh.bphi), p(sh.hphi), p(sh.gC), p(sh.gTheta), p(sh.gphi), 1, p(sh.S),
+                                                   p(sh.rhs), p(first), 1, ba.engine._lib.stream_ptr()))
+        n = sh.n_red
+        return (torch.tril(sh.S[:n, :n]).cpu().numpy(), sh.rhs[:n].cpu().numpy(), sh.Xphi.cpu().numpy().copy(),
+                first.cpu().numpy().copy())
+    got = build()
+    os.environ['BA_SCHUR_NO_MFMA'] = '1'
+    try:
+        want = build()
+    finally:
+        os.environ.pop('BA_SCHUR_NO_MFMA', None)
+    for a, b in zip(got[:3], want[:3]):
+        assert np.isfinite(a).all()
+        assert np.abs(a - b).max() <= 1e-11 * np.abs(b).max()
+    assert (got[3] == want[3]).all()
+    sh.close()
+
+
 def _numpy_lm(sc, iters, lam):
     """The same LM loop with dense NumPy normal equations (reference for the trajectory)."""
     X, C, Th = orc.align_scene(sc['X_0'], sc['C_0'], Theta=sc['Theta_0'])
