@@ -778,7 +778,7 @@ __global__ void __launch_bounds__(256) k_solve_step(const double *__restrict__ A
 
 using namespace ba;
 
-// (kernels instead of memset commands: the sequence they belong to is captured into a graph)
+// (the two clearing steps of a call, as kernels like everything else it queues)
 __global__ void k_zero_int(int *p) { *p = 0; }
 __global__ void k_zero_doubles(double *__restrict__ p, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0.0;
