@@ -984,7 +984,7 @@ __global__ void __launch_bounds__(SCHUR_TILE_BLOCK) k_schur_tile(SchurTileArgs a
 // NBT = ceil((6 cam_cap + 2) / 16) <= 6, i.e. tiles of up to 15 cameras: beyond that the accumulators do not fit
 // the registers and k_schur_tile is used.
 // --------------------------------------------------------------------------------------------
-constexpr int SCHUR_GEMM_BLOCK = 512;
+constexpr int SCHUR_GEMM_BLOCK = 256;
 constexpr int SCHUR_GEMM_PTS = 4;       // points per trip of a wave: 12 rows = three steps of four
 
 __host__ __device__ inline int schur_gemm_nbt(int cam_cap) { return (6 * cam_cap + 2 + 15) / 16; }
@@ -995,7 +995,7 @@ __host__ __device__ inline size_t schur_gemm_lds_doubles(int cam_cap) {
 }
 
 template <int NBT>
-__global__ void __launch_bounds__(SCHUR_GEMM_BLOCK) k_schur_gemm(SchurTileArgs a) {
+__global__ void __launch_bounds__(SCHUR_GEMM_BLOCK, 2) k_schur_gemm(SchurTileArgs a) {
     extern __shared__ double lds[];
     constexpr int MP = 16 * NBT, NT = NBT * (NBT + 1) / 2, ROWS = 3 * SCHUR_GEMM_PTS, PITCH = MP;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
