@@ -121,6 +121,12 @@ struct ba_problem {
     double *partials_jtj = nullptr;  // 3 per tile
     int64_t *row_ptr = nullptr;      // N + 1
     int max_degree = 0;              // most observations of one point
+    // Schur build on the matrix cores: ranges of points of a tile whose cameras lie within a window of slots
+    // ({tile, first point in the tile, points, first slot | cameras << 16}), and per tile whether the pair kernel
+    // takes it instead (a point of it sees cameras further apart than the window); built on first use
+    int4 *schur_sub = nullptr;
+    int *schur_rest = nullptr;
+    int n_schur_sub = 0, n_schur_rest = -1;
     // timing ring
     std::vector<hipEvent_t> ev_begin, ev_end;
     int ev_count = 0;

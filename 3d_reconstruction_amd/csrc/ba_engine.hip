@@ -2575,6 +2575,8 @@ int ba_problem_destroy(ba_problem *p) {
     hipFree(p->cam_sums_jtj);
     hipFree(p->partials_jtj);
     hipFree(p->row_ptr);
+    hipFree(p->schur_sub);
+    hipFree(p->schur_rest);
     hipFree(p->flag);
     if (p->mailbox_host) hipHostFree((void *)p->mailbox_host);
     if (p->aux_stream) {

@@ -541,7 +541,8 @@ struct SchurTileArgs {
     double *Xphi;            // N x 3, written: point x phi column
     double *S, *rhs;
     int *first;              // optional: first occupied 64-column block of every 64-row block of S (atomic minimum)
-    int nc_min = 0, nc_max = 0x7fffffff;    // the launch deals with the tiles of nc_min .. nc_max cameras
+    const int4 *sub = nullptr;   // k_schur_gemm: its ranges of points (one workgroup each)
+    const int *only = nullptr;   // k_schur_tile: if given, the tiles it deals with (flag per tile)
 };
 
 __host__ __device__ inline size_t schur_tile_lds_doubles(int cam_cap, int max_deg, int waves = 16) {
@@ -582,7 +583,7 @@ __global__ void __launch_bounds__(SCHUR_TILE_BLOCK) k_schur_tile(SchurTileArgs a
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const TileMeta tm = a.meta[blockIdx.x];
     const int nc = tm.nc, np = tm.np, p0 = tm.p0;
-    if (tm.e0 >= tm.e1 || nc < a.nc_min || nc > a.nc_max) return;
+    if (tm.e0 >= tm.e1 || (a.only && !a.only[blockIdx.x])) return;
     const int m = 6 * nc;
     double *rows = lds;                                   // cam_cap x CAM_ROW
     double *Tt = rows + (size_t)a.cam_cap * CAM_ROW;      // cam_cap x 6 x 3: the three non-zero entries of every column of the frame change
@@ -999,10 +1000,12 @@ __global__ void __launch_bounds__(SCHUR_GEMM_BLOCK, 2) k_schur_gemm(SchurTileArg
     extern __shared__ double lds[];
     constexpr int MP = 16 * NBT, NT = NBT * (NBT + 1) / 2, ROWS = 3 * SCHUR_GEMM_PTS, PITCH = MP;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const TileMeta tm = a.meta[blockIdx.x];
-    const int nc = tm.nc, np = tm.np, p0 = tm.p0;
-    if (tm.e0 >= tm.e1 || nc < a.nc_min || nc > a.nc_max) return;
-    const int m = 6 * nc;       // columns: 6 per camera slot, then phi_x (m), then g (m + 1)
+    // a range of points of a tile and the window of the tile's camera slots they see
+    const int4 sub = a.sub[blockIdx.x];
+    const TileMeta tm = a.meta[sub.x];
+    const int slot_lo = sub.w & 0xffff, nc = sub.w >> 16, np = sub.z, p0 = tm.p0 + sub.y;
+    auto camera_of = [&](int s) -> int64_t { return tm.j0 >= 0 ? tm.j0 + slot_lo + s : a.cam_list[tm.cb + slot_lo + s]; };
+    const int m = 6 * nc;       // columns: 6 per camera slot of the window, then phi_x (m), then g (m + 1)
     double *rows = lds;                                   // cam_cap x CAM_ROW
     double *Tt = rows + (size_t)a.cam_cap * CAM_ROW;      // cam_cap x 6 x 3 (see k_schur_tile)
     double *patch = Tt + (size_t)a.cam_cap * 18 + (size_t)wid * (ROWS * (PITCH + 1));   // ROWS x PITCH, then ROWS sums for w_phi
@@ -1012,13 +1015,11 @@ __global__ void __launch_bounds__(SCHUR_GEMM_BLOCK, 2) k_schur_gemm(SchurTileArg
     for (int idx = tid; idx < a.cam_cap; idx += SCHUR_GEMM_BLOCK) low[idx] = 0x7fffffff;
     for (int idx = tid; idx < nc * (CAM_ROW / 2); idx += SCHUR_GEMM_BLOCK) {
         const int row = idx / (CAM_ROW / 2), piece = idx - row * (CAM_ROW / 2);
-        const int j = tm.j0 >= 0 ? tm.j0 + row : a.cam_list[tm.cb + row];
-        ((double2 *)rows)[idx] = ((const double2 *)(a.T + (int64_t)j * CAM_ROW))[piece];
+        ((double2 *)rows)[idx] = ((const double2 *)(a.T + camera_of(row) * CAM_ROW))[piece];
     }
     for (int idx = tid; idx < nc * 18; idx += SCHUR_GEMM_BLOCK) {
         const int row = idx / 18, rest = idx - 18 * row, al = rest / 3, k = rest - 3 * al;
-        const int j = tm.j0 >= 0 ? tm.j0 + row : a.cam_list[tm.cb + row];
-        const double *src = a.T + (int64_t)j * CAM_ROW;
+        const double *src = a.T + camera_of(row) * CAM_ROW;
         double v;
         if (al < 3) v = src[3 * al + k];
         else if (al == 3) v = k == 0 ? src[12] : (k == 1 ? -src[13] : 0.0);
@@ -1111,7 +1112,7 @@ __global__ void __launch_bounds__(SCHUR_GEMM_BLOCK, 2) k_schur_gemm(SchurTileArg
         inverse_factor(cur.V6, li);
         const int64_t i = (int64_t)p0 + pt0 + pl;
         auto one_observation = [&](uint32_t pk, double2 uv) {
-            const int slot = (int)(pk & 0xffffu);
+            const int slot = (int)(pk & 0xffffu) - slot_lo;
             const ObsJac ob = obs_jacobian(cur.x, (const double2 *)(rows + slot * CAM_ROW), f, pcx, pcy, uv);
 #pragma unroll
             for (int k = 0; k < 3; ++k)
@@ -1201,17 +1202,14 @@ __global__ void __launch_bounds__(SCHUR_GEMM_BLOCK, 2) k_schur_gemm(SchurTileArg
         __syncthreads();
         for (int sr = tid; sr < nc; sr += SCHUR_GEMM_BLOCK) {
             if (low[sr] > sr) continue;
-            const int64_t jr = tm.j0 >= 0 ? tm.j0 + sr : a.cam_list[tm.cb + sr];
-            const int64_t jc = tm.j0 >= 0 ? tm.j0 + low[sr] : a.cam_list[tm.cb + low[sr]];
-            note_block_first(a.first, jr, jc);
+            note_block_first(a.first, camera_of(sr), camera_of(low[sr]));
         }
     }
     // global row of local row / column r <= m: a camera's unknown or phi_x
     auto global_index = [&](int r) -> int64_t {
         if (r == m) return nphi;
         const int sr = r / 6;
-        const int64_t j = tm.j0 >= 0 ? tm.j0 + sr : a.cam_list[tm.cb + sr];
-        return 6 * j + (r - 6 * sr);
+        return 6 * camera_of(sr) + (r - 6 * sr);
     };
     for (int idx = tid; idx < NT * 256; idx += SCHUR_GEMM_BLOCK) {
         const double v = Gt[idx];
@@ -1574,6 +1572,85 @@ static int ensure_row_ptr(ba_problem *p) {
     return BA_OK;
 }
 
+// Lowest and highest camera slot (of its tile) among a point's observations; {INT_MAX, -1} for a point nobody sees.
+__global__ void k_point_slot_range(int64_t N, const int64_t *__restrict__ row_ptr, const uint32_t *__restrict__ opack,
+                                   int2 *__restrict__ range) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    int lo = 0x7fffffff, hi = -1;
+    for (int64_t e = row_ptr[i]; e < row_ptr[i + 1]; ++e) {
+        const int s = (int)(opack[e] & 0xffffu);
+        lo = min(lo, s);
+        hi = max(hi, s);
+    }
+    range[i] = make_int2(lo, hi);
+}
+
+// Cuts every tile into ranges of consecutive points whose cameras lie within a window of SCHUR_GEMM_WINDOW slots of
+// the tile (k_schur_gemm's accumulators hold that many cameras): in the tracks of a video a tile of 384 points with
+// 18 cameras becomes two ranges with 13 and 12.  A tile with a point that alone sees cameras further apart (the seam
+// of a closed camera path) is left to the pair kernel.
+constexpr int SCHUR_GEMM_WINDOW = 13;       // 6 x 13 + 2 = 80 columns: five tile rows of 16
+static int ensure_schur_subtiles(ba_problem *p) {
+    if (p->n_schur_rest >= 0) return BA_OK;
+    const int64_t N = p->N;
+    const int nt = p->n_tiles;
+    int2 *d_range = nullptr;
+    BA_HIP(hipMalloc(&d_range, sizeof(int2) * N));
+    hipLaunchKernelGGL(k_point_slot_range, dim3(cdiv_i(N, 256)), dim3(256), 0, 0, N, p->row_ptr, p->opack, d_range);
+    std::vector<int2> range((size_t)N);
+    std::vector<TileMeta> meta((size_t)nt);
+    hipError_t e = hipMemcpy(range.data(), d_range, sizeof(int2) * N, hipMemcpyDeviceToHost);
+    hipFree(d_range);
+    BA_HIP(e);
+    BA_HIP(hipMemcpy(meta.data(), p->tile_meta, sizeof(TileMeta) * nt, hipMemcpyDeviceToHost));
+    std::vector<int4> subs;
+    std::vector<int> rest((size_t)nt, 0);
+    int n_rest = 0;
+    for (int t = 0; t < nt; ++t) {
+        const TileMeta &tm = meta[t];
+        if (tm.e0 >= tm.e1) continue;
+        const size_t mark = subs.size();
+        bool ok = true;
+        int begin = 0, lo = 0x7fffffff, hi = -1;
+        auto close = [&](int end) {
+            if (end > begin) subs.push_back(make_int4(t, begin, end - begin, hi >= lo ? (lo | ((hi - lo + 1) << 16)) : (0 | (1 << 16))));
+        };
+        for (int pt = 0; pt < tm.np && ok; ++pt) {
+            const int2 r = range[(size_t)tm.p0 + pt];
+            if (r.y < r.x) continue;                                   // nobody sees it: it rides along
+            if (r.y - r.x + 1 > SCHUR_GEMM_WINDOW) ok = false;
+            else if (hi >= lo && std::max(hi, r.y) - std::min(lo, r.x) + 1 > SCHUR_GEMM_WINDOW) {
+                close(pt);
+                begin = pt, lo = r.x, hi = r.y;
+            } else {
+                lo = std::min(lo, r.x), hi = std::max(hi, r.y);
+            }
+        }
+        if (ok) {
+            close(tm.np);
+        } else {
+            subs.resize(mark);
+            rest[t] = 1;
+            ++n_rest;
+        }
+    }
+    hipFree(p->schur_sub), hipFree(p->schur_rest);
+    p->schur_sub = nullptr, p->schur_rest = nullptr;
+    if (!subs.empty()) {
+        BA_HIP(hipMalloc(&p->schur_sub, sizeof(int4) * subs.size()));
+        BA_HIP(hipMemcpy(p->schur_sub, subs.data(), sizeof(int4) * subs.size(), hipMemcpyHostToDevice));
+    }
+    BA_HIP(hipMalloc(&p->schur_rest, sizeof(int) * (nt > 0 ? nt : 1)));
+    BA_HIP(hipMemcpy(p->schur_rest, rest.data(), sizeof(int) * nt, hipMemcpyHostToDevice));
+    p->n_schur_sub = (int)subs.size();
+    p->n_schur_rest = n_rest;
+    if (getenv("BA_VERBOSE"))
+        fprintf(stderr, "[ba] schur: %d ranges of points for the matrix-core kernel, %d of %d tiles left to the pair kernel\n",
+                p->n_schur_sub, n_rest, nt);
+    return BA_OK;
+}
+
 int ba_schur_build(ba_problem *p, const double *X, double lambda, const double *V, double *Xphi, const double *gX,
                    const double *B, const double *bphi, const double *hphi, const double *gC, const double *gTheta,
                    const double *gphi, int with_camera_blocks, double *S, double *rhs, void *stream) {
@@ -1638,13 +1715,13 @@ int ba_schur_build_tracked(ba_problem *p, const double *X, double lambda, const 
             hipLaunchKernelGGL(kernel, dim3(p->n_tiles), dim3(block), lds_tile, st, ta);
             return BA_OK;
         };
-        // tiles of up to 15 cameras: the Gram-matrix form on the matrix cores; the others (if any: in a closed camera
-        // path the tiles that hold its first and last cameras) in a launch of the pair kernel on a second stream beside
-        // it - a few workgroups that each run for the length of a tenth of the other launch.  Either kernel returns at
-        // once from a tile that is not its own; both add to S with atomics.
-        constexpr int GEMM_MAX_CAMS = 15;
+        // The Gram-matrix form on the matrix cores for every range of points whose cameras fit its window
+        // (ensure_schur_subtiles); the tiles it cannot take (if any: in a closed camera path those at the seam, which
+        // hold its first and last cameras) go to the pair kernel on a second stream beside it - a few workgroups that
+        // each run for the length of a fifth of the other launch.  Both add to S with atomics.
         if (!form && !getenv("BA_SCHUR_NO_MFMA")) {
-            const bool rest = p->cam_cap > GEMM_MAX_CAMS;
+            if (int rc = ensure_schur_subtiles(p)) return rc;
+            const bool rest = p->n_schur_rest > 0;
             if (rest) {
                 if (!p->aux_stream) {
                     BA_HIP(hipStreamCreateWithFlags(&p->aux_stream, hipStreamNonBlocking));
@@ -1654,30 +1731,21 @@ int ba_schur_build_tracked(ba_problem *p, const double *X, double lambda, const 
                 BA_HIP(hipEventRecord(p->aux_fork, st));
                 BA_HIP(hipStreamWaitEvent(p->aux_stream, p->aux_fork, 0));
                 SchurTileArgs tr = ta;
-                tr.nc_min = GEMM_MAX_CAMS + 1;
+                tr.only = p->schur_rest;
                 if (lds_tile > 64 * 1024)
                     BA_HIP(hipFuncSetAttribute((const void *)k_schur_tile<true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tile));
                 hipLaunchKernelGGL((k_schur_tile<true, 512>), dim3(p->n_tiles), dim3(512), lds_tile, p->aux_stream, tr);
                 BA_HIP(hipEventRecord(p->aux_join, p->aux_stream));
             }
-            // one launch per accumulator size: tiles of up to 13 and of 14 .. 15 cameras (5, 6 tile rows of 16; 4 when
-            // no tile of the scene has more than 10: a launch of its own for the small tiles of a scene with larger
-            // ones does not pay)
-            const int caps[3] = {p->cam_cap <= 10 ? 10 : 0, 13, GEMM_MAX_CAMS};
-            int done_up_to = 0;
-            for (int v = 0; v < 3 && done_up_to < p->cam_cap; ++v) {
-                if (caps[v] <= done_up_to) continue;
+            if (p->n_schur_sub > 0) {
                 SchurTileArgs tg = ta;
-                tg.nc_min = done_up_to + 1;
-                tg.nc_max = caps[v] < p->cam_cap ? caps[v] : p->cam_cap;
-                tg.cam_cap = tg.nc_max;
+                tg.sub = p->schur_sub;
+                tg.cam_cap = SCHUR_GEMM_WINDOW;
+                constexpr int NBT = (6 * SCHUR_GEMM_WINDOW + 2 + 15) / 16;
                 const size_t lds_gemm = sizeof(double) * schur_gemm_lds_doubles(tg.cam_cap);
-                const void *fn = v == 0 ? (const void *)k_schur_gemm<4> : (v == 1 ? (const void *)k_schur_gemm<5> : (const void *)k_schur_gemm<6>);
-                if (lds_gemm > 64 * 1024) BA_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_gemm));
-                if (v == 0) hipLaunchKernelGGL(k_schur_gemm<4>, dim3(p->n_tiles), dim3(SCHUR_GEMM_BLOCK), lds_gemm, st, tg);
-                else if (v == 1) hipLaunchKernelGGL(k_schur_gemm<5>, dim3(p->n_tiles), dim3(SCHUR_GEMM_BLOCK), lds_gemm, st, tg);
-                else hipLaunchKernelGGL(k_schur_gemm<6>, dim3(p->n_tiles), dim3(SCHUR_GEMM_BLOCK), lds_gemm, st, tg);
-                done_up_to = tg.nc_max;
+                if (lds_gemm > 64 * 1024)
+                    BA_HIP(hipFuncSetAttribute((const void *)k_schur_gemm<NBT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_gemm));
+                hipLaunchKernelGGL(k_schur_gemm<NBT>, dim3(p->n_schur_sub), dim3(SCHUR_GEMM_BLOCK), lds_gemm, st, tg);
             }
             if (rest) BA_HIP(hipStreamWaitEvent(st, p->aux_join, 0));
             BA_HIP(hipGetLastError());
