@@ -982,8 +982,10 @@ __global__ void __launch_bounds__(SCHUR_TILE_BLOCK) k_schur_tile(SchurTileArgs a
 // add the patch's Gram matrix to the lower 16 x 16 tiles the wave keeps in registers for the whole tile of points:
 // per step NBT column-operand registers and 4 NBT row-operand registers from LDS for 2 NBT (NBT + 1) instructions.
 // No barrier between waves until the end, where the waves' sums meet in LDS and leave for S as in k_schur_tile.
-// NBT = ceil((6 cam_cap + 2) / 16) <= 6, i.e. tiles of up to 15 cameras: beyond that the accumulators do not fit
-// the registers and k_schur_tile is used.
+// A workgroup's share is not a whole tile but a range of its points whose cameras lie within a window of cam_cap
+// slots (ensure_schur_subtiles): NBT = ceil((6 cam_cap + 2) / 16) tile rows of accumulators must fit the registers
+// at two waves per SIMD (NBT = 5, a window of 13 cameras: 214 registers; a sixth row spills, a seventh needs the
+// whole register file of a SIMD for one wave and was slower).
 // --------------------------------------------------------------------------------------------
 constexpr int SCHUR_GEMM_BLOCK = 256;
 constexpr int SCHUR_GEMM_PTS = 4;       // points per trip of a wave: 12 rows = three steps of four
