@@ -326,9 +326,10 @@ def test_schur_tile_kernel_mixed_track_lengths(ba):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('N,K,track,tile_obs', [(8000, 40, 10, None), (8000, 40, 4, None), (6800, 80, 10, None),
-                                                (3000, 300, 10, '512'), (20000, 100, 10, None)])
-def test_schur_gram_kernel_equals_pair_kernel(ba, N, K, track, tile_obs):
+@pytest.mark.parametrize('N,K,track,tile_obs,relabel', [(8000, 40, 10, None, 1), (8000, 40, 4, None, 1), (6800, 80, 10, None, 1),
+                                                        (3000, 300, 10, '512', 1), (20000, 100, 10, None, 1),
+                                                        (20000, 100, 10, None, 7), (8000, 41, 10, None, 9)])
+def test_schur_gram_kernel_equals_pair_kernel(ba, N, K, track, tile_obs, relabel):
     """Tiles of up to 15 cameras go through the Gram-matrix kernel on the matrix cores, the others through the pair
     kernel beside it (a closed orbit has both kinds: the tiles at its seam hold the first and the last cameras).
     Same S, right-hand side, point x phi column and block profile as with the pair kernel alone; some points lose
@@ -338,13 +339,22 @@ def test_schur_gram_kernel_equals_pair_kernel(ba, N, K, track, tile_obs):
     rng = np.random.default_rng(N + K)
     keep = rng.random(sc['i'].size) < rng.choice([1.0, 0.7, 0.0], size=N, p=[0.7, 0.27, 0.03])[sc['i']]
     i, j, uv = sc['i'][keep], sc['j'][keep], sc['uv'][keep]
+    C_0, Theta_0 = sc['C_0'], sc['Theta_0']
+    if relabel > 1:     # camera numbers scattered (a tile's cameras are then a list, not a range of numbers)
+        perm = (np.arange(K) * relabel) % K
+        assert np.unique(perm).size == K
+        j = perm[j].astype(j.dtype)
+        order = np.lexsort((j, i))
+        i, j, uv = i[order], j[order], uv[order]
+        C_0, Theta_0 = np.empty_like(C_0), np.empty_like(Theta_0)
+        C_0[perm], Theta_0[perm] = sc['C_0'], sc['Theta_0']
     if tile_obs:
         os.environ['BA_TILE_OBS'] = tile_obs
     try:
         sh = ba.engine.Shard(i, j, uv, N, K, sc['W'], sc['H'], DEV)
     finally:
         os.environ.pop('BA_TILE_OBS', None)
-    sh.set_params(sc['X_0'], sc['C_0'], sc['Theta_0'], sc['phi_x_0'])
+    sh.set_params(sc['X_0'], C_0, Theta_0, sc['phi_x_0'])
     sh.eval_jtj()
     lib, p = sh.lib, ba.engine.ptr
     first = torch.zeros(sh.ld_red // 64 + 1, dtype=torch.int32, device=DEV)
