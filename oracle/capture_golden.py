@@ -55,8 +55,11 @@ def make_scene(N, K, seed, vis_frac=1.0, W=1920, H=1080, phi_x=1.2):
                 X_0=X0, C_0=C0, Theta_0=Th0, phi_x_0=phi_x * 1.02)
 
 
-def run_reference(scene, lr, max_iters, optimizer='Adam', masks=(True, True, True), **kw):
-    """Run p.fit_scene with the recording hooks installed; returns a dict of arrays."""
+def run_reference(scene, lr, max_iters, optimizer='Adam', masks=(True, True, True), frame_hook=None, **kw):
+    """Run p.fit_scene with the recording hooks installed; returns a dict of arrays.
+    `frame_hook(step_index, locals_of_fit_scene)` is called once per update, before the first
+    group's update rule runs: the registry entry is called from inside fit_scene (p2w:705), so the
+    caller's frame holds that iteration's intermediate arrays (read only, nothing is modified)."""
     steps = []          # one entry per executed update: {'X':(x,g), 'C':..., ...}
     cur = {}
     names = []
@@ -71,6 +74,8 @@ def run_reference(scene, lr, max_iters, optimizer='Adam', masks=(True, True, Tru
     manager_calls = []
 
     def rec_update(x, grad, lr_, **state):
+        if frame_hook is not None and not cur:
+            frame_hook(len(steps), sys._getframe(1).f_locals)
         name = names[len(cur)]
         cur[name] = (np.array(x, dtype=np.float64).copy(), np.array(grad, dtype=np.float64).copy())
         if len(cur) == len(names):
@@ -488,6 +493,56 @@ def capture_f10(out):
     save_npz(os.path.join(out, 'f10_early_stops.npz'), **arrays)
 
 
+def _jacobian_recorder(keep, store):
+    """frame_hook for run_reference: at the update steps listed in `keep`, copy the visible entries
+    of the per-observation Jacobians the reference has just formed (p2w:654-657 D['X_model','X'],
+    p2w:694-695 D['X_model','Theta'], p2w:700-701 D['X_model','phi_x']), the residuals (p2w:573) and
+    the rotation matrices they were formed with (p2w:606-609, 711)."""
+    def hook(step, loc):
+        if step not in keep:
+            return
+        vis, D = loc['X_visible'], loc['D']
+        store[step] = dict(J_X=D['X_model', 'X'][vis].copy(), J_Theta=D['X_model', 'Theta'][vis].copy(),
+                           J_phi=D['X_model', 'phi_x'][vis].copy(), r=loc['X_diff'][vis].copy(),
+                           R=np.array(loc['R']).copy(), Rx=np.array(loc['Rx']).copy(),
+                           Ry=np.array(loc['Ry']).copy(), Rz=np.array(loc['Rz']).copy(),
+                           f=np.array(loc['f'], dtype=np.float64).reshape(-1)[:1].copy())
+    return hook
+
+
+def capture_f11(out):
+    """Per-observation Jacobians of the reference itself (the pin of the J^T J blocks, the Schur
+    complement and the LM step, none of which the reference forms): the F1 scene (all groups free,
+    Adam) at its first four iterates and the moscow_ride tracks at iterates 0 and 3."""
+    arrays = {}
+    sc = make_scene(60, 15, seed=3, vis_frac=0.6)
+    vis = sc['X_pix'][:, :, 0] >= 0
+    ii, jj = np.nonzero(vis)
+    store = {}
+    r = run_reference(sc, lr=1e-3, max_iters=5, frame_hook=_jacobian_recorder({0, 1, 2, 3}, store))
+    arrays.update(f1_N=60, f1_K=15, f1_W=sc['W'], f1_H=sc['H'], f1_obs_i=ii.astype(np.int32),
+                  f1_obs_j=jj.astype(np.int32), f1_obs_xy=sc['X_pix'][vis].astype(np.int32),
+                  f1_keep=np.array(sorted(store)))
+    for n in ('X', 'C', 'Theta', 'phi_x'):
+        arrays['f1_step_' + n] = r['step_' + n][sorted(store)]
+        arrays['f1_grad_' + n] = r['grad_' + n][sorted(store)]
+    for k in store[0]:
+        arrays['f1_' + k] = np.array([store[t][k] for t in sorted(store)])
+
+    X_pix, W, H = read_tracks_pickle(os.path.join(REF_DIR, 'demo_examples/moscow_ride/input.txt'))
+    X0, C0, Th0, phi0 = moscow_init(X_pix, W, H)
+    sc = dict(X_pix=X_pix, W=W, H=H, X_0=X0, C_0=C0, Theta_0=Th0, phi_x_0=phi0)
+    store = {}
+    r = run_reference(sc, lr=1e-3, max_iters=5, patience=1000, frame_hook=_jacobian_recorder({0, 3}, store))
+    arrays['f2_keep'] = np.array(sorted(store))       # observation list, sizes: f2_moscow_ride.npz
+    for n in ('X', 'C', 'Theta', 'phi_x'):
+        arrays['f2_step_' + n] = r['step_' + n][sorted(store)]
+        arrays['f2_grad_' + n] = r['grad_' + n][sorted(store)]
+    for k in store[0]:
+        arrays['f2_' + k] = np.array([store[t][k] for t in sorted(store)])
+    save_npz(os.path.join(out, 'f11_jacobians.npz'), **arrays)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden'))
@@ -495,7 +550,8 @@ def main():
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     todo = dict(f1=capture_f1, f2=capture_f2, f3=capture_f3, f4=capture_f4, f5=capture_f5,
-                f6=capture_f6, f7=capture_f7, f8=capture_f8, f9=capture_f9, f10=capture_f10)
+                f6=capture_f6, f7=capture_f7, f8=capture_f8, f9=capture_f9, f10=capture_f10,
+                f11=capture_f11)
     for name, fn in todo.items():
         if a.only and name not in a.only.split(','):
             continue

@@ -1,6 +1,9 @@
-"""Second-order extension (J^T J blocks, Schur complement, fp64 Cholesky, LM step).  The reference
-has no such solver: these results are pinned by this repository's own dense normal equations
-(oracle.dense_jacobian) on small scenes — "parity unpinned" with respect to the reference."""
+"""Second-order extension (J^T J blocks, Schur complement, fp64 Cholesky, LM step).  The reference has no
+such solver, but it forms the per-observation Jacobians these quantities are made of (p2w:654-657, 694-695,
+700-701): golden F11 holds them as the reference computed them at its own iterates, and
+test_second_order_blocks_from_the_reference_jacobians pins V, B, bphi, hphi, the reduced system S / rhs and the
+damped step to what those arrays give.  The other tests use oracle.dense_jacobian on scenes of other shapes;
+tests/test_oracle_golden.py checks that restatement against the same golden entry by entry."""
 import importlib
 import os
 
@@ -8,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import f11_case, normal_equations_from_jacobians, rel_err, row_err
 from oracle import ba_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -72,6 +75,56 @@ def test_jtj_blocks_match_dense_normal_equations(ba, layout, env, tile_obs):
     assert rel_err(sh.B.cpu().numpy(), B_ref) < 1e-10
     assert rel_err(sh.bphi.cpu().numpy(), b_ref) < 1e-10
     assert abs(float(sh.hphi.item()) - H[-1, -1]) < 1e-10 * H[-1, -1]
+    sh.close()
+
+
+@pytest.mark.parametrize('layout', ['default', 'point-major', 'blocks'])
+@pytest.mark.parametrize('which,t', [('f1', 0), ('f1', 1), ('f1', 2), ('f1', 3), ('f2', 0), ('f2', 1)])
+def test_second_order_blocks_from_the_reference_jacobians(ba, golden, which, t, layout):
+    """Teacher-forced at the reference's iterates (F1 scene, moscow_ride tracks): the blocks of the J^T J pass,
+    the reduced camera system of the Schur build and the damped step equal what the REFERENCE's per-observation
+    Jacobians (golden F11, read out of fit_scene's frame while it ran) give, to 1e-9."""
+    c = f11_case(golden, which, t)
+    N, K, lam = c['N'], c['K'], 1e-3
+    env = {'BA_BLOCK_MIN_FILL': '0'} if layout == 'blocks' else {}
+    os.environ.update(env)
+    try:
+        sh = ba.engine.Shard(c['i'], c['j'], c['uv'], N, K, c['W'], c['H'], DEV)
+    finally:
+        for k in env:
+            os.environ.pop(k, None)
+    sh.set_params(c['step_X'], c['step_C'], c['step_Theta'], float(c['step_phi_x'][0]))
+    sh.eval_jtj(point_major=layout == 'point-major', dense_blocks=layout == 'blocks')
+    ne = normal_equations_from_jacobians(c, lam)
+    back = lambda x: sh.points_to_caller(x).cpu().numpy()
+    rr = float((c['r'] ** 2).sum())
+    assert abs(float(sh.E_sum.item()) - rr) <= 1e-9 * rr
+    g = ne['g']
+    gcam = g[3 * N:3 * N + 6 * K].reshape(K, 6)
+    assert row_err(back(sh.gX), g[:3 * N].reshape(N, 3)) < 1e-9
+    assert row_err(sh.gC.cpu().numpy(), gcam[:, :3]) < 1e-9 and row_err(sh.gTheta.cpu().numpy(), gcam[:, 3:]) < 1e-9
+    assert abs(float(sh.gphi.item()) - g[-1]) <= 1e-9 * abs(g[-1])
+    assert row_err(back(sh.V), ne['V']) < 1e-9
+    assert row_err(sh.B.cpu().numpy(), ne['B']) < 1e-9
+    assert row_err(sh.bphi.cpu().numpy(), ne['bphi']) < 1e-9
+    assert abs(float(sh.hphi.item()) - ne['hphi']) <= 1e-9 * ne['hphi']
+    lib, p = sh.lib, ba.engine.ptr
+    ba.engine.check(lib.ba_schur_build(sh.handle, p(sh.X), lam, p(sh.V), p(sh.Xphi), p(sh.gX), p(sh.B), p(sh.bphi),
+                                       p(sh.hphi), p(sh.gC), p(sh.gTheta), p(sh.gphi), 1, p(sh.S), p(sh.rhs), None))
+    n = sh.n_red
+    S, rhs = torch.tril(sh.S[:n, :n]).cpu().numpy(), sh.rhs[:n].cpu().numpy()
+    assert np.abs(S - np.tril(ne['S'])).max() <= 1e-9 * np.abs(ne['S']).max()
+    assert np.abs(rhs - ne['rhs']).max() <= 1e-9 * np.abs(ne['rhs']).max()
+    assert rel_err(back(sh.Xphi), ne['Xphi']) < 1e-9
+    # the damped step itself (conditioning of the reduced system: looser, like the other step tests)
+    sh.S.zero_()
+    assert sh.lm_step(lam) == 0
+    seen = np.repeat(np.bincount(c['i'], minlength=N) > 0, 3)
+    d = np.zeros(3 * N + 6 * K + 1)
+    d[np.r_[seen, np.ones(6 * K + 1, bool)]] = ne['step']
+    per_cam = d[3 * N:3 * N + 6 * K].reshape(K, 6)       # the step leaves as [dC | dTheta | dphi]
+    assert rel_err(sh.dcam.cpu().numpy(), np.r_[per_cam[:, :3].ravel(), per_cam[:, 3:].ravel(), d[-1]]) < 1e-6
+    assert rel_err(back(sh.dX).ravel()[seen], d[:3 * N][seen]) < 1e-6
     sh.close()
 
 

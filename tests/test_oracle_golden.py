@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, logs_match, rel_err
+from conftest import GOLDEN, f11_case, logs_match, normal_equations_from_jacobians, rel_err
 from oracle import ba_oracle as orc
 
 TOL = 1e-9       # per-iteration energy / gradient contract (relative, max-norm)
@@ -350,3 +350,34 @@ def test_f9_h_diff_matrix(golden):
         assert np.array_equal(np.isnan(got), np.isnan(ref))
         ok = ~np.isnan(ref)
         assert (np.abs(got - ref)[ok] <= 1e-9 * ref[ok]).all()
+
+
+@pytest.mark.parametrize('which,t', [('f1', 0), ('f1', 1), ('f1', 2), ('f1', 3), ('f2', 0), ('f2', 1)])
+def test_f11_jacobians_of_the_reference(golden, which, t):
+    """The restatement's per-observation Jacobian blocks against the arrays the reference itself formed inside
+    fit_scene (p2w:654-657, 694-695, 700-701), with the rotation matrices the reference used at that iterate; and
+    the gradients the reference handed to its update rule are J^T r / |V| of those very blocks."""
+    c = f11_case(golden, which, t)
+    r, J_X, J_Theta, J_phi = orc.jacobian_blocks(c['step_X'], c['step_C'], c['R'], c['Rx'], c['Ry'], c['Rz'],
+                                                 float(c['f'][0]), float(c['step_phi_x'][0]), c['W'], c['H'],
+                                                 c['i'], c['j'], c['uv'])
+    assert rel_err(r, c['r']) < 1e-12
+    assert rel_err(J_X, c['J_X']) < 1e-12
+    assert rel_err(J_Theta, c['J_Theta']) < 1e-12
+    assert rel_err(J_phi, c['J_phi']) < 1e-12
+    # dense_jacobian (angles -> R by sincos, what the second-order tests use) against the same arrays
+    rr, J = orc.dense_jacobian(c['step_X'], c['step_C'], c['step_Theta'], c['step_phi_x'], c['W'], c['H'],
+                               c['i'], c['j'], c['uv'])
+    N, K, nV = c['N'], c['K'], c['i'].size
+    o = np.arange(nV)
+    for a in range(2):
+        for b in range(3):
+            assert rel_err(J[2 * o + a, 3 * c['i'] + b], c['J_X'][:, a, b]) < 1e-10
+            assert rel_err(J[2 * o + a, 3 * N + 3 * K + 3 * c['j'] + b], c['J_Theta'][:, a, b]) < 1e-10
+        assert rel_err(J[2 * o + a, -1], c['J_phi'][:, a]) < 1e-10
+    ne = normal_equations_from_jacobians(c)
+    g = ne['g'] / nV
+    assert rel_err(g[:3 * N].reshape(N, 3), c['grad_X']) < 1e-12
+    gcam = g[3 * N:3 * N + 6 * K].reshape(K, 6)
+    assert rel_err(gcam[:, :3], c['grad_C']) < 1e-12 and rel_err(gcam[:, 3:], c['grad_Theta']) < 1e-12
+    assert abs(g[-1] - c['grad_phi_x'][0]) < 1e-12 * abs(c['grad_phi_x'][0])
