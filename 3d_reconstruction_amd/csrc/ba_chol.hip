@@ -73,7 +73,7 @@ struct CholCache {
     Buf linv, tmp, info, newpos, moves, T, runs, first;
     // what the lists in `newpos`, `moves` and `runs` were built for
     bool lists_valid = false;
-    int64_t n = 0, ld = 0;
+    int64_t n = 0, ld = 0, chains = 0, chain_blocks = 0, sep_blocks = 0;
     int clear = 0;
     std::vector<int> profile;
     hipError_t grow(Buf &b, size_t bytes) {
@@ -1097,7 +1097,9 @@ int ba_cholesky_solve_tracked(int64_t n, int64_t ld, double *S, double *rhs, con
 
     // the lists that steer the moves and the clearing: uploaded when the profile they follow is not the last call's
     // (waited for: the host vectors are this call's)
-    const bool same = ws.lists_valid && ws.n == n && ws.ld == ld && ws.clear == clear_on_return && ws.profile == first;
+    // (the layout also depends on the split into chains, which a switch can change under one and the same profile)
+    const bool same = ws.lists_valid && ws.n == n && ws.ld == ld && ws.clear == clear_on_return && ws.profile == first &&
+                      ws.chains == P && ws.chain_blocks == s_blocks && ws.sep_blocks == bw;
     if (!same) {
         ws.lists_valid = false;
         if (P > 1) {
@@ -1108,6 +1110,7 @@ int ba_cholesky_solve_tracked(int64_t n, int64_t ld, double *S, double *rhs, con
             e = hipMemcpy(d_runs, runs.data(), sizeof(int4) * runs.size(), hipMemcpyHostToDevice);
         BA_HIP(e);
         ws.n = n, ws.ld = ld, ws.clear = clear_on_return, ws.profile = first, ws.lists_valid = true;
+        ws.chains = P, ws.chain_blocks = s_blocks, ws.sep_blocks = bw;
     }
     e = issue(st);
     if (e == hipSuccess) e = hipGetLastError();

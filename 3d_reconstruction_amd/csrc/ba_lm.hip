@@ -1230,7 +1230,10 @@ __global__ void __launch_bounds__(SCHUR_GEMM_BLOCK, 2) k_schur_gemm(SchurTileArg
     }
 }
 
-// One wave per point.  LDS per wave: W (deg x 18) and Z = V'^-1 W (deg x 18), camera index (deg).
+// One wave per point.  LDS per wave: W (cap x 18) and Z = V'^-1 W (cap x 18), camera indices (2 x cap), with
+// cap = a.max_deg rows.  A point with more observations than that (a keypoint tracked through hundreds of frames)
+// goes through in chunks of cap: the W rows of chunk A against the Z rows of chunk B for every pair of chunks, the
+// rows formed again for every pair (only such points pay for it).
 __global__ void __launch_bounds__(256) k_schur_points(SchurArgs a) {
     extern __shared__ double lds[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -1242,23 +1245,29 @@ __global__ void __launch_bounds__(256) k_schur_points(SchurArgs a) {
         if (lane < 3) a.Xphi[3 * i + lane] = 0.0;
         return;
     }
-    double *Wl = lds + (size_t)wid * a.max_deg * 37;
-    double *Zl = Wl + (size_t)a.max_deg * 18;
-    int *jl = (int *)(Zl + (size_t)a.max_deg * 18);
+    const int cap = a.max_deg;
+    double *Wl = lds + (size_t)wid * cap * 37;
+    double *Zl = Wl + (size_t)cap * 18;
+    int *jA = (int *)(Zl + (size_t)cap * 18), *jB = jA + cap;
     const double f = a.scalars[SC_F], pcx = a.scalars[SC_CX], pcy = a.scalars[SC_CY], dphi = a.scalars[SC_DPHI];
     double Vi[6];
     inv_sym3(a.V + 6 * i, a.lambda, Vi);
     const double x[3] = {a.X[3 * i], a.X[3 * i + 1], a.X[3 * i + 2]};
     // point x phi column w = dphi sum_obs J_X^T m (summed here, stored for the back-substitution)
     double wp[3] = {0.0, 0.0, 0.0};
+    int lowest = 0x7fffffff;
     for (int o = lane; o < deg; o += 64) {
         const int64_t e = e0 + o;
-        const ObsJac ob = obs_jacobian(x, (const double2 *)(a.T + (int64_t)a.oj[e] * CAM_ROW), f, pcx, pcy, a.ouv[e]);
+        const int j = a.oj[e];
+        lowest = min(lowest, j);
+        const ObsJac ob = obs_jacobian(x, (const double2 *)(a.T + (int64_t)j * CAM_ROW), f, pcx, pcy, a.ouv[e]);
 #pragma unroll
         for (int k = 0; k < 3; ++k) wp[k] += ob.jx0[k] * ob.m0 + ob.jx1[k] * ob.m1;
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) wp[k] = dphi * wave_sum(wp[k]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) lowest = min(lowest, __shfl_xor(lowest, off));
     if (lane < 3) a.Xphi[3 * i + lane] = lane == 0 ? wp[0] : (lane == 1 ? wp[1] : wp[2]);
     const double gx[3] = {a.gX[3 * i], a.gX[3 * i + 1], a.gX[3 * i + 2]};
     // V'^-1 wphi and V'^-1 gX
@@ -1267,77 +1276,100 @@ __global__ void __launch_bounds__(256) k_schur_points(SchurArgs a) {
     const double zg[3] = {Vi[0] * gx[0] + Vi[1] * gx[1] + Vi[2] * gx[2], Vi[1] * gx[0] + Vi[3] * gx[1] + Vi[4] * gx[2],
                           Vi[2] * gx[0] + Vi[4] * gx[1] + Vi[5] * gx[2]};
     const int64_t nphi = 6 * a.K;
-
-    for (int o = lane; o < deg; o += 64) {
-        const int64_t e = e0 + o;
-        const int j = a.oj[e];
-        const double *row = a.T + (int64_t)j * CAM_ROW;
-        ObsJac ob = obs_jacobian(x, (const double2 *)row, f, pcx, pcy, a.ouv[e]);
-        double Tm[6][6];
-        camera_frame_change(row, Tm);
-        double jc0[6], jc1[6];  // rows of J_cam = G T
-#pragma unroll
-        for (int al = 0; al < 6; ++al) {
-            double v0 = 0.0, v1 = 0.0;
-#pragma unroll
-            for (int mu = 0; mu < 6; ++mu) {
-                v0 += ob.G0[mu] * Tm[mu][al];
-                v1 += ob.G1[mu] * Tm[mu][al];
-            }
-            jc0[al] = v0;
-            jc1[al] = v1;
-        }
-        double W[3][6];
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int al = 0; al < 6; ++al) W[p][al] = ob.jx0[p] * jc0[al] + ob.jx1[p] * jc1[al];
-#pragma unroll
-        for (int al = 0; al < 6; ++al) {
-            const double z0 = Vi[0] * W[0][al] + Vi[1] * W[1][al] + Vi[2] * W[2][al];
-            const double z1 = Vi[1] * W[0][al] + Vi[3] * W[1][al] + Vi[4] * W[2][al];
-            const double z2 = Vi[2] * W[0][al] + Vi[4] * W[1][al] + Vi[5] * W[2][al];
-            Wl[o * 18 + 0 * 6 + al] = W[0][al];
-            Wl[o * 18 + 1 * 6 + al] = W[1][al];
-            Wl[o * 18 + 2 * 6 + al] = W[2][al];
-            Zl[o * 18 + 0 * 6 + al] = z0;
-            Zl[o * 18 + 1 * 6 + al] = z1;
-            Zl[o * 18 + 2 * 6 + al] = z2;
-            // camera x phi column, right-hand side
-            const double sphi = W[0][al] * zw[0] + W[1][al] * zw[1] + W[2][al] * zw[2];
-            const double rr = W[0][al] * zg[0] + W[1][al] * zg[1] + W[2][al] * zg[2];
-            const int64_t ra = 6 * (int64_t)j + al;
-            __hip_atomic_fetch_add(a.S + nphi * a.ld + ra, -sphi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(a.rhs + ra, rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        jl[o] = j;
-    }
     if (lane == 0) {
         const double spp = wp[0] * zw[0] + wp[1] * zw[1] + wp[2] * zw[2];
         const double rp = wp[0] * zg[0] + wp[1] * zg[1] + wp[2] * zg[2];
         __hip_atomic_fetch_add(a.S + nphi * a.ld + nphi, -spp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(a.rhs + nphi, rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __builtin_amdgcn_wave_barrier();
-    __threadfence_block();
-    if (a.first) {
-        int lowest = 0x7fffffff;
-        for (int o = lane; o < deg; o += 64) lowest = min(lowest, jl[o]);
+
+    // rows of the observations c0 .. c0 + cn - 1: W into Wd and / or Z into Zd (either may be null), camera indices
+    // into jd; emit: these observations' part of the camera x phi column, of the right-hand side and of the profile
+    auto rows = [&](int c0, int cn, double *Wd, double *Zd, int *jd, bool emit) {
+        for (int o = lane; o < cn; o += 64) {
+            const int64_t e = e0 + c0 + o;
+            const int j = a.oj[e];
+            const double *row = a.T + (int64_t)j * CAM_ROW;
+            ObsJac ob = obs_jacobian(x, (const double2 *)row, f, pcx, pcy, a.ouv[e]);
+            double Tm[6][6];
+            camera_frame_change(row, Tm);
+            double jc0[6], jc1[6];  // rows of J_cam = G T
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) lowest = min(lowest, __shfl_xor(lowest, off));
-        for (int o = lane; o < deg; o += 64) note_block_first(a.first, jl[o], lowest);
+            for (int al = 0; al < 6; ++al) {
+                double v0 = 0.0, v1 = 0.0;
+#pragma unroll
+                for (int mu = 0; mu < 6; ++mu) {
+                    v0 += ob.G0[mu] * Tm[mu][al];
+                    v1 += ob.G1[mu] * Tm[mu][al];
+                }
+                jc0[al] = v0;
+                jc1[al] = v1;
+            }
+            double W[3][6];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int al = 0; al < 6; ++al) W[p][al] = ob.jx0[p] * jc0[al] + ob.jx1[p] * jc1[al];
+#pragma unroll
+            for (int al = 0; al < 6; ++al) {
+                if (Wd) {
+                    Wd[o * 18 + 0 * 6 + al] = W[0][al];
+                    Wd[o * 18 + 1 * 6 + al] = W[1][al];
+                    Wd[o * 18 + 2 * 6 + al] = W[2][al];
+                }
+                if (Zd) {
+                    Zd[o * 18 + 0 * 6 + al] = Vi[0] * W[0][al] + Vi[1] * W[1][al] + Vi[2] * W[2][al];
+                    Zd[o * 18 + 1 * 6 + al] = Vi[1] * W[0][al] + Vi[3] * W[1][al] + Vi[4] * W[2][al];
+                    Zd[o * 18 + 2 * 6 + al] = Vi[2] * W[0][al] + Vi[4] * W[1][al] + Vi[5] * W[2][al];
+                }
+                if (emit) {     // camera x phi column, right-hand side
+                    const double sphi = W[0][al] * zw[0] + W[1][al] * zw[1] + W[2][al] * zw[2];
+                    const double rr = W[0][al] * zg[0] + W[1][al] * zg[1] + W[2][al] * zg[2];
+                    const int64_t ra = 6 * (int64_t)j + al;
+                    __hip_atomic_fetch_add(a.S + nphi * a.ld + ra, -sphi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(a.rhs + ra, rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            jd[o] = j;
+            if (emit && a.first) note_block_first(a.first, j, lowest);
+        }
+    };
+    // all ordered pairs (o in chunk A, o' in chunk B) of observations, 36 entries each: S[j, j'] -= W_o^T Z_o'
+    auto pairs = [&](int na, int nb) {
+        const int total = na * nb * 36;
+        for (int w = lane; w < total; w += 64) {
+            const int pair = w / 36, ent = w - pair * 36;
+            const int o = pair / nb, o2 = pair - o * nb;
+            const int al = ent / 6, be = ent - al * 6;
+            const double v = Wl[o * 18 + al] * Zl[o2 * 18 + be] + Wl[o * 18 + 6 + al] * Zl[o2 * 18 + 6 + be] +
+                             Wl[o * 18 + 12 + al] * Zl[o2 * 18 + 12 + be];
+            if (jA[o] < jB[o2] || (jA[o] == jB[o2] && al < be)) continue;  // lower triangle only: nothing reads the rest
+            const int64_t ra = 6 * (int64_t)jA[o] + al, cbx = 6 * (int64_t)jB[o2] + be;
+            __hip_atomic_fetch_add(a.S + ra * a.ld + cbx, -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    if (deg <= cap) {
+        rows(0, deg, Wl, Zl, jA, true);
+        for (int o = lane; o < deg; o += 64) jB[o] = a.oj[e0 + o];
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        pairs(deg, deg);
+        return;
     }
-    // all ordered pairs (o, o') of the point's observations, 36 entries each: S[j, j'] -= W_o^T Z_o'
-    const int total = deg * deg * 36;
-    for (int w = lane; w < total; w += 64) {
-        const int pair = w / 36, ent = w - pair * 36;
-        const int o = pair / deg, o2 = pair - o * deg;
-        const int al = ent / 6, be = ent - al * 6;
-        const double v = Wl[o * 18 + al] * Zl[o2 * 18 + be] + Wl[o * 18 + 6 + al] * Zl[o2 * 18 + 6 + be] +
-                         Wl[o * 18 + 12 + al] * Zl[o2 * 18 + 12 + be];
-        if (jl[o] < jl[o2] || (jl[o] == jl[o2] && al < be)) continue;  // lower triangle only: nothing reads the rest
-        const int64_t ra = 6 * (int64_t)jl[o] + al, cbx = 6 * (int64_t)jl[o2] + be;
-        __hip_atomic_fetch_add(a.S + ra * a.ld + cbx, -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int ca = 0; ca < deg; ca += cap) {
+        const int na = min(cap, deg - ca);
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();          // the pairs of the last trip have read W
+        rows(ca, na, Wl, nullptr, jA, true);
+        for (int cb = 0; cb < deg; cb += cap) {
+            const int nb = min(cap, deg - cb);
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();      // ... and Z
+            rows(cb, nb, nullptr, Zl, jB, false);
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+            pairs(na, nb);
+        }
     }
 }
 
@@ -1670,15 +1702,19 @@ int ba_schur_build_tracked(ba_problem *p, const double *X, double lambda, const 
     hipStream_t st = (hipStream_t)stream;
     int64_t n, ld;
     ba_schur_dim(p->K, &n, &ld);
-    const size_t lds = (size_t)4 * p->max_degree * 37 * sizeof(double);
+    // rows of W and Z a wave of the point kernel keeps in LDS; points with more observations go through in chunks
+    constexpr int SCHUR_POINT_ROWS = 128;
+    const int point_rows = getenv("BA_SCHUR_POINT_ROWS") ? std::max(1, atoi(getenv("BA_SCHUR_POINT_ROWS")))
+                                                          : std::min(p->max_degree, SCHUR_POINT_ROWS);
+    const size_t lds = (size_t)4 * point_rows * 37 * sizeof(double);
     const char *form = getenv("BA_SCHUR_FORM");      // 0: entry-per-lane pair loop; 1: pairs in registers, 16 waves; 2: 8 waves
     const int which = form ? atoi(form) : 2;
     const int tile_waves = which < 2 ? 16 : 8;
     const size_t lds_tile = p->tiled ? sizeof(double) * schur_tile_lds_doubles(p->cam_cap, p->max_degree, tile_waves) : ~(size_t)0;
     const bool use_tile = p->tiled && p->tiles_worth && lds_tile <= 150 * 1024 && !getenv("BA_SCHUR_POINTS");
     if (!use_tile && lds > 160 * 1024 - 256) {
-        set_error("ba_schur_build: a point has too many observations for the Schur kernel");
-        return BA_ERR_STATE;
+        set_error("ba_schur_build: BA_SCHUR_POINT_ROWS asks for more LDS than a workgroup has");
+        return BA_ERR_ARG;
     }
     if (!S_is_zero) BA_HIP(hipMemsetAsync(S, 0, sizeof(double) * ld * ld, st));
     if (block_first)
@@ -1777,7 +1813,7 @@ int ba_schur_build_tracked(ba_problem *p, const double *X, double lambda, const 
     a.gX = gX;
     a.S = S;
     a.rhs = rhs;
-    a.max_deg = p->max_degree;
+    a.max_deg = point_rows;
     a.first = block_first;
     if (lds > 64 * 1024)
         BA_HIP(hipFuncSetAttribute((const void *)k_schur_points, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

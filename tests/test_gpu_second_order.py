@@ -204,6 +204,49 @@ def test_cholesky_skips_structural_zeros_correctly(ba):
                 assert rel_err(np.tril(Sd.cpu().numpy()[:n, :n]), want_L) < 1e-11, (n, switch)
 
 
+@pytest.mark.parametrize('clear', [0, 1])
+def test_cholesky_switch_order_does_not_reuse_stale_lists(ba, clear):
+    """The solver keeps the lists that steer its block moves and its clearing from call to call while the block
+    profile stays the same.  The split into chains changes them under one profile: unchained first, chained second
+    (and back) must each upload their own lists.  With and without clearing S on return."""
+    lib = ba.engine._lib.load()
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    n, bw = 9000, 50
+    ld = (n + 63) // 64 * 64
+    S = np.zeros((n, n))
+    for d in range(1, bw + 1):
+        S[np.arange(d, n), np.arange(n - d)] = rng.normal(size=n - d)
+    S[n - 1, :n - 1] = rng.normal(size=n - 1)
+    S = S + S.T
+    S[np.diag_indices(n)] = np.abs(S).sum(axis=1) + 1.0
+    b = rng.normal(size=n)
+    want_x = np.linalg.solve(S, b)
+    Sp = np.zeros((ld, ld))
+    Sp[:n, :n] = np.tril(S)
+    Sp[np.arange(n, ld), np.arange(n, ld)] = 1.0
+    nb = ld // 64
+    first = np.array([max(0, (64 * ib - bw) // 64) for ib in range(nb)], dtype=np.int32)
+    first[(n - 1) // 64:] = 0
+    first_d = torch.from_numpy(first).to(DEV)
+    for switch in ('BA_CHOL_NO_CHAINS', None, 'BA_CHOL_NO_CHAINS', None):
+        Sd = torch.from_numpy(Sp).to(DEV)
+        bd = torch.zeros(ld, dtype=torch.float64, device=DEV)
+        bd[:n] = torch.from_numpy(b)
+        info = C.c_int(7)
+        if switch:
+            os.environ[switch] = '1'
+        try:
+            ba.engine.check(lib.ba_cholesky_solve_tracked(n, ld, C.c_void_p(Sd.data_ptr()), C.c_void_p(bd.data_ptr()),
+                                                          C.c_void_p(first_d.data_ptr()), clear, C.byref(info), None))
+        finally:
+            os.environ.pop(switch or '', None)
+        assert info.value == 0
+        assert rel_err(bd.cpu().numpy()[:n], want_x) < 1e-10, switch
+        if clear:
+            assert float(Sd.abs().max()) == 0.0, switch
+
+
 def test_tracked_build_and_solve_keep_S_clean(ba):
     """The pair of entry points an LM loop uses: the Schur build reports the block profile of S (a lower bound of every
     block row's first occupied block, exact here), the solver takes it instead of reading S, gives the solution of the
@@ -361,6 +404,15 @@ def test_schur_tile_kernel_mixed_track_lengths(ba):
     assert np.abs(S_tile - S_pts).max() <= 1e-11 * np.abs(S_pts).max()
     assert np.abs(rhs_tile - rhs_pts).max() <= 1e-11 * np.abs(rhs_pts).max()
     assert np.abs(xphi_tile - xphi_pts).max() <= 1e-11 * np.abs(xphi_pts).max()
+    # the point kernel with room for 5 observations per wave: longer tracks go through in chunks (5 + 5 + 4)
+    os.environ['BA_SCHUR_POINTS'], os.environ['BA_SCHUR_POINT_ROWS'] = '1', '5'
+    try:
+        S_chk, rhs_chk, xphi_chk = build()
+    finally:
+        os.environ.pop('BA_SCHUR_POINTS', None), os.environ.pop('BA_SCHUR_POINT_ROWS', None)
+    assert np.abs(S_chk - S_pts).max() <= 1e-11 * np.abs(S_pts).max()
+    assert np.abs(rhs_chk - rhs_pts).max() <= 1e-11 * np.abs(rhs_pts).max()
+    assert np.abs(xphi_chk - xphi_pts).max() <= 1e-11 * np.abs(xphi_pts).max()
     # the reduced system against the dense normal equations (points nobody sees have no unknowns there)
     seen = deg > 0
     r, J = orc.dense_jacobian(sc['X_0'], sc['C_0'], sc['Theta_0'], sc['phi_x_0'], sc['W'], sc['H'], i, j, uv)
