@@ -21,14 +21,33 @@ import numpy as np
 
 RHO_1, RHO_2 = 0.9, 0.999      # p2w:351-352
 
-# optimiser registry, looked up by name like the reference's gd_func_dict (p2w:362, 527, 705).
-# A string value names the device update rule the shard runs.  A CALLABLE value is a user's update
-# rule with the reference's calling convention, `rule(x, grad, lr, **state) -> (x_new, new_state)`,
-# called once per free group in the order X, C, Theta, phi_x on host copies (p2w:704-708); as in the
-# reference (p2w:469-473) the state is {'s', 'r', 't'} under the name 'Adam' and empty under any other
-# name.  That is the slow path (parameters and gradients cross PCIe every iteration, nothing is queued
-# ahead); with several ranks the rule sees each rank's own block of X.
-gd_func_dict = {'SGD': 'ba_sgd_step', 'Adam': 'ba_adam_step'}
+
+
+def sgd(x, grad_x, lr):
+    """Plain gradient step on host arrays, the reference's `sgd` (p2w:336-342): (x_new, {})."""
+    return x - lr * grad_x, {}
+
+
+def gd_adam(x, grad_x, lr, s, r, t, rho_1=RHO_1, rho_2=RHO_2):
+    """Adam on host arrays with the reference's arithmetic (p2w:344-360): bias-corrected moments, the
+    1e-12 added OUTSIDE the square root, `t` a one-element integer array that counts from 1.
+    Returns (x_new, {'s', 'r', 't'})."""
+    s_new = rho_1 * s + (1.0 - rho_1) * grad_x
+    r_new = rho_2 * r + (1.0 - rho_2) * grad_x ** 2
+    step = (s_new / (1.0 - rho_1 ** t)) / (1e-12 + np.sqrt(r_new / (1.0 - rho_2 ** t)))
+    return x - lr * step, {'s': s_new, 'r': r_new, 't': t + 1}
+
+
+# Optimiser registry, looked up by name like the reference's gd_func_dict (p2w:362, 527, 705); every value is a
+# callable with the reference's convention, `rule(x, grad, lr, **state) -> (x_new, new_state)`.  While an entry IS
+# one of the two functions above, the loop runs the same rule on the device (ba_sgd_step / ba_adam_step and the
+# fused forms) and never calls it.  Any other callable - a new name, or a wrapper put in place of 'SGD' / 'Adam',
+# which may forward to the original - is called once per free group in the order X, C, Theta, phi_x on host copies
+# (p2w:704-708); as in the reference (p2w:469-473) its state is {'s', 'r', 't'} under the name 'Adam' and empty
+# under any other name.  That is the slow path (parameters and gradients cross PCIe every iteration, nothing is
+# queued ahead); with several ranks the rule sees each rank's own block of X.
+gd_func_dict = {'SGD': sgd, 'Adam': gd_adam}
+_device_rules = {sgd: 1, gd_adam: 2}        # rule numbers of the C ABI
 
 # optimisers beyond the reference's registry, accepted by fit_scene(optimizer=...)
 extra_optimizers = {'LM': 'Levenberg-Marquardt with Schur complement (lm.LMFit)'}
@@ -49,7 +68,9 @@ class SceneFit:
             raise ValueError(f'Unkown name of the optmizer, choose one from {[key for key in gd_func_dict]}')
         self.sh = shard
         rule = gd_func_dict[optimizer]
-        self.host_rule = rule if callable(rule) else None
+        if not callable(rule):
+            raise ValueError(f'gd_func_dict[{optimizer!r}] must be callable as rule(x, grad, lr, **state)')
+        self.host_rule = None if rule in _device_rules else rule
         if self.host_rule is not None:
             speculate = fuse = False
         self.lr, self.max_iters = lr, int(max_iters)
@@ -81,11 +102,11 @@ class SceneFit:
             shard.gauge_fix()                                            # p2w:533-536
 
         self.release = shard.snapshot()                                  # p2w:463-464
-        self.adam = optimizer == 'Adam' and self.host_rule is None
+        self.adam = rule is gd_adam
         self.host_state = self.host_state_tmp = None
         if self.host_rule is not None:                                   # p2w:466-473
-            self.host_state, self.host_state_tmp = self._host_state_init(optimizer), self._host_state_init(optimizer)
             self._host_state_named = optimizer
+            self.host_state, self.host_state_tmp = self._host_state_init(optimizer), self._host_state_init(optimizer)
         self.mom_x = self.mom_cam = self.mom_x_tmp = self.mom_cam_tmp = None
         if self.adam:                                                    # p2w:469-473
             self.mom_x, self.mom_cam = self._zero_moments()
@@ -151,9 +172,8 @@ class SceneFit:
         return {name: {'s': np.zeros(shape), 'r': np.zeros(shape), 't': np.array([1])}
                 for name, shape in self._host_group_shapes()}
 
-    def _host_update(self):
-        """One step of the registered callable on every free group, then the gauge fix on the device."""
-        import torch
+    def _host_fetch(self):
+        """Host copies of every group's parameters (views of `cam` where they live there) and gradients."""
         sh = self.sh
         K3, inv = 3 * sh.K, 1.0 / sh.nV
         cam = sh.cam.cpu().numpy().copy()
@@ -163,16 +183,27 @@ class SceneFit:
         if self.masks[0]:
             main['X'] = sh.points_to_caller(sh.X).cpu().numpy().copy()
             grad['X'] = sh.points_to_caller(sh.gX).cpu().numpy() * inv
-        for name, shape in self._host_group_shapes():
-            new, new_state = self.host_rule(main[name], grad[name], self.lr, **self.host_state[name])
-            main[name][:] = np.asarray(new, dtype=np.float64).reshape(shape)
-            for key, val in self.host_state[name].items():
-                val[:] = new_state[key]
+        return cam, main, grad
+
+    def _host_store(self, cam, main):
+        """The updated host copies become the current device state; then the gauge fix on the device."""
+        import torch
+        sh = self.sh
         X_new = sh.points_to_engine(main['X']) if self.masks[0] else sh.X
         sh.adopt(X_new, torch.from_numpy(cam).to(sh.cam.device))
         sh.invalidate_table()
         if self.gauge:
             sh.gauge_fix()                                               # p2w:710-712
+
+    def _host_update(self):
+        """One step of the registered callable on every free group (p2w:704-708)."""
+        cam, main, grad = self._host_fetch()
+        for name, shape in self._host_group_shapes():
+            new, new_state = self.host_rule(main[name], grad[name], self.lr, **self.host_state[name])
+            main[name][:] = np.asarray(new, dtype=np.float64).reshape(shape)
+            for key, val in self.host_state[name].items():
+                val[:] = new_state[key]
+        self._host_store(cam, main)
 
     def _evaluate(self):
         timed = self.timed_every > 0 and self._passes % self.timed_every == 0

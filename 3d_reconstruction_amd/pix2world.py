@@ -7,7 +7,8 @@ arithmetic on an MI355X through libba_mi355x.so.
     transform(...)           p2w:192-216
     error(...)               p2w:98-111
     validate_scene_parameters(...)  p2w:21-95
-    gd_func_dict             p2w:362       optimiser names accepted by `optimizer=`
+    sgd, gd_adam             p2w:336-360   the update rules on host arrays (reference arithmetic)
+    gd_func_dict             p2w:362       optimiser registry {'SGD': sgd, 'Adam': gd_adam}; the names `optimizer=` accepts
 
 Inputs are never modified; returned arrays are fresh NumPy arrays owned by the caller."""
 from __future__ import annotations
@@ -16,11 +17,11 @@ import numpy as np
 import torch
 
 from . import engine
-from .fit_loop import SceneFit, extra_optimizers, gd_func_dict  # noqa: F401  (gd_func_dict re-exported)
+from .fit_loop import SceneFit, extra_optimizers, gd_adam, gd_func_dict, sgd  # noqa: F401  (registry re-exported)
 from .lm import LMFit
 from .sharding import all_ranks_ok, checked_partition, connected_components_count
 
-__all__ = ['fit_scene', 'fit_scene_sparse', 'transform', 'error', 'validate_scene_parameters', 'gd_func_dict',
+__all__ = ['fit_scene', 'fit_scene_sparse', 'transform', 'error', 'validate_scene_parameters', 'gd_func_dict', 'sgd', 'gd_adam',
            'get_X_from_C_Theta', 'get_C_Theta_from_X', 'get_H_diff_matrix', 'ryxz', 'get_rotations', 'align_scene',
            'normalize_scene']
 

@@ -115,6 +115,24 @@ class SubsceneFit(SceneFit):
         super().__init__(subscenes, lr, max_iters, X_mask=False, C_Theta_mask=True, phi_x_mask=True, fuse=False, **kw)
         self.cam_range = (0, 7 * subscenes.P)
 
+    # a callable from the optimiser registry sees the groups S, T, Psi in that order (p2w:926-930)
+    def _host_group_shapes(self):
+        P = self.sh.P
+        return [('S', (P,)), ('T', (P, 3)), ('Psi', (P, 3))]
+
+    def _host_fetch(self):
+        sh, P = self.sh, self.sh.P
+        cam = sh.cam.cpu().numpy().copy()
+        g = sh.sums.cpu().numpy()[1:1 + 7 * P] * (2.0 / float(sh.n))        # p2w:888, 890, 923
+        cut = lambda v: {'S': v[:P], 'T': v[P:4 * P].reshape(P, 3), 'Psi': v[4 * P:].reshape(P, 3)}
+        return cam, cut(cam), cut(g)
+
+    def _host_store(self, cam, main):
+        sh = self.sh
+        sh.cam = torch.from_numpy(cam).to(sh.device)
+        # the gauge of p2w:932-937 is the tail of the step kernel: a plain step of length zero leaves only that
+        _, sh.cam, _, _ = sh.step_update(1, 0.0, 1.0, 1.0, False, self.cam_range, None, None, True)
+
 
 def fit_subscenes_GD(X, lr, max_iters, S_0=None, T_0=None, Psi_0=None, optimizer='Adam', patience=1000,
                      factor=2.0, stop_value=0.0, stop_diff=1e-12, print_step=1000, ret_all_iters=False, device=None):

@@ -76,6 +76,39 @@ def test_fit_subscenes_runs(ba, golden, tag):
     assert out[5].shape == (max_iters, g['X'].shape[1]) and out[7].shape == (max_iters, g['X'].shape[1], 3)
 
 
+@pytest.mark.parametrize('tag', ['adam', 'sgd', 'events'])
+def test_fit_subscenes_with_a_wrapped_registry_entry(ba, golden, tag):
+    """The capture hook of the golden files (oracle/capture_golden.py: a recording wrapper in gd_func_dict that
+    forwards to the original entry) run against the drop-in: it sees the groups S, T, Psi with the reference's
+    parameters and gradients (p2w:926-930), and the run is the reference's."""
+    g = golden('f8_subscenes.npz')
+    kw = f8_kwargs(g, tag)
+    max_iters = kw.pop('max_iters')
+    name = kw.get('optimizer', 'Adam')
+    orig, seen = ba.gd_func_dict[name], []
+
+    def rec(x, grad, lr_, **state):
+        seen.append((np.array(x).copy(), np.array(grad).copy()))
+        return orig(x, grad, lr_, **state)
+    ba.gd_func_dict[name] = rec
+    try:
+        with contextlib.redirect_stdout(io.StringIO()) as out_txt:
+            out = ba.fit_subscenes_GD(g['X'], kw.pop('lr'), max_iters, **kw)
+    finally:
+        ba.gd_func_dict[name] = orig
+    assert rel_err(out[4], g[f'{tag}_E']) < 1e-9
+    assert logs_match(out_txt.getvalue().splitlines(), g[f'{tag}_log'].tolist())
+    steps = g[f'{tag}_step_S'].shape[0]
+    assert len(seen) == 3 * steps
+    for t in range(0, steps, 5):
+        for k, n in enumerate(('S', 'T', 'Psi')):
+            x, grad = seen[3 * t + k]
+            assert np.abs(x - g[f'{tag}_step_{n}'][t]).max() < 1e-9
+            assert rel_err(grad, g[f'{tag}_grad_{n}'][t]) < 1e-8
+    for k, n in ((1, 'S'), (2, 'T'), (3, 'Psi')):
+        assert np.abs(out[k].reshape(g[f'{tag}_final_{n}'].shape) - g[f'{tag}_final_{n}']).max() < 1e-9
+
+
 def test_fit_subscenes_errors(ba, golden):
     g = golden('f8_subscenes.npz')
     X = g['X']

@@ -166,12 +166,16 @@ def test_loop_control_all_masks(golden, opt):
         assert logs_match(lines, g[f'{tag}__log'].tolist()), tag
 
 
-def _numpy_adam(x, grad_x, lr, s, r, t):
-    """Adam as the reference states it (p2w:344-360), written here as a user of the registry would."""
-    s_new = 0.9 * s + 0.1 * grad_x
-    r_new = 0.999 * r + 0.001 * grad_x ** 2
-    x_new = x - lr * (s_new / (1.0 - 0.9 ** t)) / (1e-12 + np.sqrt(r_new / (1.0 - 0.999 ** t)))
-    return x_new, {'s': s_new, 'r': r_new, 't': t + 1}
+def test_registry_holds_the_reference_update_rules(golden):
+    """gd_func_dict maps the names to callables (p2w:362); sgd / gd_adam compute what the reference's do (F5)."""
+    g = golden('f5_gauge_funcs.npz')
+    assert p2w.gd_func_dict == {'SGD': p2w.sgd, 'Adam': p2w.gd_adam}
+    x_new, st = p2w.gd_adam(g['adam_x'], g['adam_g'], 1e-2, g['adam_s'], g['adam_r'], np.array([3]))
+    assert np.array_equal(x_new, g['adam_x_new']) or rel_err(x_new, g['adam_x_new']) < 1e-15
+    assert rel_err(st['s'], g['adam_s_new']) < 1e-15 and rel_err(st['r'], g['adam_r_new']) < 1e-15
+    assert st['t'].tolist() == g['adam_t_new'].tolist()
+    xs, none = p2w.sgd(g['adam_x'], g['adam_g'], 1e-2)
+    assert none == {} and np.array_equal(xs, g['sgd_x_new'])
 
 
 def check_registered_callables(golden, run):
@@ -187,10 +191,11 @@ def check_registered_callables(golden, run):
         return x - lr * grad_x, {}
 
     recorded = []
+    orig = reg['Adam']          # the capture hook of the golden files: record, then forward to the original entry
 
     def recording_adam(x, grad_x, lr, **state):
         recorded.append((x.copy(), grad_x.copy()))
-        return _numpy_adam(x, grad_x, lr, **state)
+        return orig(x, grad_x, lr, **state)
 
     saved = dict(reg)
     try:
