@@ -130,8 +130,10 @@ struct UpdateRule {
 
 // One parameter: returns the new value, updates the moments in place.  The two bias corrections are
 // multiplications by reciprocals formed once on the host and the final quotient is a multiplication by
-// fast_rcp of the denominator (>= 1e-12): a few 1e-16 relative from the reference's three divisions, and
-// a third of the instructions on the path every parameter takes every iteration.
+// the Newton reciprocal of the denominator (>= 1e-12): a few 1e-16 relative from the reference's three divisions,
+// and a third of the instructions on the path every parameter takes every iteration.  The denominator is the root
+// of a squared gradient and leaves the range of a float when one observation has a depth near zero (gradients of
+// 1e39 and more, from which the reference recovers in one step of length lr): double-precision estimate.
 __device__ __forceinline__ double apply_rule(const UpdateRule &u, double x, double g, double *s, double *r) {
     const double rho1 = 0.9, rho2 = 0.999;
     const double gr = g * u.gscale;
@@ -144,7 +146,7 @@ __device__ __forceinline__ double apply_rule(const UpdateRule &u, double x, doub
         // 9 instructions instead of the library sequence's 20 odd (the update is a sixth of the fused pass's arithmetic)
         const double y = rn * u.ibc2;
         const double root = y > 0.0 ? y * fast_rsqrt(y) : 0.0;
-        return x - u.lr * (sn * u.ibc1) * fast_rcp(1e-12 + root);
+        return x - u.lr * (sn * u.ibc1) * fast_rcp_wide(1e-12 + root);
     }
     return x - u.lr * gr;
 }

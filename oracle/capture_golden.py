@@ -543,6 +543,76 @@ def capture_f11(out):
     save_npz(os.path.join(out, 'f11_jacobians.npz'), **arrays)
 
 
+def capture_f12(out):
+    """Inputs the reference accepts without complaint and every other fixture avoids (p2w:571-573, 654-655 divide
+    by the depth whatever its sign or size; visibility is X_pix[:,:,0] >= 0 alone, p2w:506):
+      edge   observations of points BEHIND their cameras, pixels at the int16 limits, a negative y
+      wide   the same with pixels beyond the int16 range
+      tiny   one point at depth 2^-40 in cameras 0 and 1 (camera 0 at the origin with zero angles and the longest
+             baseline exactly 1 make the initial gauge fix exact, so both observations have exactly that depth)
+      zero   the same point at depth exactly 0: the reference's energy and gradients are inf / NaN
+      blind  cameras and phi_x free, points fixed, one camera that sees nothing (no gauge, no connectivity test)
+    Adam, teacher-forcing data of the first iterations of each."""
+    import warnings
+    rng = np.random.default_rng(77)
+    N, K, W, H, phi = 28, 6, 1920, 1080, 1.2
+    C = np.zeros((K, 3))
+    C[1] = (1.0, 0.0, 0.0)
+    C[2:] = rng.uniform(-0.4, 0.4, (K - 2, 3))
+    C[2:, 2] -= 0.3
+    assert np.linalg.norm(C[2:], axis=1).max() < 0.95
+    Theta = np.zeros((K, 3))
+    Theta[2:] = rng.normal(0, 0.05, (K - 2, 3))
+    X = rng.uniform(-2, 2, (N, 3))
+    X[:, 2] = rng.uniform(3, 6, N)
+    X[1:4, 2] = -rng.uniform(3, 5, 3)                       # behind every camera
+    X[0] = (0.5, 0.25, 1.0)                                 # depth set per case below
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model = p.transform(X, C, Theta, phi, W, H, delete_back_points=False)
+    base = np.floor(model).astype(np.int32)
+    vis = rng.random((N, K)) < 0.75
+    vis[:, 0] |= ~vis.any(axis=1)
+    vis[1:4, 2:5] = True                                    # the points behind the cameras are observed
+    vis[0, :] = [False, False, True, True, False, True]
+    base[~vis] = -1
+    base[vis & (base[:, :, 0] < 0), 0] = 3                  # keep every chosen pair visible (x >= 0)
+    edge = base.copy()
+    edge[5, 2], edge[6, 3], edge[7, 4], edge[8, 2] = (32767, -32768), (0, 32767), (32767, 0), (11, -7)
+    for ij in ((5, 2), (6, 3), (7, 4), (8, 2)):
+        vis[ij] = True
+    wide = edge.copy()
+    wide[5, 2], wide[6, 3], wide[7, 4] = (40000, -40000), (70000, 12), (32768, -32769)
+    tiny = edge.copy()
+    tiny[0, 0], tiny[0, 1] = (700, 300), (1200, 310)
+    blind = edge.copy()
+    blind[:, 5] = -1
+    rng2 = np.random.default_rng(78)
+    X0 = X + rng2.normal(0, 0.05, X.shape)
+    C0 = C.copy()
+    C0[2:] += rng2.normal(0, 0.02, (K - 2, 3))
+    Th0 = Theta.copy()
+    Th0[2:] += rng2.normal(0, 0.01, (K - 2, 3))
+    X0_tiny, X0_zero = X0.copy(), X0.copy()
+    X0_tiny[0] = (0.5, 0.25, 2.0 ** -40)
+    X0_zero[0] = (0.5, 0.25, 0.0)
+    cases = dict(edge=(edge, X0, (True, True, True), 4), wide=(wide, X0, (True, True, True), 4),
+                 tiny=(tiny, X0_tiny, (True, True, True), 4), zero=(tiny, X0_zero, (True, True, True), 2),
+                 blind=(blind, X0, (False, True, True), 4))
+    arrays = dict(N=N, K=K, W=W, H=H, C_0=C0, Theta_0=Th0, phi_x_0=phi * 1.02, cases=np.array(list(cases)))
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for tag, (X_pix, X_init, masks, iters) in cases.items():
+            sc = dict(X_pix=X_pix, W=W, H=H, X_0=X_init, C_0=C0, Theta_0=Th0, phi_x_0=phi * 1.02)
+            r = run_reference(sc, lr=1e-3, max_iters=iters, masks=masks)
+            arrays[f'{tag}__X_pix'], arrays[f'{tag}__X_0'], arrays[f'{tag}__masks'] = X_pix, X_init, np.array(masks)
+            for k, v in r.items():
+                arrays[f'{tag}__{k}'] = np.array(v) if k == 'log' else v
+            print(tag, 'E', r['E'], 'steps', r['grad_C'].shape[0],
+                  'non-finite gradient rows (C)', (~np.isfinite(r['grad_C'][0])).any(axis=1).sum())
+    save_npz(os.path.join(out, 'f12_edge_cases.npz'), **arrays)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden'))
@@ -551,7 +621,7 @@ def main():
     os.makedirs(a.out, exist_ok=True)
     todo = dict(f1=capture_f1, f2=capture_f2, f3=capture_f3, f4=capture_f4, f5=capture_f5,
                 f6=capture_f6, f7=capture_f7, f8=capture_f8, f9=capture_f9, f10=capture_f10,
-                f11=capture_f11)
+                f11=capture_f11, f12=capture_f12)
     for name, fn in todo.items():
         if a.only and name not in a.only.split(','):
             continue

@@ -123,3 +123,29 @@ def normal_equations_from_jacobians(case, lam=None):
         out['step'] = np.linalg.solve(Hd[np.ix_(np.r_[seen, np.ones(6 * K + 1, bool)], np.r_[seen, np.ones(6 * K + 1, bool)])],
                                       -g[np.r_[seen, np.ones(6 * K + 1, bool)]])
     return out
+
+
+def f12_check(g, tag, s, E, gX, gC, gT, gp, tol=1e-9):
+    """One teacher-forced evaluation against golden F12 (inputs every other fixture avoids: observations behind
+    the camera, pixels at and beyond the int16 limits, a depth of 2^-40, a depth of exactly 0, a camera that sees
+    nothing).  Where the reference is finite: energy within `tol`, every gradient row within `tol` of its own
+    magnitude.  Where it is not (depth 0): the same rows are non-finite, the others agree as before."""
+    want_E = g[f'{tag}__E'][s]
+    if np.isfinite(want_E):
+        assert abs(E - want_E) <= tol * abs(want_E), (tag, s, E, want_E)
+    else:
+        assert not np.isfinite(E), (tag, s, E)
+    for name, got in (('X', gX), ('C', gC), ('Theta', gT), ('phi_x', gp)):
+        key = f'{tag}__grad_{name}'
+        if key not in g.files:
+            continue
+        want = np.asarray(g[key][s], dtype=np.float64).reshape(-1, 3 if name != 'phi_x' else 1)
+        got = np.asarray(got, dtype=np.float64).reshape(want.shape)
+        bad = ~np.isfinite(want).all(axis=1)
+        assert np.array_equal(~np.isfinite(got).all(axis=1), bad), (tag, s, name)
+        if (~bad).any():
+            w, a = want[~bad], got[~bad]
+            scale = np.maximum(np.abs(w).max(axis=1), 1e-300)
+            zero = np.abs(w).max(axis=1) == 0.0
+            assert (np.abs(a - w).max(axis=1)[~zero] / scale[~zero]).max(initial=0.0) < tol, (tag, s, name)
+            assert np.abs(a[zero]).max(initial=0.0) == 0.0, (tag, s, name)

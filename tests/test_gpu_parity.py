@@ -11,7 +11,7 @@ import contextlib
 import numpy as np
 import pytest
 
-from conftest import logs_match, rel_err, row_err
+from conftest import f12_check, logs_match, rel_err, row_err
 from oracle import ba_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -84,6 +84,41 @@ def test_eval_teacher_forced_moscow(ba, golden, variant):
                     row_err(gT, g['tf__grad_Theta'][s]))
     sh.close()
     assert worst < TOL, worst
+
+
+@pytest.mark.parametrize('variant', [dict(), dict(point_major=True), dict(untiled=True), dict(cam_atomics=True)],
+                         ids=['camera-runs', 'point-major-tiles', 'wave-chunks', 'global-atomics'])
+def test_eval_teacher_forced_edge_cases(ba, golden, variant):
+    """Golden F12 through every kernel form: observations behind the camera, pixels at the int16 limits (8-byte
+    records) and beyond them (f64 records), a depth of 2^-40, a depth of exactly 0 (same non-finite rows as the
+    reference), a camera without observations; at the reference's own iterates."""
+    g = golden('f12_edge_cases.npz')
+    N, K, W, H = int(g['N']), int(g['K']), int(g['W']), int(g['H'])
+    for tag in g['cases'].tolist():
+        oi, oj, uv, _ = ba.engine.visibility_coo(g[f'{tag}__X_pix'], DEV)
+        nv = int(oi.numel())
+        sh = ba.engine.Shard(oi, oj, uv, N, K, W, H, DEV)
+        m = [bool(t) for t in g[f'{tag}__masks']]
+        for s in range(g[f'{tag}__grad_C'].shape[0]):
+            X = g[f'{tag}__step_X'][s] if m[0] else g[f'{tag}__X_0']
+            sh.set_params(X, g[f'{tag}__step_C'][s], g[f'{tag}__step_Theta'][s], g[f'{tag}__step_phi_x'][s][0])
+            E, gX, gC, gT, gp = _eval_all(ba, sh, nv, grad_x=m[0], grad_cam=m[1], grad_phi=m[2], **variant)
+            f12_check(g, tag, s, E, gX, gC, gT, gp)
+        sh.close()
+
+
+def test_fit_scene_edge_cases_free_run(ba, golden):
+    """The drop-in on the same inputs, free-running for the recorded iterations: energies and returned parameters."""
+    g = golden('f12_edge_cases.npz')
+    for tag in ('edge', 'wide', 'tiny', 'blind'):
+        m = [bool(t) for t in g[f'{tag}__masks']]
+        with contextlib.redirect_stdout(io.StringIO()):
+            out = ba.fit_scene(g[f'{tag}__X_pix'], int(g['W']), int(g['H']), 1e-3, g[f'{tag}__E'].size, g[f'{tag}__X_0'],
+                               g['C_0'], g['Theta_0'], float(g['phi_x_0']), X_mask=m[0], C_Theta_mask=m[1], phi_x_mask=m[2])
+        names = (['X'] if m[0] else []) + (['C', 'Theta'] if m[1] else []) + (['phi_x'] if m[2] else [])
+        assert rel_err(out[len(names)], g[f'{tag}__E']) < 1e-8, tag
+        for n, v in zip(names, out):
+            assert np.abs(np.asarray(v) - g[f'{tag}__final_{n}']).max() < 1e-8, (tag, n)
 
 
 def test_eval_teacher_forced_f3_and_f6(ba, golden):

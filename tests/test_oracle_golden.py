@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, f11_case, logs_match, normal_equations_from_jacobians, rel_err
+from conftest import GOLDEN, f11_case, f12_check, logs_match, normal_equations_from_jacobians, rel_err
 from oracle import ba_oracle as orc
 
 TOL = 1e-9       # per-iteration energy / gradient contract (relative, max-norm)
@@ -381,3 +381,27 @@ def test_f11_jacobians_of_the_reference(golden, which, t):
     gcam = g[3 * N:3 * N + 6 * K].reshape(K, 6)
     assert rel_err(gcam[:, :3], c['grad_C']) < 1e-12 and rel_err(gcam[:, 3:], c['grad_Theta']) < 1e-12
     assert abs(g[-1] - c['grad_phi_x'][0]) < 1e-12 * abs(c['grad_phi_x'][0])
+
+
+def test_f12_edge_cases_teacher_forced(golden):
+    """The restatement at the reference's iterates on the inputs of golden F12 (see conftest.f12_check)."""
+    import warnings
+    g = golden('f12_edge_cases.npz')
+    W, H = float(g['W']), float(g['H'])
+    for tag in g['cases'].tolist():
+        i, j, uv = orc.visibility_coo(g[f'{tag}__X_pix'])
+        masks = g[f'{tag}__masks']
+        steps = g[f'{tag}__grad_C'].shape[0]
+        assert steps == (1 if tag == 'zero' else 3)
+        for s_ in range(steps):
+            X = g[f'{tag}__step_X'][s_] if masks[0] else g[f'{tag}__X_0']
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                E, gX, gC, gT, gp = orc.energy_and_gradients(X, g[f'{tag}__step_C'][s_], g[f'{tag}__step_Theta'][s_],
+                                                             g[f'{tag}__step_phi_x'][s_], W, H, i, j, uv)
+            f12_check(g, tag, s_, E, gX, gC, gT, gp)
+    # what the cases are about really is in them
+    g_t = golden('f12_edge_cases.npz')
+    assert g_t['tiny__step_X'][0][0][2] == 2.0 ** -40 and g_t['tiny__E'][0] > 1e27
+    assert np.isinf(g_t['zero__E'][0]) and (g_t['blind__X_pix'][:, 5, 0] < 0).all()
+    assert g_t['wide__X_pix'].max() == 70000 and g_t['edge__X_pix'][:, :, 1].min() == -32768
