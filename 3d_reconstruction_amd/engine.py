@@ -624,6 +624,14 @@ class Shard:
         if self.distributed:
             first = 1 if torch.distributed.get_rank(self.group) == 0 else 0
         S_is_zero, self._S_is_zero = self._S_is_zero, False
+        marks = getattr(self, 'lm_marks', None)     # a list: device time stamps around the three phases (benchmarks)
+
+        def mark():
+            if marks is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(torch.cuda.current_stream(self.device))
+                marks.append(ev)
+        mark()
         check(self.lib.ba_schur_build_tracked(self.handle, X.data_ptr(), float(lam), ptr(self.V), ptr(self.Xphi),
                                               ptr(self.gX), ptr(self.B), ptr(self.bphi), ptr(self.hphi), ptr(self.gC),
                                               ptr(self.gTheta), ptr(self.gphi), first, ptr(self.S), ptr(self.rhs),
@@ -632,11 +640,13 @@ class Shard:
             self._sum_over_ranks(self.S)
             self._sum_over_ranks(self.rhs)
             self._min_over_ranks(self.S_first)
+        mark()
         if on_system is not None:
             on_system(self.S, self.rhs)
         status = self.lib.ba_cholesky_solve_tracked(self.n_red, self.ld_red, ptr(self.S), ptr(self.rhs), ptr(self.S_first),
                                                     1, C.byref(info), self.stream)
         self._S_is_zero = status in (0, -4)     # the solver ran to its end and cleared S
+        mark()
         if self.distributed:
             # Every rank factorised the same system, but sums inside the factorisation are not ordered (the update
             # kernel adds parts of a tile with atomics): the ranks' solutions can differ in the last bits, and at a
@@ -656,6 +666,7 @@ class Shard:
         check(self.lib.ba_backsubstitute(self.handle, X.data_ptr(), float(lam), ptr(self.V), ptr(self.Xphi),
                                          ptr(self.gX), ptr(self.rhs), ptr(self.dcam), ptr(self.dX), cam.data_ptr(),
                                          ptr(self.X_trial), ptr(self.cam_trial), self.stream))
+        mark()
         return 0
 
 

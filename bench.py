@@ -111,6 +111,7 @@ def roofline_block(kernel, algo_bytes, kern_ms, traffic, extra=None):
            'traffic_source': (f'{TRAFFIC_FILE}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, '
                               'committed; a constant of that profile, not collected by this run') if traffic else None,
            'achieved_traffic': (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None,
+           'frac_physical': (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
            'algorithmic_bytes_per_launch': algo_bytes, 'avg_kernel_ms': avg_ms, 'launches_timed': len(kern_ms)}
     if extra:
         out.update(extra)
@@ -138,7 +139,80 @@ def time_jtj_pass(ba, sc, dev, nv_total, launches=24):
         sh.close()
 
 
+F64_MATRIX_PEAK_TFLOPS = 78.6      # MI355X fp64 matrix rate (= its fp64 vector rate)
+
+
+def lm_iteration_times(ba, dev, K, N, track_len, iterations=7):
+    """Steady-state wall time of whole Levenberg-Marquardt iterations (lm.LMFit: Schur build, Cholesky solve,
+    back-substitution, gauge fix, the trial point's J^T J pass, energy read-back) on a scene of N points and K
+    cameras, and the device time of the three phases of the damped solve from events around them."""
+    import torch
+    sc = ba.scenes.orbit_scene(N=N, K=K, track_len=track_len, seed=0)
+    sh = ba.engine.Shard(sc['i'], sc['j'], sc['uv'], sc['N_local'], K, sc['W'], sc['H'], dev)
+    try:
+        sh.set_params(sc['X_0'], sc['C_0'], sc['Theta_0'], sc['phi_x_0'])
+        sh.lm_marks = []
+        fit = ba.lm.LMFit(sh, iterations + 1, lam=1e-3, print_step=10 ** 9, printer=lambda *a: None)
+        fit.run()
+        torch.cuda.synchronize()
+        st = np.diff(np.array(fit.stamps)) * 1e3      # [first evaluation, iteration 1 (sets up S), iteration 2, ...]
+        later = st[2:] if len(st) > 2 else st[1:]
+        ev = sh.lm_marks
+        phases = np.array([[ev[k].elapsed_time(ev[k + 1]) for k in range(q, q + 3)] for q in range(0, len(ev) - 3, 4)])
+        ph = phases[1:] if len(phases) > 1 else phases
+        E = fit.energies()
+        return {'cameras': K, 'points': sc['N_local'], 'observations': int(sc['i'].size), 'reduced_system_unknowns': sh.n_red,
+                'iteration_ms': float(later.mean()), 'iteration_ms_min': float(later.min()), 'iterations_timed': int(later.size),
+                'first_iteration_ms': float(st[1]), 'schur_build_ms': float(ph[:, 0].mean()),
+                'cholesky_solve_ms': float(ph[:, 1].mean()), 'back_substitution_ms': float(ph[:, 2].mean()),
+                'accepted': fit.accepted, 'rejected': fit.rejected, 'energy_first': float(E[0]), 'energy_last': float(E[-1])}
+    finally:
+        sh.close()
+
+
+def dense_cholesky_rate(ba, dev, n=30001, repeats=2):
+    """ba_cholesky_solve on a dense SPD matrix of n unknowns with every tile computed (BA_CHOL_DENSE=1: the default
+    path leaves out the structural zeros of a video's reduced camera system, which a dense matrix does not have):
+    n^3 / 3 flops over the wall time of the whole call (factorisation + both triangular solves)."""
+    import ctypes as C
+    import torch
+    lib = ba.engine._lib.load()
+    ld = (n + 63) // 64 * 64
+    g = torch.Generator(device=dev).manual_seed(1)
+    A = torch.randn(ld, 192, dtype=torch.float64, device=dev, generator=g)
+    S0 = A @ A.T
+    S0.diagonal().add_(float(n))
+    del A
+    b0 = torch.randn(ld, dtype=torch.float64, device=dev, generator=g)
+    b0[n:] = 0.0
+    times, resid = [], None
+    os.environ['BA_CHOL_DENSE'] = '1'
+    try:
+        for rep in range(repeats + 1):
+            S, b = S0.clone(), b0.clone()
+            info = C.c_int(0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ba.engine.check(lib.ba_cholesky_solve(n, ld, C.c_void_p(S.data_ptr()), C.c_void_p(b.data_ptr()), C.byref(info),
+                                                  ba.engine._lib.stream_ptr()))
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+            if rep == 0:
+                r = S0[:n, :n] @ b[:n] - b0[:n]
+                resid = float(r.abs().max() / b0[:n].abs().max())
+            del S, b
+    finally:
+        os.environ.pop('BA_CHOL_DENSE', None)
+    dt = float(np.mean(times[1:]))
+    tflops = n ** 3 / 3.0 / dt / 1e12
+    return {'bound': 'mfma_f64', 'kernel': 'ba_cholesky_solve, every tile computed (ba::k_syrk_trailing on v_mfma_f64_4x4x4_4b_f64, '
+            'ba::k_panel_rows, ba::k_potrf64)', 'unknowns': n, 'flops': n ** 3 / 3.0, 'ms': dt * 1e3, 'achieved': tflops,
+            'peak': F64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tflops / F64_MATRIX_PEAK_TFLOPS,
+            'residual_max_rel': resid, 'calls_timed': repeats}
+
+
 PREHEAT_ITERATIONS = 700
+EVENT_TIMED_LAUNCHES = 12
 
 
 def preheat(ba, sh, sc, iterations=PREHEAT_ITERATIONS):
@@ -160,24 +234,29 @@ def run_loop(ba, sh, sc, steps, warmup, sync, timed=True):
     preheat(ba, sh, sc)
     sh.set_params(sc['X_0'], sc['C_0'], sc['Theta_0'], sc['phi_x_0'])
     total = steps + warmup
-    fit = ba.SceneFit(sh, lr=1e-3, max_iters=total + 8, patience=1000, print_step=10 ** 9, printer=lambda *a: None)
-    # HIP events on about ten launches of the observation-pass kernel spread over the timed region (handed to the
-    # dispatch itself, so they hold the kernel's own begin and end; such a launch costs the host about 30 us more than
-    # a plain one - the launch is issued by the wait for the previous energy, with a few microseconds of camera step
-    # left to hide it - which is why not every launch carries them): one sample in runs under 40 iterations (2.5 %
-    # of a 20-iteration run), two up to 90, then one in every tenth of the run
-    fit.timed_every = max(1, steps // 10 if steps >= 90 else (-(-steps // 2) if steps >= 40 else steps)) if timed else 0
+    fit = ba.SceneFit(sh, lr=1e-3, max_iters=total + 8 + EVENT_TIMED_LAUNCHES, patience=1000, print_step=10 ** 9,
+                      printer=lambda *a: None)
     for _ in range(warmup):
         if not fit.step():
             raise RuntimeError('the fit stopped during the warm-up')
-    sh.eval_kernel_ms()          # drop warm-up timings
     sync()
     t0 = time.perf_counter()
     for _ in range(steps):
         if not fit.step():
             raise RuntimeError('the fit stopped inside the timed region: the iterations counted would not all be full ones')
     sync()
-    return fit, time.perf_counter() - t0
+    dt = time.perf_counter() - t0
+    # The kernel's own duration for the roofline: HIP events handed to the dispatch of the observation-pass kernel
+    # (they hold its begin and end) on the launches of the iterations that FOLLOW the timed region - the same loop in
+    # the same state.  Such a launch costs the host about 30 us more than a plain one, so none is inside the region.
+    if timed:
+        sh.eval_kernel_ms()          # drop anything recorded so far
+        fit.timed_every = 1
+        for _ in range(EVENT_TIMED_LAUNCHES):
+            if not fit.step():
+                raise RuntimeError('the fit stopped during the event-timed iterations')
+        sync()
+    return fit, dt
 
 
 # ------------------------------------------------------------------------------------------------- #
@@ -255,6 +334,7 @@ def main():
     ap.add_argument('--track-len', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-jtj', action='store_true', help='skip the stand-alone timing of the J^T J pass')
+    ap.add_argument('--no-lm', action='store_true', help='N = 1: skip the second-order measurements (roofline_lm)')
     ap.add_argument('--no-one-gpu-reference', action='store_true',
                     help='N > 1: skip the timing of the whole scene on one GPU')
     ap.add_argument('--no-exchange-trial', action='store_true',
@@ -424,6 +504,18 @@ def main():
                 path: {'ms_per_step': out['ms_per_step']},
                 'node exchange kernel (opt-in, BA_NODE_EXCHANGE=1)': rep if isinstance(rep, dict) else {'error': rep}}
         dist.barrier()
+
+    # ---- N = 1: the second-order path - whole LM iterations at 2 k and at 20 k cameras, and the dense fp64 solve
+    if world == 1 and not args.no_lm:
+        note('Levenberg-Marquardt iterations at K = 2000 and K = 20000, dense Cholesky at n = 30001')
+        torch.cuda.empty_cache()
+        out['roofline_lm'] = {
+            'cfg3': lm_iteration_times(ba, dev, args.cameras, args.points_per_gpu, args.track_len),
+            'cfg5': lm_iteration_times(ba, dev, 20000, args.points_per_gpu, args.track_len),
+            'dense_solve': dense_cholesky_rate(ba, dev),
+            'note': 'iteration_ms: host clock between consecutive energy read-backs of lm.LMFit in the steady state; the '
+                    'phase times are device time between events around Shard.lm_step\'s three calls'}
+        torch.cuda.empty_cache()
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
