@@ -25,6 +25,20 @@ def _take_rows(t, idx):
     return torch.stack([t[:, c][idx] for c in range(t.shape[1])], dim=1)
 
 
+def visibility_components(oi, oj, N, K, device, want_labels=False):
+    """Connected components of the bipartite visibility graph of a COO list (ba_visibility_components):
+    (components with a camera, components of points alone[, camera labels (K,) int32 device tensor])."""
+    lib = _lib.load()
+    dev = torch.device(device)
+    oi, oj = _dev_tensor(oi, torch.int32, dev), _dev_tensor(oj, torch.int32, dev)
+    labels = torch.empty(int(K), dtype=torch.int32, device=dev) if want_labels else None
+    n_cam, n_pts = C.c_int64(0), C.c_int64(0)
+    with torch.cuda.device(dev):
+        check(lib.ba_visibility_components(int(N), int(K), int(oi.numel()), ptr(oi), ptr(oj), ptr(labels), C.byref(n_cam),
+                                           C.byref(n_pts), stream_ptr()))
+    return (int(n_cam.value), int(n_pts.value), labels) if want_labels else (int(n_cam.value), int(n_pts.value))
+
+
 def _dev_tensor(a, dtype, device):
     if isinstance(a, torch.Tensor):
         return a.to(device=device, dtype=dtype).contiguous()
@@ -286,19 +300,20 @@ class Shard:
         seen by the same few cameras and the observation list cuts into tiles with short camera
         lists (a keypoint track of a video lives in consecutive frames).  The parameters X and
         everything indexed by point are kept in this order on the device; `points_to_caller`
-        restores the caller's order.  Nothing is permuted when the input already has the property."""
-        i64 = oi.to(torch.int64)
-        first = torch.full((self.N,), self.K, dtype=torch.int64, device=self.device)
-        first.scatter_reduce_(0, i64, oj.to(torch.int64), reduce='amin', include_self=True)
-        if bool((first[1:] >= first[:-1]).all()):
+        restores the caller's order.  Nothing is permuted when the input already has the property.
+        (ba_order_points_by_first_camera: key build, stable radix sort and the rewrite of the list on the device.)"""
+        nV = int(oi.numel())
+        perm = torch.empty(self.N, dtype=torch.int32, device=self.device)
+        new_i, new_j, new_uv = torch.empty_like(oi), torch.empty_like(oj), torch.empty_like(uv)
+        identity = C.c_int(0)
+        with torch.cuda.device(self.device):
+            check(self.lib.ba_order_points_by_first_camera(self.N, self.K, nV, ptr(oi), ptr(oj), ptr(uv), ptr(perm),
+                                                           ptr(new_i), ptr(new_j), ptr(new_uv), C.byref(identity),
+                                                           stream_ptr()))
+        if identity.value:
             return oi, oj, uv
-        perm = torch.argsort(first, stable=True)
-        inv = torch.empty_like(perm)
-        inv[perm] = torch.arange(self.N, device=self.device)
-        new_i = inv[i64]
-        order = torch.argsort(new_i, stable=True)
-        self.perm = perm
-        return new_i[order].to(torch.int32), oj[order].contiguous(), _take_rows(uv, order)
+        self.perm = perm.to(torch.int64)
+        return new_i, new_j, new_uv
 
     def points_to_engine(self, a):
         """(N, ...) array in the caller's point order -> device tensor in engine order."""

@@ -19,7 +19,7 @@ import torch
 from . import engine
 from .fit_loop import SceneFit, extra_optimizers, gd_adam, gd_func_dict, sgd  # noqa: F401  (registry re-exported)
 from .lm import LMFit
-from .sharding import all_ranks_ok, checked_partition, connected_components_count
+from .sharding import all_ranks_ok, checked_partition
 
 __all__ = ['fit_scene', 'fit_scene_sparse', 'transform', 'error', 'validate_scene_parameters', 'gd_func_dict', 'sgd', 'gd_adam',
            'get_X_from_C_Theta', 'get_C_Theta_from_X', 'get_H_diff_matrix', 'ryxz', 'get_rotations', 'align_scene',
@@ -109,9 +109,37 @@ def check_solvable(n_visible, N, K, X_mask, C_Theta_mask, phi_x_mask):
                          'degrees of freedom')
 
 
-def check_connected(i, j, N, K):
+def visibility_graph_components(i, j, N, K, device, group=None):
+    """Number of connected components of the bipartite point / camera visibility graph (what the reference asks
+    scipy for on a dense (N + K)^2 matrix, p2w:519-523), counted on the device from the COO list.  With several
+    ranks every rank passes ITS points (local numbers 0 .. N - 1) and observations; the ranks' graphs meet in the
+    cameras, so each rank labels its own graph, the camera labels (K integers per rank) are gathered and merged on
+    the host, and the components of points alone are added up."""
+    n_cam, n_pts, labels = engine.visibility_components(i, j, N, K, device, want_labels=True)
+    dist = torch.distributed
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return n_cam + n_pts
+    world = dist.get_world_size(group)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (labels.cpu().numpy(), n_pts), group=group)
+    parent = np.arange(K)
+
+    def find(a):
+        while parent[a] != a:
+            parent[a] = parent[parent[a]]
+            a = parent[a]
+        return a
+    for lab, _ in gathered:
+        for cam in np.nonzero(lab != np.arange(K))[0]:
+            a, b = find(int(cam)), find(int(lab[cam]))
+            if a != b:
+                parent[max(a, b)] = min(a, b)
+    return int(sum(1 for cam in range(K) if find(cam) == cam)) + int(sum(n for _, n in gathered))
+
+
+def check_connected(i, j, N, K, device=None, group=None):
     """The bipartite visibility graph must be one component (p2w:519-525)."""
-    n = connected_components_count(i, j, N, K)
+    n = visibility_graph_components(i, j, N, K, device if device is not None else _default_device(), group)
     if n > 1:
         raise ValueError('Unable to solve the problem, expected the number of connected components of '
                          f'visibility graph to be 1, got {n}')
@@ -187,7 +215,11 @@ def fit_scene_sparse(i, j, uv, N, K, W, H, lr, max_iters, X_0, C_0, Theta_0, phi
     nV = int(i_t.numel())
     check_solvable(nV, N, K, X_mask, C_Theta_mask, phi_x_mask)
     if X_mask and C_Theta_mask and check_connectivity:
-        check_connected(i_t.cpu().numpy(), j_t.cpu().numpy(), N, K)
+        # every rank holds the whole list here and labels the whole graph itself (no exchange needed)
+        n_cam, n_pts = engine.visibility_components(i_t, j_t, N, K, dev)
+        if n_cam + n_pts > 1:
+            raise ValueError('Unable to solve the problem, expected the number of connected components of '
+                             f'visibility graph to be 1, got {n_cam + n_pts}')
     if optimizer not in gd_func_dict and optimizer not in extra_optimizers:
         raise ValueError(f'Unkown name of the optmizer, choose one from {[key for key in gd_func_dict]}')
     if optimizer == 'LM' and not (X_mask and C_Theta_mask and phi_x_mask):

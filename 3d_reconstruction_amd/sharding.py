@@ -69,18 +69,6 @@ def all_ranks_ok(flag, device=None, group=None):
     return bool(t.item() > 0.5)
 
 
-def connected_components_count(i, j, N, K):
-    """Number of connected components of the bipartite point/camera visibility graph with
-    N + K nodes (the reference builds the dense adjacency, p2w:519-523; the sparse form gives
-    the same count in O(|V|))."""
-    from scipy.sparse import coo_matrix
-    from scipy.sparse.csgraph import connected_components
-    i = np.asarray(i, dtype=np.int64)
-    j = np.asarray(j, dtype=np.int64) + N
-    g = coo_matrix((np.ones(i.size, dtype=np.int8), (i, j)), shape=(N + K, N + K))
-    return int(connected_components(g, directed=False, return_labels=False))
-
-
 def allreduce_sum_(t, group=None):
     """In-place sum over ranks (RCCL on GPUs; a no-op without an initialised process group)."""
     if torch.distributed.is_available() and torch.distributed.is_initialized() \

@@ -68,6 +68,26 @@ int ba_visibility_count(const int32_t *X_pix, int64_t N, int64_t K, int64_t *row
 int ba_visibility_fill(const int32_t *X_pix, int64_t N, int64_t K, const int64_t *row_ptr,
                        int32_t *i, int32_t *j, double *uv, void *stream);
 
+/* ---- the bipartite point / camera visibility graph of a COO list (p2w:519-525: the reference builds the dense
+ * (N + K)^2 adjacency and asks scipy for its number of connected components; fit_scene needs it to be 1).
+ * Label propagation on the device copy of the list: *h_camera_components = components that contain a camera (a
+ * camera that sees nothing is one), *h_point_components = components of points alone (points nobody
+ * sees); their sum is the reference's count.  camera_label (optional, K entries) receives for every camera the
+ * smallest camera index of its component: what ranks that hold different point ranges exchange to merge their
+ * verdicts. */
+int ba_visibility_components(int64_t N, int64_t K, int64_t nV, const int32_t *i, const int32_t *j,
+                             int32_t *camera_label, int64_t *h_camera_components, int64_t *h_point_components,
+                             void *stream);
+
+/* ---- the engine's internal point order: ascending first observing camera, ties in the caller's order (no
+ * counterpart in the reference, whose arrays are dense).  Observations sorted by point.  *h_identity = 1: the list
+ * already has the property, nothing is written.  Otherwise perm[N] (row of the new order -> caller's point index)
+ * and the list rewritten in the new order (i_out holds new point numbers, sorted; every point's observations keep
+ * their order). */
+int ba_order_points_by_first_camera(int64_t N, int64_t K, int64_t nV, const int32_t *i, const int32_t *j,
+                                    const double *uv, int32_t *perm, int32_t *i_out, int32_t *j_out, double *uv_out,
+                                    int *h_identity, void *stream);
+
 /* ---- problem handle: the observation list of one GPU's shard (its points, all cameras).
  * Observations must be sorted by point (i non-decreasing); the arrays are copied.
  * Replaces the dense (N,K) temporaries fit_scene allocates at p2w:538-542, 555-573. */

@@ -57,6 +57,64 @@ def test_visibility_only_x_decides(ba):
     assert uv.cpu().numpy().tolist() == [[5.5, -0.5], [0.5, 0.5]]
 
 
+# ---- H1: the visibility graph's components, counted on the device (p2w:519-525) ------------------------
+def test_visibility_components_match_union_find(ba):
+    """Random bipartite graphs (isolated points and cameras, many small components), a long chain (one camera pair
+    per point: the worst case for label propagation) and a video orbit: the device count equals the union-find
+    count of the restatement, which is the count scipy gives the reference on the dense adjacency."""
+    rng = np.random.default_rng(0)
+    cases = []
+    for N, K, n in ((30, 8, 40), (50, 20, 45), (10, 3, 30), (2000, 700, 1500), (1, 1, 1), (5, 4, 0)):
+        cases.append((np.sort(rng.integers(0, N, n)).astype(np.int32), rng.integers(0, K, n).astype(np.int32), N, K))
+    K = 3000                                            # chain: point p sees cameras p and p + 1
+    i = np.repeat(np.arange(K - 1), 2).astype(np.int32)
+    j = (i + np.tile([0, 1], K - 1)).astype(np.int32)
+    cases.append((i, j, K - 1, K))
+    cases.append((i[:-2], j[:-2], K - 1, K))            # ... with the last point unobserved and the last camera blind
+    sc = ba.scenes.orbit_scene(N=20000, K=300, track_len=10, seed=1)
+    cases.append((sc['i'], sc['j'], sc['N_local'], 300))
+    for i, j, N, K in cases:
+        n_cam, n_pts, labels = ba.engine.visibility_components(i, j, N, K, DEV, want_labels=True)
+        assert n_cam + n_pts == orc.count_components(i, j, N, K), (N, K, i.size)
+        assert n_pts == int((np.bincount(i, minlength=N) == 0).sum())
+        lab = labels.cpu().numpy()
+        assert (lab <= np.arange(K)).all() and (lab[lab] == lab).all() and np.unique(lab).size == n_cam
+    assert ba.pix2world.visibility_graph_components(cases[-1][0], cases[-1][1], cases[-1][2], 300, DEV) == 1
+
+
+def test_point_order_is_the_stable_sort_by_first_camera(ba):
+    """The engine's internal point order, built on the device (key, stable radix sort, rewrite of the list):
+    ascending first observing camera, ties and every point's observations in the caller's order; unobserved
+    points last; nothing is permuted when the list already has the property; an unsorted list is refused."""
+    import torch
+    rng = np.random.default_rng(3)
+    for N, K, deg in ((5000, 40, 6), (3000, 300, 3), (70000, 70000, 2), (100, 2, 2)):
+        counts = rng.integers(0, deg + 1, N)
+        i = np.repeat(np.arange(N), counts).astype(np.int32)
+        j = np.concatenate([np.sort(rng.choice(K, c, replace=False)) for c in counts] + [np.zeros(0, int)]).astype(np.int32)
+        uv = rng.normal(0, 1, (i.size, 2))
+        sh = ba.engine.Shard(i, j, uv, N, K, 640, 480, DEV)
+        first = np.full(N, K)
+        np.minimum.at(first, i, j)
+        want = np.argsort(first, kind='stable')
+        if (np.diff(first) >= 0).all():
+            assert sh.perm is None
+            continue
+        assert np.array_equal(sh.perm.cpu().numpy(), want)
+        # the observation list in that order, through a round trip of per-point data
+        marks = torch.arange(N, dtype=torch.float64, device=DEV)
+        assert torch.equal(sh.points_to_caller(sh.points_to_engine(marks.view(-1, 1).repeat(1, 3))), marks.view(-1, 1).repeat(1, 3))
+        sh.close()
+    sc = ba.scenes.orbit_scene(N=3000, K=60, track_len=8, seed=2)      # tracker output: already ordered
+    sh = ba.engine.Shard(sc['i'], sc['j'], sc['uv'], sc['N_local'], 60, sc['W'], sc['H'], DEV)
+    first = np.full(sc['N_local'], 60)
+    np.minimum.at(first, sc['i'], sc['j'])
+    assert (sh.perm is None) == bool((np.diff(first) >= 0).all())
+    sh.close()
+    with pytest.raises(ba.engine._lib.BAError, match='sorted by point'):
+        ba.engine.Shard(np.array([1, 0, 0], dtype=np.int32), np.array([0, 0, 1], dtype=np.int32), np.zeros((3, 2)), 2, 2, 640, 480, DEV)
+
+
 # ---- H3/H4/H7/H8/H9: fused observation pass --------------------------------------------------
 def _eval_all(ba, sh, nv, **kw):
     sh.eval(**kw)

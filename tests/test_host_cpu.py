@@ -92,14 +92,6 @@ def test_validation_messages():
         p2w.check_solvable(8, 4, 2, True, True, True)
 
 
-def test_connected_components_match_union_find():
-    rng = np.random.default_rng(0)
-    for N, K, n in ((30, 8, 40), (50, 20, 45), (10, 3, 30)):
-        i = np.sort(rng.integers(0, N, n))
-        j = rng.integers(0, K, n)
-        assert sharding.connected_components_count(i, j, N, K) == orc.count_components(i, j, N, K)
-
-
 # ---- host loop control against the reference's own traces ------------------------------------------
 def _run_mock(g, i, j, uv, N, K, lr, max_iters, **kw):
     sh = MockShard(i, j, uv, N, K, int(g['W']), int(g['H']))
