@@ -5,7 +5,7 @@
 
 The compute path needs libba_mi355x.so (built in-tree by `__graft_entry__.build()`) and a GPU;
 there is no CPU fallback."""
-from .pix2world import (align_scene, error, fit_scene, fit_scene_sparse, gd_adam, gd_func_dict, get_C_Theta_from_X,  # noqa: F401
+from .pix2world import (align_scene, error, fit_scene, fit_scene_sharded, fit_scene_sparse, gd_adam, gd_func_dict, get_C_Theta_from_X,  # noqa: F401
                         get_H_diff_matrix, get_rotations, get_X_from_C_Theta, normalize_scene, ryxz, sgd, transform,
                         validate_scene_parameters)
 from .fit_loop import SceneFit  # noqa: F401

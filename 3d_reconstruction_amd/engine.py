@@ -194,6 +194,7 @@ class Shard:
             t = torch.tensor([float(cap.value)], dtype=F64)
             if torch.distributed.get_backend(self.group) != 'gloo':
                 t = t.to(self.device)
+            self._use_communicator('torch')
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=self.group)
             cap = int(t.item())
             # [camera-frame sums (6K) | sum r^2, sum m.r]: what one sum over the ranks carries per iteration
@@ -206,6 +207,7 @@ class Shard:
         t = torch.tensor([1.0 if flag else 0.0], dtype=F64)
         if torch.distributed.get_backend(self.group) != 'gloo':
             t = t.to(self.device)
+        self._use_communicator('torch')
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN, group=self.group)
         return bool(t.item() > 0.5)
 
@@ -214,17 +216,36 @@ class Shard:
     # with the collective library
     NODE_EXCHANGE_CAPACITY = 131072
 
+    # Two communicators serve a fit on RCCL: the library's own (StreamAllReduce: every collective of the loops, on
+    # the compute stream) and torch.distributed's (set-up and result gathering, on a stream of torch's).  Collectives
+    # of two communicators must never be in flight together on one GPU (their kernels can start in different orders
+    # on different ranks and wait for each other for ever), so whoever changes from one to the other first waits for
+    # the device to drain.
+    def _use_communicator(self, which):
+        if getattr(self, '_communicator_in_use', which) != which and not self._stage_reduce:
+            torch.cuda.synchronize(self.device)
+        self._communicator_in_use = which
+
+    def _own_collectives(self):
+        """The library's communicator on the compute stream (None: torch.distributed carries everything)."""
+        if self._stream_allreduce is False:
+            self._use_communicator('torch')         # its set-up talks through torch.distributed
+            self._stream_allreduce = None if self._stage_reduce else StreamAllReduce.create(self.group, self.device)
+        return self._stream_allreduce
+
     def _sum_over_ranks(self, t):
         if self._node_exchange is False:         # first use: every rank gets here in the same iteration
+            self._use_communicator('torch')
             self._node_exchange = NodeExchange.shared(self.group, self.device, self.NODE_EXCHANGE_CAPACITY)
         if self._node_exchange is not None and t.numel() <= self._node_exchange.capacity:
             self._node_exchange(t, self.stream)
             return
-        if self._stream_allreduce is False:
-            self._stream_allreduce = None if self._stage_reduce else StreamAllReduce.create(self.group, self.device)
-        if self._stream_allreduce is not None:
-            self._stream_allreduce(t, self.stream)
+        own = self._own_collectives()
+        if own is not None:
+            self._use_communicator('own')
+            own(t, self.stream)
             return
+        self._use_communicator('torch')
         if self._stage_reduce:
             host = t.cpu()
             torch.distributed.all_reduce(host, op=torch.distributed.ReduceOp.SUM, group=self.group)
@@ -235,6 +256,12 @@ class Shard:
     def _min_over_ranks(self, t):
         """Elementwise minimum of a device tensor over the ranks of the group, in place."""
         dist = torch.distributed
+        own = self._own_collectives()
+        if own is not None:
+            self._use_communicator('own')
+            own(t, self.stream, op='min')
+            return
+        self._use_communicator('torch')
         if self._stage_reduce:
             host = t.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.MIN, group=self.group)
@@ -245,6 +272,12 @@ class Shard:
     def _broadcast_first(self, t):
         """The first rank's values of a device tensor to every rank of the group, in place."""
         dist = torch.distributed
+        own = self._own_collectives()
+        if own is not None:
+            self._use_communicator('own')
+            own.broadcast(t, 0, self.stream)
+            return
+        self._use_communicator('torch')
         src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
         if self._stage_reduce:
             host = t.cpu()

@@ -4,6 +4,7 @@ arithmetic on an MI355X through libba_mi355x.so.
 
     fit_scene(...)           p2w:480-726   dense (N,K,2) integer tracks, as the reference takes them
     fit_scene_sparse(...)    —             same optimisation on a COO observation list (O(|V|) input)
+    fit_scene_sharded(...)   —             the same, every rank of a process group passing only its own points
     transform(...)           p2w:192-216
     error(...)               p2w:98-111
     validate_scene_parameters(...)  p2w:21-95
@@ -21,7 +22,7 @@ from .fit_loop import SceneFit, extra_optimizers, gd_adam, gd_func_dict, sgd  # 
 from .lm import LMFit
 from .sharding import all_ranks_ok, checked_partition
 
-__all__ = ['fit_scene', 'fit_scene_sparse', 'transform', 'error', 'validate_scene_parameters', 'gd_func_dict', 'sgd', 'gd_adam',
+__all__ = ['fit_scene', 'fit_scene_sparse', 'fit_scene_sharded', 'transform', 'error', 'validate_scene_parameters', 'gd_func_dict', 'sgd', 'gd_adam',
            'get_X_from_C_Theta', 'get_C_Theta_from_X', 'get_H_diff_matrix', 'ryxz', 'get_rotations', 'align_scene',
            'normalize_scene']
 
@@ -248,21 +249,94 @@ def fit_scene_sparse(i, j, uv, N, K, W, H, lr, max_iters, X_0, C_0, Theta_0, phi
 
         def gather_X(x_local):
             from .sharding import all_gather_rows
+            torch.cuda.synchronize(dev)         # the loop's collectives (another communicator) have drained
             return all_gather_rows(x_local, bounds)
     else:
         shard = engine.Shard(i_t, j_t, uv_t, N, K, W, H, dev)
         shard.set_params(X_0, C_0, Theta_0, phi_x_0)
+    return _run_fit(shard, lr, max_iters, (X_mask, C_Theta_mask, phi_x_mask), optimizer, patience, factor, stop_value,
+                    stop_diff, print_step, ret_all_iters, gather_X)
+
+
+def _run_fit(shard, lr, max_iters, masks, optimizer, patience, factor, stop_value, stop_diff, print_step, ret_all_iters,
+             gather_X):
     try:
         if optimizer == 'LM':
             fit = LMFit(shard, max_iters, lam=lr, stop_value=stop_value, stop_diff=stop_diff, print_step=print_step)
             fit.ret_all_iters = False
         else:
-            fit = SceneFit(shard, lr, max_iters, X_mask, C_Theta_mask, phi_x_mask, optimizer, patience, factor,
-                           stop_value, stop_diff, print_step, ret_all_iters)
+            fit = SceneFit(shard, lr, max_iters, *masks, optimizer, patience, factor, stop_value, stop_diff, print_step,
+                           ret_all_iters)
         fit.run()
-        return _pack_results(fit, shard, (X_mask, C_Theta_mask, phi_x_mask), gather_X)
+        return _pack_results(fit, shard, masks, gather_X)
     finally:
         shard.close()
+
+
+def fit_scene_sharded(i_local, j_local, uv_local, N_local, K, W, H, lr, max_iters, X_0_local, C_0, Theta_0, phi_x_0,
+                      X_mask=True, C_Theta_mask=True, phi_x_mask=True, optimizer='Adam', patience=1000, factor=2.0,
+                      stop_value=0.0, stop_diff=1e-12, print_step=1000, ret_all_iters=False, device=None,
+                      check_connectivity=True, gather=False, group=None):
+    """`fit_scene_sparse` for callers that already hold the scene in pieces: every rank of the (initialised)
+    torch.distributed group passes ONLY its own points - local numbers 0 .. N_local - 1, in the order of the
+    global numbering (rank 0's points first) - with their observations (sorted by point, device tensors or arrays)
+    and initial positions; cameras and phi_x are passed in full by everyone.  Nothing of the size of the whole
+    scene is built on any rank.  Same checks and messages as the reference on the WHOLE scene (the counts are
+    added up over the ranks, the visibility graphs are merged through the cameras), same optimisation.  Returns
+    the reference's list with this rank's block of X (and of its history); gather=True returns all points on
+    every rank."""
+    dist = torch.distributed
+    X_0_local, C_0, Theta_0 = (np.asarray(a, dtype=np.float64) for a in (X_0_local, C_0, Theta_0))
+    validate_scene_parameters(X=X_0_local, C=C_0, Theta=Theta_0, phi_x=phi_x_0)
+    if X_0_local.shape[0] != N_local or C_0.shape[0] != K:
+        raise ValueError(f'Expected X_0_local, C_0 to have shape[0] = {N_local}, {K}, got {X_0_local.shape[0]}, {C_0.shape[0]}')
+    dev = torch.device(device) if device is not None else _default_device()
+    several = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    as_t = lambda a: a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
+    i_t, j_t, uv_t = as_t(i_local), as_t(j_local), as_t(uv_local)
+    counts = torch.tensor([int(i_t.numel()), int(N_local)], dtype=torch.int64)
+    sizes = [int(N_local)]
+    if several:
+        host = dist.get_backend(group) == 'gloo'
+        c = counts if host else counts.to(dev)
+        dist.all_reduce(c, group=group)
+        counts = c.cpu()
+        sizes = [None] * dist.get_world_size(group)
+        dist.all_gather_object(sizes, int(N_local), group=group)
+    nV, N = int(counts[0]), int(counts[1])
+    check_solvable(nV, N, K, X_mask, C_Theta_mask, phi_x_mask)
+    if optimizer not in gd_func_dict and optimizer not in extra_optimizers:
+        raise ValueError(f'Unkown name of the optmizer, choose one from {[key for key in gd_func_dict]}')
+    if optimizer == 'LM' and not (X_mask and C_Theta_mask and phi_x_mask):
+        raise ValueError("optimizer='LM' needs X_mask, C_Theta_mask and phi_x_mask to be true")
+    shard, failure = None, None
+    try:
+        if int(i_t.numel()) == 0 or N_local <= 0:
+            raise ValueError('every rank must hold at least one point with an observation')
+        shard = engine.Shard(i_t, j_t, uv_t, N_local, K, W, H, dev, n_visible_total=nV, group=group)
+        shard.set_params(X_0_local, C_0, Theta_0, phi_x_0)
+    except Exception as e:        # the other ranks are about to enter collectives: tell them first
+        failure = e
+    if not all_ranks_ok(failure is None, dev, group):
+        if shard is not None:
+            shard.close()
+        raise failure if failure is not None else RuntimeError('another rank could not set up its shard')
+    if X_mask and C_Theta_mask and check_connectivity:
+        n = visibility_graph_components(i_t, j_t, N_local, K, dev, group)      # the same number on every rank
+        if n > 1:
+            shard.close()
+            raise ValueError('Unable to solve the problem, expected the number of connected components of '
+                             f'visibility graph to be 1, got {n}')
+    gather_X = None
+    if gather and several:
+        bounds = np.concatenate([[0], np.cumsum(sizes)]).tolist()
+
+        def gather_X(x_local):
+            from .sharding import all_gather_rows
+            torch.cuda.synchronize(dev)
+            return all_gather_rows(x_local, bounds, group)
+    return _run_fit(shard, lr, max_iters, (X_mask, C_Theta_mask, phi_x_mask), optimizer, patience, factor, stop_value,
+                    stop_diff, print_step, ret_all_iters, gather_X)
 
 
 def fit_scene(X_pix, W, H, lr, max_iters, X_0, C_0, Theta_0, phi_x_0, X_mask=True, C_Theta_mask=True,

@@ -104,18 +104,31 @@ class StreamAllReduce:
     compared with torch.distributed's before the object is used.  `StreamAllReduce.create` returns
     None (callers then stay with torch.distributed) whenever any of that is not possible."""
 
+    last_created = None      # the latest object `create` handed out in this process (tests look at it)
     NCCL_FLOAT64, NCCL_SUM = 8, 0
+    NCCL_DTYPE = {torch.float64: 8, torch.int32: 2, torch.int64: 4}      # ncclDataType_t
+    NCCL_OP = {'sum': 0, 'max': 2, 'min': 3}                             # ncclRedOp_t
 
     def __init__(self, lib, comm):
         self._lib, self._comm = lib, comm
 
-    def __call__(self, t, stream):
+    def __call__(self, t, stream, op='sum'):
+        """In-place reduction (sum / max / min) of a float64, int32 or int64 device tensor over the ranks."""
         import ctypes as C
         p = C.c_void_p(t.data_ptr())
         st = stream if isinstance(stream, C.c_void_p) else C.c_void_p(stream)
-        rc = self._lib.ncclAllReduce(p, p, C.c_size_t(t.numel()), self.NCCL_FLOAT64, self.NCCL_SUM, self._comm, st)
+        rc = self._lib.ncclAllReduce(p, p, C.c_size_t(t.numel()), self.NCCL_DTYPE[t.dtype], self.NCCL_OP[op], self._comm, st)
         if rc != 0:
             raise RuntimeError(f'ncclAllReduce failed with status {rc}')
+
+    def broadcast(self, t, root, stream):
+        """Rank `root`'s values of a device tensor to every rank, in place, on the caller's stream."""
+        import ctypes as C
+        p = C.c_void_p(t.data_ptr())
+        st = stream if isinstance(stream, C.c_void_p) else C.c_void_p(stream)
+        rc = self._lib.ncclBroadcast(p, p, C.c_size_t(t.numel()), self.NCCL_DTYPE[t.dtype], int(root), self._comm, st)
+        if rc != 0:
+            raise RuntimeError(f'ncclBroadcast failed with status {rc}')
 
     @classmethod
     def create(cls, group, device):
@@ -138,7 +151,8 @@ class StreamAllReduce:
             lib.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
             lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
             lib.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-            for fn in (lib.ncclGetUniqueId, lib.ncclCommInitRank, lib.ncclAllReduce):
+            lib.ncclBroadcast.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+            for fn in (lib.ncclGetUniqueId, lib.ncclCommInitRank, lib.ncclAllReduce, lib.ncclBroadcast):
                 fn.restype = C.c_int
             rank, world = dist.get_rank(group), dist.get_world_size(group)
             uid = UniqueId()
@@ -162,9 +176,23 @@ class StreamAllReduce:
                 obj(a, torch.cuda.current_stream().cuda_stream)
                 torch.cuda.synchronize()        # never two collectives of two communicators in flight on one GPU
             dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group)
-            same = torch.tensor([1.0 if torch.equal(a, b) else 0.0], dtype=torch.float64, device=device)
+            ok = torch.equal(a, b)
+            torch.cuda.synchronize(device)
+            # the other two calls the fit loop makes: minimum of int32, broadcast from the first rank
+            m = torch.tensor([rank + 5, 9 - rank], dtype=torch.int32, device=device)
+            c = torch.full((7,), float(rank + 1), dtype=torch.float64, device=device)
+            with torch.cuda.device(device):
+                obj(m, torch.cuda.current_stream().cuda_stream, op='min')
+                obj.broadcast(c, 0, torch.cuda.current_stream().cuda_stream)
+                torch.cuda.synchronize()
+            ok = ok and m.tolist() == [5, 10 - world] and c.tolist() == [1.0] * 7
+            same = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=device)
             dist.all_reduce(same, op=dist.ReduceOp.MIN, group=group)
-            return obj if float(same.item()) > 0.5 else None
+            torch.cuda.synchronize(device)
+            if float(same.item()) > 0.5:
+                cls.last_created = obj
+                return obj
+            return None
         except Exception:
             return None
 

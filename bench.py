@@ -393,8 +393,23 @@ def main():
         return float(t.item())
 
     note(f'{nv_total} observations in all, {nv_local} here: problem set-up, pre-heating, timed loop')
-    sh = ba.engine.Shard(sc['i'], sc['j'], sc['uv'], sc['N_local'], sc['K'], sc['W'], sc['H'], dev,
-                         n_visible_total=nv_total)
+    # set-up of this rank's share, timed with the list already on the device: the connectivity check of the
+    # reference (p2w:519-525) on the device, then point order + tiles + record layouts (engine.Shard)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    i_d, j_d, uv_d = (torch.from_numpy(sc[k]).to(dev) for k in ('i', 'j', 'uv'))
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    components = ba.pix2world.visibility_graph_components(i_d, j_d, sc['N_local'], sc['K'], dev)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    sh = ba.engine.Shard(i_d, j_d, uv_d, sc['N_local'], sc['K'], sc['W'], sc['H'], dev, n_visible_total=nv_total)
+    torch.cuda.synchronize()
+    t3 = time.perf_counter()
+    setup = {'upload_ms': (t1 - t0) * 1e3, 'connectivity_ms': (t2 - t1) * 1e3, 'components': components,
+             'order_tiles_records_ms': (t3 - t2) * 1e3,
+             'note': 'one-off, outside the timed loop; connectivity and the point order run on the device copy of the list'}
+    del i_d, j_d, uv_d
     fit, dt = run_loop(ba, sh, sc, args.steps, args.warmup, sync)
     dt = max_over_ranks(dt)
     kern_ms = sh.eval_kernel_ms()
@@ -433,7 +448,8 @@ def main():
             'config': {'workload': workload, 'points': N_total, 'cameras': K, 'observations': nv_total,
                        'preheat_iterations': PREHEAT_ITERATIONS,
                        'parallelism': f'point-sharded x{world}, cameras replicated',
-                       'sum_over_ranks': path, 'energy_first_timed': E_first, 'energy_last_timed': E_last},
+                       'sum_over_ranks': path, 'energy_first_timed': E_first, 'energy_last_timed': E_last,
+                       'setup_ms': setup},
             'roofline': roofline_block(
                 'ba::k_run_pass<ba::GradOp, ba::RecI16> (fused observation pass: gradient + point update)',
                 grad_pass_bytes(nv_local, N_loc, K), kern_ms,
@@ -443,6 +459,10 @@ def main():
                          'and out) / kernel time; the kernel streams 8-byte records and carries the fused point '
                          'update, so the bytes it really moves are `traffic`'}),
         }
+        # what an iteration spends outside the observation pass: the camera step, the hand-over between the two
+        # launches and, with several ranks, the sum over the ranks - the part that does not shrink with the shard
+        if len(kern_ms):
+            out['serial_us'] = (dt / args.steps - float(np.mean(kern_ms)) * 1e-3) * 1e6
     sh.close()
     del sh, fit
 

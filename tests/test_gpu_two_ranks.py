@@ -1,7 +1,12 @@
-"""Two ranks on ONE GPU (sums over the ranks by the library's node exchange, or by gloo through the host): the multi-GPU sequence
-of the first-order loop and of the LM extension with real partitioning — each rank holds a point
-range, the camera-side blocks (and, for LM, the Schur complement) are summed across the ranks.
-Results must equal the reference's trace (golden F6) resp. the one-process LM run."""
+"""Two ranks: the multi-GPU sequence of the first-order loop and of the LM extension with real partitioning — each
+rank holds a point range, the camera-side blocks (and, for LM, the Schur complement) are summed across the ranks.
+Results must equal the reference's trace (golden F6) resp. the one-process LM run.
+
+  * on ONE GPU shared by both ranks (what a one-GPU box can run): sums by the library's node exchange, or by gloo
+    through the host;
+  * on TWO GPUs over RCCL (`nccl` backend; skipped where fewer than two are visible): the library's own
+    communicator on the compute stream carries every collective of the loops, torch.distributed's the set-up and the
+    gathering of results - and, opted in, the node exchange across xGMI."""
 import importlib
 import os
 import socket
@@ -30,12 +35,12 @@ def _lm_scene(ba):
     return ba.scenes.orbit_scene(N=300, K=80, track_len=8, seed=4)
 
 
-def _exchange_checks(ba, rank, world):
+def _exchange_checks(ba, rank, world, dev='cuda:0'):
     """The node exchange on its own: lengths around the workgroup chunk, many calls in a row (both slots),
     sums in rank order with identical bits on every rank; then a rank that calls alone gives up and says so."""
     sharding = importlib.import_module('3d_reconstruction_amd.sharding')
     _lib = importlib.import_module('3d_reconstruction_amd._lib')
-    ex = sharding.NodeExchange.create(None, torch.device('cuda:0'), 5000)
+    ex = sharding.NodeExchange.create(None, torch.device(dev), 5000)
     assert ex is not None
     st = torch.cuda.current_stream().cuda_stream
     call = 0
@@ -48,22 +53,22 @@ def _exchange_checks(ba, rank, world):
             want = parts[0].clone()
             for r in range(1, world):
                 want += parts[r]
-            t = parts[rank].to('cuda:0')
+            t = parts[rank].to(dev)
             ex(t, st)
             assert torch.equal(t.cpu(), want), (n, call)
     # the windows' mark for "not yet published" as a value: summed as a NaN, nobody waits for it
     mark = torch.from_numpy(np.array([0x7ff4a5a57ff4a5a5, 0x3ff0000000000000], dtype=np.uint64).view(np.float64))
-    t = (mark if rank == 0 else torch.tensor([2.0, 2.0], dtype=torch.float64)).to('cuda:0')
+    t = (mark if rank == 0 else torch.tensor([2.0, 2.0], dtype=torch.float64)).to(dev)
     ex(t, st)
     got = t.cpu()
     assert torch.isnan(got[0]) and got[1] == (3.0 if world == 2 else 1.0 + 2.0 * (world - 1))
     ex.check()
     with pytest.raises(_lib.BAError):
-        ex(torch.zeros(5001, dtype=torch.float64, device='cuda:0'), st)        # beyond the capacity
+        ex(torch.zeros(5001, dtype=torch.float64, device=dev), st)        # beyond the capacity
     dist.barrier()
     if rank == 0:                       # nobody else calls: the wait runs out, the buffer stays, the status says so
         _lib.check(ex._lib.ba_exchange_set_wait(ex._handle, 0.2))
-        t = torch.full((10,), 3.0, dtype=torch.float64, device='cuda:0')
+        t = torch.full((10,), 3.0, dtype=torch.float64, device=dev)
         ex(t, st)
         torch.cuda.synchronize()
         assert torch.equal(t.cpu(), torch.full((10,), 3.0, dtype=torch.float64))
@@ -76,7 +81,7 @@ def _exchange_checks(ba, rank, world):
     ex.close()
 
 
-def _worker(rank, world, port, out_dir, exchange):
+def _worker(rank, world, port, out_dir, exchange, backend='gloo'):
     sys.path.insert(0, ROOT)
     if exchange:
         os.environ['BA_NODE_EXCHANGE'] = '1'      # opt-in: the default leaves the sums to the collective library
@@ -84,11 +89,17 @@ def _worker(rank, world, port, out_dir, exchange):
         os.environ.pop('BA_NODE_EXCHANGE', None)
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dev = 'cuda:0' if backend == 'gloo' else f'cuda:{rank}'
+    torch.cuda.set_device(dev)
+    if backend == 'gloo':
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    else:
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(dev))
     try:
         ba = importlib.import_module('3d_reconstruction_amd')
         g = np.load(os.path.join(GOLDEN, 'f6_medium.npz'), allow_pickle=False)
-        quiet = dict(print_step=10 ** 9, device='cuda:0')
+        quiet = dict(print_step=10 ** 9, device=dev)
         X, C, Th, phi, E = ba.fit_scene_sparse(g['obs_i'], g['obs_j'], g['obs_xy'] + 0.5, int(g['N']), int(g['K']),
                                                int(g['W']), int(g['H']), 1e-3, 120, g['X_0'], g['C_0'], g['Theta_0'],
                                                float(g['phi_x_0']), patience=100, **quiet)
@@ -104,20 +115,50 @@ def _worker(rank, world, port, out_dir, exchange):
         assert h[5].shape == (5, 60, 3) and h[6].shape == (5, 15, 3) and h[8].shape == (5,)
         assert np.abs(h[5][:4] - g1['Adam_111__step_X']).max() < 1e-9
         assert np.abs(h[0] - g1['Adam_111__final_X']).max() < 1e-9
+        # the entry for callers that hold the scene in pieces: every rank passes its own points only
+        bounds, obs_bounds = ba.sharding.partition_points(g['obs_i'], int(g['N']), world)
+        p0, p1, e0, e1 = bounds[rank], bounds[rank + 1], obs_bounds[rank], obs_bounds[rank + 1]
+        own = ba.fit_scene_sharded(g['obs_i'][e0:e1] - p0, g['obs_j'][e0:e1], g['obs_xy'][e0:e1] + 0.5, p1 - p0, int(g['K']),
+                                   int(g['W']), int(g['H']), 1e-3, 120, g['X_0'][p0:p1], g['C_0'], g['Theta_0'],
+                                   float(g['phi_x_0']), patience=100, **quiet)
+        assert own[0].shape == (p1 - p0, 3) and np.abs(own[0] - X[p0:p1]).max() < 1e-9
+        assert np.abs(own[1] - C).max() < 1e-9 and rel_err(own[4], E) < 1e-9
+        whole = ba.fit_scene_sharded(g['obs_i'][e0:e1] - p0, g['obs_j'][e0:e1], g['obs_xy'][e0:e1] + 0.5, p1 - p0, int(g['K']),
+                                     int(g['W']), int(g['H']), 1e-3, 6, g['X_0'][p0:p1], g['C_0'], g['Theta_0'],
+                                     float(g['phi_x_0']), optimizer='LM', gather=True, **quiet)
+        assert whole[0].shape == (int(g['N']), 3) and whole[4][-1] < 0.5 * whole[4][0]
+        # a scene that falls apart ACROSS the ranks only (every rank's own graph is connected): same verdict and
+        # message on every rank as the reference gives on the whole scene
+        K2 = 6
+        ii = np.repeat(np.arange(40), 3).astype(np.int32)
+        jj = (np.tile(np.arange(3), 40) + 3 * rank).astype(np.int32)
+        with pytest.raises(ValueError, match='connected components of visibility graph to be 1, got 2'):
+            ba.fit_scene_sharded(ii, jj, np.zeros((120, 2)) + 0.5, 40, K2, 640, 480, 1e-3, 3, np.ones((40, 3)),
+                                 np.zeros((K2, 3)), np.zeros((K2, 3)), 1.0, **quiet)
         sharding = importlib.import_module('3d_reconstruction_amd.sharding')
-        assert sharding.NodeExchange.created == (1 if exchange else 0)        # one per process, shared by both fits
+        assert sharding.NodeExchange.created == (1 if exchange else 0)        # one per process, shared by all fits
+        if backend == 'nccl' and not exchange:
+            assert isinstance(sharding.StreamAllReduce.last_created, sharding.StreamAllReduce)   # RCCL on the compute stream
         if exchange:
-            _exchange_checks(ba, rank, world)
+            _exchange_checks(ba, rank, world, dev)
         np.savez(os.path.join(out_dir, f'rank{rank}.npz'), X=X, C=C, Th=Th, phi=phi, E=E, lm_X=lm[0], lm_C=lm[1],
-                 lm_Th=lm[2], lm_phi=lm[3], lm_E=lm[4], hist_X=h[5])
+                 lm_Th=lm[2], lm_phi=lm[3], lm_E=lm[4], hist_X=h[5], lm2_X=whole[0], lm2_E=whole[4])
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('exchange', [True, False], ids=['node exchange', 'sums through the host'])
-def test_two_ranks_share_one_gpu(ba, tmp_path, exchange):
+def _two_gpus():
+    return torch.cuda.device_count() >= 2         # counting devices does not initialise the GPU
+
+
+@pytest.mark.parametrize('backend,exchange', [
+    ('gloo', True), ('gloo', False),
+    pytest.param('nccl', False, marks=pytest.mark.skipif(not _two_gpus(), reason='needs two GPUs')),
+    pytest.param('nccl', True, marks=pytest.mark.skipif(not _two_gpus(), reason='needs two GPUs'))],
+    ids=['one GPU, node exchange', 'one GPU, sums through the host', 'two GPUs, RCCL', 'two GPUs, node exchange over xGMI'])
+def test_two_ranks(ba, tmp_path, backend, exchange):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), exchange), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), exchange, backend), nprocs=world, join=True)
     r0, r1 = np.load(tmp_path / 'rank0.npz'), np.load(tmp_path / 'rank1.npz')
     for key in r0.files:       # replicated state and gathered points are identical on both ranks
         assert np.array_equal(r0[key], r1[key]), key
