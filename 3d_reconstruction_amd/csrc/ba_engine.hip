@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <map>
 #include <mutex>
 #include "ba_device.h"
 
@@ -3242,6 +3243,37 @@ int ba_gauge_fix(int64_t N, int64_t K, double *X, double *C, double *Theta, doub
     return BA_OK;
 }
 
+}  // extern "C"
+
+// Camera table of ba_project: one buffer per (GPU, stream), grown on demand and kept until the process ends, so that a
+// call neither allocates (after the first of its size) nor waits for the stream; calls on one stream are ordered by
+// the stream, calls on different streams have tables of their own.
+static int project_table(hipStream_t st, int64_t K, double **out) {
+    struct Table {
+        double *p = nullptr;
+        int64_t rows = 0;
+    };
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, Table> tables;
+    int dev = -1;
+    BA_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    Table &t = tables[std::make_pair(dev, st)];
+    if (t.rows < K) {
+        if (t.p) {
+            BA_HIP(hipStreamSynchronize(st));       // the last call on this stream may still read the old table
+            BA_HIP(hipFree(t.p));
+            t.p = nullptr, t.rows = 0;
+        }
+        BA_HIP(hipMalloc(&t.p, sizeof(double) * K * CAM_ROW));
+        t.rows = K;
+    }
+    *out = t.p;
+    return BA_OK;
+}
+
+extern "C" {
+
 int ba_project(int64_t N, int64_t K, int64_t n, const int32_t *i, const int32_t *j, const double *X, const double *C,
                const double *Theta, double phi, double W, double H, int delete_back_points, int delete_boundary_points,
                double *out, void *stream) {
@@ -3251,23 +3283,22 @@ int ba_project(int64_t N, int64_t K, int64_t n, const int32_t *i, const int32_t 
     if (n == 0) return BA_OK;
     hipStream_t st = (hipStream_t)stream;
     double *T = nullptr;
-    BA_HIP(hipMalloc(&T, sizeof(double) * K * CAM_ROW));
+    if (int rc = project_table(st, K, &T)) return rc;
     hipLaunchKernelGGL(k_camera_table, dim3(cdiv(K, 256)), dim3(256), 0, st, K, C, Theta, (const double *)nullptr, W, H,
                        T, (double *)nullptr);
     const double w_over_tan = W / tan(phi / 2.0);
     hipLaunchKernelGGL(k_project, dim3(cdiv(n, 256)), dim3(256), 0, st, K, n, i, j, X, T, w_over_tan, W, H,
                        delete_back_points, delete_boundary_points, (double2 *)out);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    hipFree(T);
-    BA_HIP(e);
+    BA_HIP(hipGetLastError());
     return BA_OK;
 }
 
 }  // extern "C"
 
 // ---- ba_project for callers that cannot allocate (HIP graph capture, serving loops): the camera table, which
-// ba_project keeps in a buffer it allocates and frees per call, lives in a fixed array of the code object.
+// ba_project keeps in buffers it allocates on demand, lives in a fixed array of the code object.  The FIRST call on
+// a GPU looks the array's address up (hipGetSymbolAddress: a runtime query that may load the code object, not a
+// stream operation) and so has to happen outside a graph capture; every later call only launches two kernels.
 // Every GPU holds its own copy at its own address; host code reaches it through the pointer
 // hipGetSymbolAddress returns for the current device, never through the array's name.
 constexpr int64_t NOALLOC_MAX_CAMERAS = 16384;                       // 2 MiB of table per GPU

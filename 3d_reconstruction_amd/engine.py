@@ -159,11 +159,17 @@ class Shard:
         """Current [C | Theta | phi_x]; a scale of the gauge fix that is still pending on the centres (the merged
         camera step leaves it to its consumers and hangs the record on the tensor, `_ba_gauge`) is applied first."""
         rec = getattr(self._cam_buf, '_ba_gauge', None)
-        if rec is not None:
-            out = torch.empty_like(self._cam_buf)
-            check(self.lib.ba_scale_centres(self.K, self._cam_buf.data_ptr(), rec.data_ptr(), out.data_ptr(), self.stream))
-            self._cam_buf = out
-        return self._cam_buf
+        if rec is None:
+            return self._cam_buf
+        # the scaled copy is kept beside the raw tensor; the raw tensor stays the current one (`_cam_buf` is what the
+        # table bookkeeping and the fused pass compare by identity), so reading this property changes no state that
+        # the kernels' routes depend on
+        scaled = getattr(self._cam_buf, '_ba_scaled', None)
+        if scaled is None:
+            scaled = torch.empty_like(self._cam_buf)
+            check(self.lib.ba_scale_centres(self.K, self._cam_buf.data_ptr(), rec.data_ptr(), scaled.data_ptr(), self.stream))
+            self._cam_buf._ba_scaled = scaled
+        return scaled
 
     @cam.setter
     def cam(self, value):
@@ -480,6 +486,7 @@ class Shard:
 
     def gauge_fix(self):
         """align_scene + normalize_scene in place on the current buffers (p2w:710-712)."""
+        self._cam_buf = self.cam        # written in place below: a pending scale is applied for good first
         c = self.cam.data_ptr()
         check(self.lib.ba_gauge_fix(self.N, self.K, self.X.data_ptr(), c, c + 24 * self.K, ptr(self.R_gauge),
                                     ptr(self.gauge), self.stream))
@@ -557,6 +564,8 @@ class Shard:
             cam_new._ba_gauge = rec
             self._table_cam = cam_new
             return cam_new, mom_cam, rec
+        if in_place:
+            self._cam_buf = self.cam    # written in place below: a pending scale is applied for good first
         cam_new = new(self.cam)
         if mom_cam is not None:
             s_in, r_in = mom_cam
@@ -646,14 +655,15 @@ class Shard:
         """Fused pass that also leaves the Gauss-Newton blocks V (this shard's points) and
         B, bphi, hphi (summed over the GPUs together with the gradient block)."""
         self._lm_buffers()
-        flags = (_lib.EVAL_TIMED if timed else 0) | (_lib.EVAL_REUSE_TABLE if self.table_valid else 0) | \
+        cam = self.cam
+        flags = (_lib.EVAL_TIMED if timed else 0) | (_lib.EVAL_REUSE_TABLE if self._table_cam is cam else 0) | \
                 (_lib.EVAL_POINT_MAJOR if point_major else 0) | (_lib.EVAL_DENSE_BLOCKS if dense_blocks else 0)
         X = self.X
-        c = self.cam.data_ptr()
+        c = cam.data_ptr()
         K24 = 24 * self.K
         check(self.lib.ba_eval_jtj(self.handle, X.data_ptr(), c, c + K24, c + 2 * K24, flags, *self._out_ptrs,
                                    ptr(self.V), ptr(self.B), ptr(self.bphi), ptr(self.hphi), self.stream))
-        self._table_cam = self.cam
+        self._table_cam = cam
         if self.distributed:
             self._sum_over_ranks(self.red)
             self._sum_over_ranks(self.jred)
@@ -766,9 +776,16 @@ def normalize_scene(X, C_, main_indexes=None, dist_scale=1.0, device='cuda:0'):
     dev = torch.device(device)
     Xd, Cd = _dev_tensor(X, F64, dev).view(-1, 3), _dev_tensor(C_, F64, dev).view(-1, 3)
     N, K = int(Xd.shape[0]), int(Cd.shape[0])
-    j0, j1 = (0, -1) if main_indexes is None else (int(main_indexes[0]), int(main_indexes[1]))
-    if main_indexes is not None:
-        j0, j1 = j0 % K, j1 % K              # numpy's negative indices
+    if main_indexes is None:
+        if K < 2:       # the reference takes the argmax over the cameras after the first one (p2w:322)
+            raise ValueError('attempt to get argmax of an empty sequence')
+        j0, j1 = 0, -1
+    else:
+        j0, j1 = int(main_indexes[0]), int(main_indexes[1])
+        for jx in (j1, j0):                  # numpy's indexing rules (p2w:325): -K .. K - 1, negative from the end
+            if not -K <= jx < K:
+                raise IndexError(f'index {jx} is out of bounds for axis 0 with size {K}')
+        j0, j1 = j0 % K, j1 % K
     X_new, C_new = torch.empty_like(Xd), torch.empty_like(Cd)
     work = torch.empty(2, dtype=F64, device=dev)
     with torch.cuda.device(dev):

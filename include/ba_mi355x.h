@@ -344,11 +344,13 @@ int ba_project(int64_t N, int64_t K, int64_t n, const int32_t *i, const int32_t 
 /* ---- ba_project without any allocation.  No counterpart in the reference: it exists for callers that cannot
  * allocate device memory at the time of the call - code under HIP graph capture, tight serving loops, harnesses that
  * forbid hipMalloc.  Same arguments and results as ba_project; the camera table (K x 16 doubles), which ba_project
- * allocates and frees per call, lives in a fixed array of the library instead (2 MiB per GPU, held until the process
- * ends), so K is limited to 16384 cameras: a larger K returns BA_ERR_ARG and nothing is launched.  The call queues two
- * kernels on `stream` and returns without waiting for them.  All calls on one GPU share that array: calls that overlap
- * on one GPU (different streams, or threads) race; queue them on one stream.  The GPU the work is meant for must be
- * the current device of the calling thread. */
+ * keeps in buffers it allocates on demand (one per GPU and stream, grown when K grows), lives in a fixed array of the
+ * library instead (2 MiB per GPU, held until the process ends), so K is limited to 16384 cameras: a larger K returns
+ * BA_ERR_ARG and nothing is launched.  The call queues two kernels on `stream` and returns without waiting for them.
+ * All calls on one GPU share that array: calls that overlap on one GPU (different streams, or threads) race; queue
+ * them on one stream.  The GPU the work is meant for must be the current device of the calling thread.  The first
+ * call on a GPU looks the array's address up (a runtime query, not a stream operation): make it outside any graph
+ * capture. */
 int ba_project_noalloc(int64_t N, int64_t K, int64_t n, const int32_t *i, const int32_t *j,
                        const double *X, const double *C, const double *Theta, double phi, double W, double H,
                        int delete_back_points, int delete_boundary_points, double *out, void *stream);

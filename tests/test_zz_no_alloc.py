@@ -60,3 +60,16 @@ def test_project_noalloc_matches_project():
     assert rc == -1 and b'16384 cameras' in lib.ba_last_error()
     torch.cuda.synchronize()
     assert float(out.abs().sum()) == 0.0            # nothing was launched
+    # no device memory changes hands in a call (the first call on the GPU, above, looked the array's address up)
+    Xd = torch.zeros((50, 3), dtype=torch.float64, device=DEV)
+    Xd[:, 2] = 5.0
+    Cd = torch.zeros((9, 3), dtype=torch.float64, device=DEV)
+    out = torch.zeros((450, 2), dtype=torch.float64, device=DEV)
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    for _ in range(3):
+        _lib.check(lib.ba_project_noalloc(50, 9, 450, None, None, _lib.ptr(Xd), _lib.ptr(Cd), _lib.ptr(Cd), 1.2, 1920.0,
+                                          1080.0, 1, 0, _lib.ptr(out), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free_before
+    assert float(out[0, 0]) == 960.0 and float(out[0, 1]) == 540.0        # a point on the optical axis: the principal point
