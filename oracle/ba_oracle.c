@@ -7,14 +7,22 @@
  * from the cpu_baseline leg of bench.py, never from the product package.  It is pinned by
  * tests/test_oracle_golden.py against vectors captured from the reference itself.
  *
- * Scalar, single-threaded, double precision; follows the reference's own formulas (the 27
- * entries of dR/dTheta are formed per camera exactly as p2w:678-692 does) rather than the
- * rearrangement the GPU kernels use, so that the two are independent derivations.
+ * Scalar double precision; follows the reference's own formulas (the 27 entries of dR/dTheta are
+ * formed per camera exactly as p2w:678-692 does) rather than the rearrangement the GPU kernels
+ * use, so that the two are independent derivations.  One thread by default (what the parity tests
+ * use); orc_set_threads(n) spreads the observation loop, the update rule and the gauge fix over n
+ * OpenMP threads for the CPU baseline (contiguous ranges of points per thread, camera sums per
+ * thread added up in thread order: deterministic for a given n).
  */
 #include <math.h>
+#include <omp.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+
+static int g_threads = 1;
+void orc_set_threads(int n) { g_threads = n > 0 ? n : 1; }
+int orc_get_threads(void) { return g_threads; }
 
 static void mat3_mul(const double *a, const double *b, double *c) {
     for (int r = 0; r < 3; ++r)
@@ -82,37 +90,69 @@ double orc_energy_and_gradients(int64_t N, int64_t K, int64_t nV, int64_t n_visi
     const double dphi = -f / sin(phi_x);
     const double inv_nv = 1.0 / (double)n_visible;
     double e_sum = 0.0, gp = 0.0;
-    for (int64_t e = 0; e < nV; ++e) {
-        const int64_t i = oi[e], j = oj[e];
-        const double *Rj = R + 9 * j, *x = X + 3 * i, *c = C + 3 * j;
-        const double d[3] = {x[0] - c[0], x[1] - c[1], x[2] - c[2]};
-        double q[3];
-        for (int k = 0; k < 3; ++k) q[k] = d[0] * Rj[k] + d[1] * Rj[3 + k] + d[2] * Rj[6 + k];
-        const double m0 = q[0] / q[2], m1 = q[1] / q[2];
-        const double r0 = f * m0 + W / 2.0 - uv[2 * e], r1 = f * m1 + H / 2.0 - uv[2 * e + 1];
-        e_sum += r0 * r0 + r1 * r1;
-        /* A = d model / d q (p2w:654-655) */
-        const double A[2][3] = {{f / q[2], 0.0, -f / (q[2] * q[2]) * q[0]}, {0.0, f / q[2], -f / (q[2] * q[2]) * q[1]}};
-        const double w0 = r0 * inv_nv, w1 = r1 * inv_nv;
-        /* J_X = A R^T (p2w:657), dE/dX += w J_X, dE/dC -= w J_X */
-        for (int k = 0; k < 3; ++k) {
-            const double jx0 = A[0][0] * Rj[3 * k] + A[0][1] * Rj[3 * k + 1] + A[0][2] * Rj[3 * k + 2];
-            const double jx1 = A[1][0] * Rj[3 * k] + A[1][1] * Rj[3 * k + 1] + A[1][2] * Rj[3 * k + 2];
-            const double g = w0 * jx0 + w1 * jx1;
-            gX[3 * i + k] += g;
-            gC[3 * j + k] -= g;
-        }
-        /* J_Theta = A (dR/dtheta)^T d (p2w:694-695) */
-        for (int l = 0; l < 3; ++l) {
-            const double *D = dR + 27 * j + 9 * l;
-            double dq[3];
-            for (int k = 0; k < 3; ++k) dq[k] = d[0] * D[k] + d[1] * D[3 + k] + d[2] * D[6 + k];
-            const double jt0 = A[0][0] * dq[0] + A[0][2] * dq[2];
-            const double jt1 = A[1][1] * dq[1] + A[1][2] * dq[2];
-            gTheta[3 * j + l] += w0 * jt0 + w1 * jt1;
-        }
-        gp += w0 * (dphi * m0) + w1 * (dphi * m1); /* p2w:701-702 */
+    const int T = g_threads;
+    /* thread t takes the observations [cut[t], cut[t + 1]): equal shares moved forward to the next point's first
+     * observation, so that no two threads touch one row of gX */
+    int64_t *cut = (int64_t *)malloc(sizeof(int64_t) * (T + 1));
+    for (int t = 0; t <= T; ++t) {
+        int64_t e = nV * t / T;
+        while (e > 0 && e < nV && oi[e] == oi[e - 1]) ++e;
+        cut[t] = e;
     }
+    double *cam_part = T > 1 ? (double *)calloc((size_t)T * 6 * K, sizeof(double)) : NULL;
+    double *sc_part = (double *)calloc((size_t)T * 2, sizeof(double));
+#pragma omp parallel num_threads(T)
+    {
+        const int t = omp_get_thread_num();
+        double *gC_t = T > 1 ? cam_part + (size_t)t * 6 * K : gC;
+        double *gTheta_t = T > 1 ? gC_t + 3 * K : gTheta;
+        double e_sum_t = 0.0, gp_t = 0.0;
+        for (int64_t e = cut[t]; e < cut[t + 1]; ++e) {
+            const int64_t i = oi[e], j = oj[e];
+            const double *Rj = R + 9 * j, *x = X + 3 * i, *c = C + 3 * j;
+            const double d[3] = {x[0] - c[0], x[1] - c[1], x[2] - c[2]};
+            double q[3];
+            for (int k = 0; k < 3; ++k) q[k] = d[0] * Rj[k] + d[1] * Rj[3 + k] + d[2] * Rj[6 + k];
+            const double m0 = q[0] / q[2], m1 = q[1] / q[2];
+            const double r0 = f * m0 + W / 2.0 - uv[2 * e], r1 = f * m1 + H / 2.0 - uv[2 * e + 1];
+            e_sum_t += r0 * r0 + r1 * r1;
+            /* A = d model / d q (p2w:654-655) */
+            const double A[2][3] = {{f / q[2], 0.0, -f / (q[2] * q[2]) * q[0]}, {0.0, f / q[2], -f / (q[2] * q[2]) * q[1]}};
+            const double w0 = r0 * inv_nv, w1 = r1 * inv_nv;
+            /* J_X = A R^T (p2w:657), dE/dX += w J_X, dE/dC -= w J_X */
+            for (int k = 0; k < 3; ++k) {
+                const double jx0 = A[0][0] * Rj[3 * k] + A[0][1] * Rj[3 * k + 1] + A[0][2] * Rj[3 * k + 2];
+                const double jx1 = A[1][0] * Rj[3 * k] + A[1][1] * Rj[3 * k + 1] + A[1][2] * Rj[3 * k + 2];
+                const double g = w0 * jx0 + w1 * jx1;
+                gX[3 * i + k] += g;
+                gC_t[3 * j + k] -= g;
+            }
+            /* J_Theta = A (dR/dtheta)^T d (p2w:694-695) */
+            for (int l = 0; l < 3; ++l) {
+                const double *D = dR + 27 * j + 9 * l;
+                double dq[3];
+                for (int k = 0; k < 3; ++k) dq[k] = d[0] * D[k] + d[1] * D[3 + k] + d[2] * D[6 + k];
+                const double jt0 = A[0][0] * dq[0] + A[0][2] * dq[2];
+                const double jt1 = A[1][1] * dq[1] + A[1][2] * dq[2];
+                gTheta_t[3 * j + l] += w0 * jt0 + w1 * jt1;
+            }
+            gp_t += w0 * (dphi * m0) + w1 * (dphi * m1); /* p2w:701-702 */
+        }
+        sc_part[2 * t] = e_sum_t;
+        sc_part[2 * t + 1] = gp_t;
+    }
+    for (int t = 0; t < T; ++t) {
+        e_sum += sc_part[2 * t];
+        gp += sc_part[2 * t + 1];
+        if (T > 1)
+            for (int64_t k = 0; k < 3 * K; ++k) {
+                gC[k] += cam_part[(size_t)t * 6 * K + k];
+                gTheta[k] += cam_part[(size_t)t * 6 * K + 3 * K + k];
+            }
+    }
+    free(cut);
+    free(cam_part);
+    free(sc_part);
     gphi[0] = gp;
     free(R);
     free(dR);
@@ -123,6 +163,7 @@ double orc_energy_and_gradients(int64_t N, int64_t K, int64_t nV, int64_t n_visi
 void orc_adam(int64_t n, double *x, const double *g, double *s, double *r, double lr, int64_t t) {
     const double rho1 = 0.9, rho2 = 0.999;
     const double bc1 = 1.0 - pow(rho1, (double)t), bc2 = 1.0 - pow(rho2, (double)t);
+#pragma omp parallel for num_threads(g_threads) schedule(static) if (n > 4096)
     for (int64_t k = 0; k < n; ++k) {
         s[k] = rho1 * s[k] + (1.0 - rho1) * g[k];
         r[k] = rho2 * r[k] + (1.0 - rho2) * (g[k] * g[k]);
@@ -152,6 +193,7 @@ void orc_gauge_fix(int64_t N, int64_t K, double *X, double *C, double *Theta) {
     }
     const double factor = 1.0 / sqrt(best);
     for (int64_t k = 0; k < 3 * K; ++k) C[k] *= factor;
+#pragma omp parallel for num_threads(g_threads) schedule(static) if (N > 4096)
     for (int64_t i = 0; i < N; ++i) {
         const double d[3] = {X[3 * i] - c0[0], X[3 * i + 1] - c0[1], X[3 * i + 2] - c0[2]};
         for (int k = 0; k < 3; ++k) X[3 * i + k] = (d[0] * R0[k] + d[1] * R0[3 + k] + d[2] * R0[6 + k]) * factor;

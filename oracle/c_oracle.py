@@ -28,10 +28,17 @@ def load():
         lib.orc_iteration.restype = C.c_double
         lib.orc_iteration.argtypes = [C.c_int64] * 3 + [_i, _i, _d, _d, _d, _d, _d, C.c_double, C.c_double,
                                                         C.c_double, C.c_int64] + [_d] * 12
+        lib.orc_set_threads.restype = None
+        lib.orc_set_threads.argtypes = [C.c_int]
         lib.orc_gauge_fix.restype = None
         lib.orc_gauge_fix.argtypes = [C.c_int64, C.c_int64, _d, _d, _d]
         _lib = lib
     return _lib
+
+
+def set_threads(n):
+    """OpenMP threads of the C restatement (1 by default: what the parity tests use)."""
+    load().orc_set_threads(int(n))
 
 
 def energy_and_gradients(X, C_, Theta, phi_x, W, H, i, j, uv, n_visible=None):
