@@ -36,7 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak
-TRAFFIC_FILE = os.path.join('profiles', 'r02_pmc_traffic_cfg3.json')
+TRAFFIC_FILE = os.path.join('profiles', 'r03_pmc_traffic_cfg3.json')
 
 
 def measured_traffic(kernel_key, points_per_gpu, cameras, track_len):
