@@ -62,6 +62,7 @@ SIGNATURES = {
     'ba_camera_step': (_int, [_p] * 8 + [_i64, _i64, _int, _dbl, _dbl, _dbl, _dbl, _int, _p, _p, _p]),
     'ba_camera_step_finalize': (_int, [_p, _p, _p, _p, _p, _int] + [_p] * 4 + [_i64, _i64, _int, _dbl, _dbl, _dbl, _dbl, _p, _p, _p, _p]),
     'ba_triangulate': (_int, [_i64, _i64, _p, _p, _p, _p, _p, _dbl, _dbl, _dbl, _int, _i64, _p, _p, _p]),
+    'ba_problem_triangulate': (_int, [_p, _p, _p, _dbl, _int, _p, _p, _p]),
     'ba_resect': (_int, [_i64, _i64, _p, _p, _p, _p, _dbl, _dbl, _dbl, _int, _i64, _p, _p, _p]),
     'ba_sum_buffer_size': (_int, [_p, _p]),
     'ba_set_sum_buffer': (_int, [_p, _p, _i64]),

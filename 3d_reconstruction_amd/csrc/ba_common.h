@@ -121,6 +121,7 @@ struct ba_problem {
     double *partials_jtj = nullptr;  // 3 per tile
     int64_t *row_ptr = nullptr;      // N + 1
     int max_degree = 0;              // most observations of one point
+    int tri_selected_cameras = -1;   // cameras that see a point observed at least twice (ba_problem_triangulate), -1: not counted yet
     // Schur build on the matrix cores: ranges of points of a tile whose cameras lie within a window of slots
     // ({tile, first point in the tile, points, first slot | cameras << 16}), and per tile whether the pair kernel
     // takes it instead (a point of it sees cameras further apart than the window); built on first use
@@ -149,4 +150,6 @@ struct ba_problem {
 namespace ba {
 // builds the camera table and scalars of the handle from C, Theta, phi (K1)
 int camera_table(ba_problem *p, const double *C, const double *Theta, const double *phi, hipStream_t st);
+// observation range of every point (row_ptr) and the longest track (max_degree) of the handle, built on first use
+int ensure_row_ptr(ba_problem *p);
 }  // namespace ba

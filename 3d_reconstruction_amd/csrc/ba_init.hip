@@ -70,110 +70,142 @@ __global__ void k_projection_matrices(int64_t K, const double *__restrict__ C, c
 // First three pivots of the Cholesky factorisation with diagonal pivoting of a symmetric positive
 // semi-definite 4 x 4 matrix (fully unrolled, no indexed registers).  The pivots follow the eigenvalues
 // within small factors, which is all the rank test needs: rank >= 3  <=>  d3 > threshold x d1.
-__device__ __forceinline__ void pivots_4x4(double (&A)[4][4], double &d1, double &d3) {
+// Nothing is swapped: the step that takes pivot p subtracts col_p col_p^T / a_pp from the WHOLE matrix, which
+// zeroes row and column p (diagonal entry included), so that index is never the largest diagonal entry again;
+// M holds the upper triangle row by row (00 01 02 03 11 12 13 22 23 33).
+__device__ __forceinline__ void pivots_4x4(const double (&M)[10], double &d1, double &d3) {
+    double a00 = M[0], a01 = M[1], a02 = M[2], a03 = M[3], a11 = M[4], a12 = M[5], a13 = M[6], a22 = M[7], a23 = M[8],
+           a33 = M[9];
     double piv[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        int p = k;
-        double best = A[k][k];
-#pragma unroll
-        for (int q = k + 1; q < 4; ++q)
-            if (A[q][q] > best) {
-                best = A[q][q];
-                p = q;
-            }
-#pragma unroll
-        for (int q = k + 1; q < 4; ++q)
-            if (q == p) {      // symmetric swap of rows / columns k and q
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double t = A[k][r];
-                    A[k][r] = A[q][r];
-                    A[q][r] = t;
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double t = A[r][k];
-                    A[r][k] = A[r][q];
-                    A[r][q] = t;
-                }
-            }
-        piv[k] = A[k][k];
-        const double inv = A[k][k] > 0.0 ? 1.0 / A[k][k] : 0.0;
-#pragma unroll
-        for (int r = k + 1; r < 4; ++r)
-#pragma unroll
-            for (int c = k + 1; c < 4; ++c) A[r][c] -= A[r][k] * A[c][k] * inv;
+        const double m01 = fmax(a00, a11), m23 = fmax(a22, a33), best = fmax(m01, m23);
+        const bool p0 = a00 == best, p1 = !p0 && a11 == best, p2 = !p0 && !p1 && a22 == best;
+        // column p of the symmetric matrix
+        const double c0 = p0 ? a00 : (p1 ? a01 : (p2 ? a02 : a03));
+        const double c1 = p0 ? a01 : (p1 ? a11 : (p2 ? a12 : a13));
+        const double c2 = p0 ? a02 : (p1 ? a12 : (p2 ? a22 : a23));
+        const double c3 = p0 ? a03 : (p1 ? a13 : (p2 ? a23 : a33));
+        piv[k] = best;
+        const double inv = best > 0.0 ? fast_rcp_wide(best) : 0.0;
+        const double s0 = c0 * inv, s1 = c1 * inv, s2 = c2 * inv, s3 = c3 * inv;
+        a00 = fma(-s0, c0, a00);
+        a01 = fma(-s0, c1, a01);
+        a02 = fma(-s0, c2, a02);
+        a03 = fma(-s0, c3, a03);
+        a11 = fma(-s1, c1, a11);
+        a12 = fma(-s1, c2, a12);
+        a13 = fma(-s1, c3, a13);
+        a22 = fma(-s2, c2, a22);
+        a23 = fma(-s2, c3, a23);
+        a33 = fma(-s3, c3, a33);
+        // the pivot's own diagonal entry is zero by construction; rounding must not leave it a candidate
+        a00 = p0 ? 0.0 : a00;
+        a11 = p1 ? 0.0 : a11;
+        a22 = p2 ? 0.0 : a22;
+        a33 = (!p0 && !p1 && !p2) ? 0.0 : a33;
     }
     d1 = piv[0];
     d3 = piv[2];
 }
 
-// One thread per point.  The observations of the workgroup's 256 consecutive points are one contiguous range
-// of the list: it is copied to LDS with coalesced loads first (a thread walking its own points' records in
-// global memory makes every load instruction touch 64 cache lines), as long as it fits TRI_STAGE records.
-constexpr int TRI_STAGE = 3072;
+// Four lanes per point: lane q of a point's quad takes its observations q, q + 4, q + 8, ... (the four lanes read four
+// consecutive records, a wave's 16 points one contiguous stretch of the list), keeps its share of the ten sums of
+// [A b]^T [A b] in registers, and the quad adds the shares up with two DPP exchanges per sum.  A track of ten
+// observations is a chain of three dependent (record, projection row) load pairs per lane instead of ten, with four
+// times as many loads in flight, and nothing is staged in LDS, so the registers alone bound the resident waves -
+// the loop is bound by that latency chain, not by arithmetic (one thread per point with the records staged in LDS:
+// 126 us at 1 M points / 10 M observations in random point order, 90 us in the engine's order; this form 94 / 83 us.
+// Measured on top of it and dropped: the rows of a workgroup's camera window staged in LDS (100 us), and four rounds
+// of sixteen points per wave so that the rank test and the solve run on all lanes instead of one in four (87 / 100)).
+__device__ __forceinline__ double quad_sum(double v) {
+    {
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xB1, 0xf, 0xf, false);     // quad_perm [1,0,3,2]
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xB1, 0xf, 0xf, false);
+        v += __hiloint2double(hi, lo);
+    }
+    {
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x4E, 0xf, 0xf, false);     // quad_perm [2,3,0,1]
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x4E, 0xf, 0xf, false);
+        v += __hiloint2double(hi, lo);
+    }
+    return v;
+}
+
 __global__ void __launch_bounds__(256) k_triangulate(int64_t N, const int64_t *__restrict__ row_ptr,
                                                      const int32_t *__restrict__ oj, const double2 *__restrict__ uv,
                                                      const double *__restrict__ P, Intrinsics in, double rank_thr,
                                                      double *__restrict__ X) {
-    __shared__ double2 s_uv[TRI_STAGE];
-    __shared__ int32_t s_j[TRI_STAGE];
-    const int64_t i_first = (int64_t)blockIdx.x * 256;
-    const int64_t i_last = i_first + 256 < N ? i_first + 256 : N;
-    const int64_t b0 = row_ptr[i_first], b1 = row_ptr[i_last];
-    const bool staged = b1 - b0 <= TRI_STAGE;
-    if (staged) {
-        for (int64_t e = b0 + threadIdx.x; e < b1; e += 256) {
-            s_uv[e - b0] = uv[e];
-            s_j[e - b0] = oj[e];
+    const int tid = threadIdx.x, q4 = tid & 3;
+    const int64_t i_raw = (int64_t)blockIdx.x * 64 + (tid >> 2);
+    const int64_t i = i_raw < N ? i_raw : N - 1;            // every lane of a quad stays in the exchange below
+    const int64_t e0 = row_ptr[i], e1 = row_ptr[i + 1];
+    double M[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};               // upper triangle of [A b]^T [A b], row-major
+    // three of the lane's observations per trip (a track of up to twelve in one): their camera numbers are requested
+    // together, then their rows and pixels together - three memory latencies per trip whatever it holds
+    constexpr int TRIP = 3;
+    for (int64_t base = e0 + q4; base < e1; base += 4 * TRIP) {
+        int jn[TRIP];
+#pragma unroll
+        for (int t = 0; t < TRIP; ++t) jn[t] = base + 4 * t < e1 ? oj[base + 4 * t] : 0;
+        double2 Pt[TRIP][6], ct[TRIP];
+#pragma unroll
+        for (int t = 0; t < TRIP; ++t) {
+            if (base + 4 * t < e1) {
+                const double2 *Pv = (const double2 *)(P + 12 * (int64_t)jn[t]);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) Pt[t][q] = Pv[q];
+                ct[t] = uv[base + 4 * t];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < TRIP; ++t) {
+            if (base + 4 * t < e1) {
+                double Pj[12];
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    Pj[2 * q] = Pt[t][q].x;
+                    Pj[2 * q + 1] = Pt[t][q].y;
+                }
+                const double u = (ct[t].x - in.sx) * in.scale, v = (ct[t].y - in.sy) * in.scale;
+                double a[4], b[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    a[q] = u * Pj[8 + q] - Pj[q];                 // p2w:1703
+                    b[q] = v * Pj[8 + q] - Pj[4 + q];             // p2w:1704
+                }
+                int idx = 0;
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int q = p; q < 4; ++q) M[idx++] += a[p] * a[q] + b[p] * b[q];
+            }
         }
     }
+#pragma unroll
+    for (int k = 0; k < 10; ++k) M[k] = quad_sum(M[k]);
+    // The rank test and the 3 x 3 solve are some six hundred instructions per point: done by the quads' first lanes
+    // they would run at a quarter of the lanes in every wave (three quarters of this kernel's time, measured with the
+    // loads taken out).  The sums of the workgroup's 64 points go through LDS to its first wave instead.
+    __shared__ double s_M[10][64];
+    __shared__ int s_deg[64];
+    if (q4 == 0) {
+#pragma unroll
+        for (int k = 0; k < 10; ++k) s_M[k][tid >> 2] = M[k];
+        s_deg[tid >> 2] = (int)(e1 - e0);
+    }
     __syncthreads();
-    const int64_t i = i_first + threadIdx.x;
-    if (i >= N) return;
+    if (tid >= 64) return;
+    const int64_t i_mine = (int64_t)blockIdx.x * 64 + tid;
+    if (i_mine >= N) return;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) M[k] = s_M[k][tid];
+    const int deg = s_deg[tid];
     const double nan = __builtin_nan("");
-    const int64_t e0 = row_ptr[i], e1 = row_ptr[i + 1];
     double x0 = nan, x1 = nan, x2 = nan;
-    if (e1 - e0 >= 2) {                                           // p2w:1671
-        double M[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};           // upper triangle of [A b]^T [A b], row-major
-        for (int64_t e = e0; e < e1; ++e) {
-            const double2 *Pv = (const double2 *)(P + 12 * (int64_t)(staged ? s_j[e - b0] : oj[e]));
-            double Pj[12];
-#pragma unroll
-            for (int q = 0; q < 6; ++q) {
-                const double2 t = Pv[q];
-                Pj[2 * q] = t.x;
-                Pj[2 * q + 1] = t.y;
-            }
-            const double2 c = staged ? s_uv[e - b0] : uv[e];
-            const double u = (c.x - in.sx) * in.scale, v = (c.y - in.sy) * in.scale;
-            double a[4], b[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                a[q] = u * Pj[8 + q] - Pj[q];                     // p2w:1703
-                b[q] = v * Pj[8 + q] - Pj[4 + q];                 // p2w:1704
-            }
-            int idx = 0;
-#pragma unroll
-            for (int p = 0; p < 4; ++p)
-#pragma unroll
-                for (int q = p; q < 4; ++q) M[idx++] += a[p] * a[q] + b[p] * b[q];
-        }
-        double A[4][4];
-        {
-            int idx = 0;
-#pragma unroll
-            for (int p = 0; p < 4; ++p)
-#pragma unroll
-                for (int q = p; q < 4; ++q) {
-                    A[p][q] = M[idx];
-                    A[q][p] = M[idx];
-                    ++idx;
-                }
-        }
+    if (deg >= 2) {                                               // p2w:1671
         double d1, d3;
-        pivots_4x4(A, d1, d3);
+        pivots_4x4(M, d1, d3);
         if (d3 > d1 * rank_thr && d1 > 0.0) {                     // rank >= 3, p2w:1707
             // X = -(A3^T A3)^-1 A3^T b  (p2w:1716-1719): G = M[0,1,2; 4,5; 7], h = M[3], M[6], M[8]
             const double g00 = M[0], g01 = M[1], g02 = M[2], g11 = M[4], g12 = M[5], g22 = M[7];
@@ -181,15 +213,31 @@ __global__ void __launch_bounds__(256) k_triangulate(int64_t N, const int64_t *_
             const double c00 = g11 * g22 - g12 * g12, c01 = g02 * g12 - g01 * g22, c02 = g01 * g12 - g02 * g11;
             const double det = g00 * c00 + g01 * c01 + g02 * c02;
             const double c11 = g00 * g22 - g02 * g02, c12 = g01 * g02 - g00 * g12, c22 = g00 * g11 - g01 * g01;
-            const double id = 1.0 / det;
+            const double id = fast_rcp_wide(det);
             x0 = -(c00 * h0 + c01 * h1 + c02 * h2) * id;
             x1 = -(c01 * h0 + c11 * h1 + c12 * h2) * id;
             x2 = -(c02 * h0 + c12 * h1 + c22 * h2) * id;
         }
     }
-    X[3 * i] = x0;
-    X[3 * i + 1] = x1;
-    X[3 * i + 2] = x2;
+    X[3 * i_mine] = x0;
+    X[3 * i_mine + 1] = x1;
+    X[3 * i_mine + 2] = x2;
+}
+
+// cameras that see at least one point observed twice or more (p2w:1676): marked, then counted
+__global__ void k_mark_selected_cameras(int64_t N, const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ oj,
+                                        int *__restrict__ mark) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int64_t e0 = row_ptr[i], e1 = row_ptr[i + 1];
+    if (e1 - e0 < 2) return;
+    for (int64_t e = e0; e < e1; ++e) mark[oj[e]] = 1;
+}
+
+__global__ void k_count_marks(int64_t K, const int *__restrict__ mark, int *__restrict__ count) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long m = __ballot(j < K && mark[j] != 0);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, __popcll(m));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -418,10 +466,33 @@ int ba_triangulate(int64_t N, int64_t K, const int64_t *row_ptr, const int32_t *
     const double tol = (double)(rank_rows > 4 ? rank_rows : 4) * 2.220446049250313e-16;
     const double thr = tol * tol > RANK_FLOOR ? tol * tol : RANK_FLOOR;
     hipLaunchKernelGGL(k_projection_matrices, dim3(cdiv_n(K, 256)), dim3(256), 0, st, K, C, Theta, in, P_work);
-    hipLaunchKernelGGL(k_triangulate, dim3(cdiv_n(N, 256)), dim3(256), 0, st, N, row_ptr, oj, (const double2 *)uv, P_work, in,
-                       thr, X_out);
+    hipLaunchKernelGGL(k_triangulate, dim3(cdiv_n(N, 64)), dim3(256), 0, st, N, row_ptr, oj, (const double2 *)uv, P_work, in, thr,
+                       X_out);
     BA_HIP(hipGetLastError());
     return BA_OK;
+}
+
+int ba_problem_triangulate(ba_problem *p, const double *C, const double *Theta, double phi_x, int normalize,
+                           double *P_work, double *X_out, void *stream) {
+    BA_REQUIRE(p && C && Theta && P_work && X_out, "ba_problem_triangulate: null pointer");
+    if (int rc = ensure_row_ptr(p)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (p->tri_selected_cameras < 0) {      // once per problem: numpy's rank tolerance counts these cameras
+        int *mark = nullptr;
+        BA_HIP(hipMalloc(&mark, sizeof(int) * (p->K + 1)));
+        hipError_t e = hipMemsetAsync(mark, 0, sizeof(int) * (p->K + 1), st);
+        hipLaunchKernelGGL(k_mark_selected_cameras, dim3(cdiv_n(p->N, 256)), dim3(256), 0, st, p->N, p->row_ptr, p->oj, mark);
+        hipLaunchKernelGGL(k_count_marks, dim3(cdiv_n(p->K, 256)), dim3(256), 0, st, p->K, mark, mark + p->K);
+        int n = 0;
+        if (e == hipSuccess) e = hipMemcpyAsync(&n, mark + p->K, sizeof(int), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        hipFree(mark);
+        BA_HIP(e);
+        p->tri_selected_cameras = n;
+    }
+    const int64_t rank_rows = 2 * (int64_t)p->tri_selected_cameras > 4 ? 2 * (int64_t)p->tri_selected_cameras : 4;
+    return ba_triangulate(p->N, p->K, p->row_ptr, p->oj, (const double *)p->ouv, C, Theta, phi_x, p->W, p->H, normalize,
+                          rank_rows, P_work, X_out, stream);
 }
 
 int ba_resect(int64_t N, int64_t K, const int64_t *col_ptr, const int32_t *oi_by_camera, const double *uv_by_camera,

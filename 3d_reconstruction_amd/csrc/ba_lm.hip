@@ -1477,6 +1477,18 @@ static int cdiv_i(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 using namespace ba;
 
+int ba::ensure_row_ptr(ba_problem *p) {
+    if (p->row_ptr) return BA_OK;
+    BA_HIP(hipMalloc(&p->row_ptr, sizeof(int64_t) * (p->N + 1)));
+    hipLaunchKernelGGL(k_row_ptr, dim3(cdiv_i(p->nV + 1, 256)), dim3(256), 0, 0, p->oi, p->nV, p->N, p->row_ptr);
+    int *dmax = p->flag + 3;
+    BA_HIP(hipMemset(dmax, 0, sizeof(int)));
+    hipLaunchKernelGGL(k_max_degree, dim3(cdiv_i(p->N, 256)), dim3(256), 0, 0, p->row_ptr, p->N, dmax);
+    BA_HIP(hipGetLastError());
+    BA_HIP(hipMemcpy(&p->max_degree, dmax, sizeof(int), hipMemcpyDeviceToHost));
+    return BA_OK;
+}
+
 extern "C" {
 
 int ba_eval_jtj(ba_problem *p, const double *X, const double *C, const double *Theta, const double *phi, int flags,
@@ -1594,17 +1606,6 @@ int ba_build_camera_table(ba_problem *p, const double *C, const double *Theta, c
     return camera_table(p, C, Theta, phi, (hipStream_t)stream);
 }
 
-static int ensure_row_ptr(ba_problem *p) {
-    if (p->row_ptr) return BA_OK;
-    BA_HIP(hipMalloc(&p->row_ptr, sizeof(int64_t) * (p->N + 1)));
-    hipLaunchKernelGGL(k_row_ptr, dim3(cdiv_i(p->nV + 1, 256)), dim3(256), 0, 0, p->oi, p->nV, p->N, p->row_ptr);
-    int *dmax = p->flag + 3;
-    BA_HIP(hipMemset(dmax, 0, sizeof(int)));
-    hipLaunchKernelGGL(k_max_degree, dim3(cdiv_i(p->N, 256)), dim3(256), 0, 0, p->row_ptr, p->N, dmax);
-    BA_HIP(hipGetLastError());
-    BA_HIP(hipMemcpy(&p->max_degree, dmax, sizeof(int), hipMemcpyDeviceToHost));
-    return BA_OK;
-}
 
 // Lowest and highest camera slot (of its tile) among a point's observations; {INT_MAX, -1} for a point nobody sees.
 __global__ void k_point_slot_range(int64_t N, const int64_t *__restrict__ row_ptr, const uint32_t *__restrict__ opack,

@@ -607,6 +607,19 @@ class Shard:
                                           rec.data_ptr() if gauge else None, self.stream))
         return X_new, cam_new, mom_x, mom_cam
 
+    def triangulate(self, normalize=False):
+        """Every point of the shard from the CURRENT cameras by linear triangulation (get_X_from_C_Theta,
+        p2w:1655-1721) on the shard's own observation list; returns a device tensor (N, 3) in the caller's point
+        order, NaN where the reference leaves NaN.  The parameters are not touched."""
+        cam = self.cam
+        c = cam.data_ptr()
+        K24 = 24 * self.K
+        X = torch.empty((self.N, 3), dtype=F64, device=self.device)
+        P = torch.empty(12 * self.K, dtype=F64, device=self.device)
+        check(self.lib.ba_problem_triangulate(self.handle, c, c + K24, float(cam[6 * self.K].item()), int(bool(normalize)),
+                                              ptr(P), ptr(X), self.stream))
+        return self.points_to_caller(X)
+
     # ---- second-order extension (no reference counterpart) ---------------------------------------
     def _lm_buffers(self):
         if not hasattr(self, 'V'):

@@ -264,6 +264,11 @@ int ba_points_step(int64_t N, const double *X_in, double *X_out, const double *g
 int ba_triangulate(int64_t N, int64_t K, const int64_t *row_ptr, const int32_t *oj, const double *uv,
                    const double *C, const double *Theta, double phi_x, double W, double H, int normalize,
                    int64_t rank_rows, double *P_work, double *X_out, void *stream);
+/* The same on the observation list a problem handle holds (its points in the engine's internal order, in which a
+ * workgroup's points see a short window of cameras whose projection rows are staged in LDS): X_out[N][3] in that
+ * order.  rank_rows is counted from the list on first use.  P_work: 12 K doubles of scratch. */
+int ba_problem_triangulate(ba_problem *p, const double *C, const double *Theta, double phi_x, int normalize,
+                           double *P_work, double *X_out, void *stream);
 int ba_resect(int64_t N, int64_t K, const int64_t *col_ptr, const int32_t *oi_by_camera,
               const double *uv_by_camera, const double *X, double phi_x, double W, double H, int normalize,
               int64_t rank_rows, double *C_out, double *Theta_out, void *stream);

@@ -654,6 +654,34 @@ def test_triangulation_and_resection_vs_oracle_and_round_trip(ba):
 
 
 # ---- full-size properties (N = 1 M points, K = 2 k cameras, ~10 M observations) ---------------
+def test_shard_triangulates_its_own_list(ba, golden):
+    """Shard.triangulate (the kernel on the engine's own point order, projection rows staged in LDS) gives what the
+    reference's get_X_from_C_Theta gives (golden F7, NaN pattern included) and what the stand-alone call gives on a
+    scene whose points come in random order."""
+    import torch
+    g = golden('f7_linear_init.npz')
+    N, K = int(g['N']), int(g['K'])
+    for tag, norm in (('true', False), ('noisy', True), ('noisy', False)):
+        sh = ba.engine.Shard(g['obs_i'], g['obs_j'], g['obs_xy'] + 0.5, N, K, int(g['W']), int(g['H']), DEV)
+        sh.set_params(np.zeros((N, 3)), g[f'C_{tag}'], g[f'Theta_{tag}'], float(g['phi_x']))
+        got = sh.triangulate(normalize=norm).cpu().numpy()
+        want = g[f"tri_{tag}_{'norm' if norm else 'pix'}"]
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        assert np.nanmax(np.abs(got - want)) < 1e-9
+        sh.close()
+    sc = ba.scenes.orbit_scene(N=30000, K=400, track_len=9, seed=6)
+    sh = ba.engine.Shard(sc['i'], sc['j'], sc['uv'], sc['N_local'], 400, sc['W'], sc['H'], DEV)
+    assert sh.perm is not None
+    sh.set_params(sc['X_0'], sc['C'], sc['Theta'], sc['phi_x'])
+    got = sh.triangulate()
+    want = ba.engine.triangulate(sc['i'], sc['j'], sc['uv'], sc['N_local'], sc['C'], sc['Theta'], sc['phi_x'], sc['W'], sc['H'],
+                                 False, DEV)
+    assert torch.equal(torch.isnan(got), torch.isnan(want))
+    assert float((got - want).abs().nan_to_num().max()) < 1e-9
+    assert float((got - torch.from_numpy(sc['X']).to(DEV)).abs().nan_to_num().max()) < 0.5      # pixel quantisation only
+    sh.close()
+
+
 def test_full_size_invariants(ba):
     import torch
     sc = ba.scenes.orbit_scene(N=1_000_000, K=2000, track_len=10, seed=0)
