@@ -260,6 +260,20 @@ __global__ void k_scatter_observations(int64_t nV, const int32_t *__restrict__ o
     uv_out[dst] = ouv[e];
 }
 
+__global__ void k_gather_int(int64_t n, const int32_t *__restrict__ src, const int *__restrict__ idx, int *__restrict__ dst) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < n) dst[v] = src[idx[v]];
+}
+
+__global__ void k_iota_check_order(int64_t n, const int32_t *__restrict__ key, int *__restrict__ key_copy, int *__restrict__ val,
+                                   int *unsorted) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    val[v] = (int)v;
+    key_copy[v] = key[v];
+    if (v > 0 && key[v] < key[v - 1]) atomicOr(unsorted, 1);
+}
+
 struct DeviceBuffers {      // frees what it holds when the call returns, whichever way
     std::vector<void *> held;
     template <class T>
@@ -274,6 +288,27 @@ struct DeviceBuffers {      // frees what it holds when the call returns, whiche
         for (void *q : held) hipFree(q);
     }
 };
+
+// Stable sort of the pairs (key[cur], val[cur]) by the low `bits` bits of the keys; returns the index of the buffer
+// pair that holds the result.  hist: 256 x blocks_of(n, RS_ITEMS) ints.
+int radix_sort_pairs(int64_t n, int *key[2], int *val[2], int *hist, int bits, hipStream_t st) {
+    const int n_blocks = (int)blocks_of(n, RS_ITEMS);
+    int cur = 0;
+    for (int shift = 0; shift < bits; shift += 8) {
+        hipLaunchKernelGGL(k_radix_hist, dim3(n_blocks), dim3(64), 0, st, key[cur], n, shift, hist, n_blocks);
+        hipLaunchKernelGGL(k_scan_int_single, dim3(1), dim3(1024), 0, st, hist, (int64_t)256 * n_blocks);
+        hipLaunchKernelGGL(k_radix_scatter, dim3(n_blocks), dim3(64), 0, st, key[cur], val[cur], n, shift, hist, n_blocks,
+                           key[cur ^ 1], val[cur ^ 1]);
+        cur ^= 1;
+    }
+    return cur;
+}
+
+int bits_for(int64_t max_key) {
+    int bits = 1;
+    while (((int64_t)1 << bits) <= max_key) ++bits;
+    return bits;
+}
 
 }  // namespace
 }  // namespace ba
@@ -355,19 +390,9 @@ int ba_order_points_by_first_camera(int64_t N, int64_t K, int64_t nV, const int3
     // stable sort of the points by that key
     BA_HIP(buf.get(&key[1], (size_t)N));
     BA_HIP(buf.get(&val[1], (size_t)N));
-    const int n_blocks = (int)blocks_of(N, RS_ITEMS);
     int *hist = nullptr;
-    BA_HIP(buf.get(&hist, (size_t)256 * n_blocks));
-    int bits = 1;
-    while (((int64_t)1 << bits) <= K) ++bits;       // keys 0 .. K
-    int cur = 0;
-    for (int shift = 0; shift < bits; shift += 8) {
-        hipLaunchKernelGGL(k_radix_hist, dim3(n_blocks), dim3(64), 0, st, key[cur], N, shift, hist, n_blocks);
-        hipLaunchKernelGGL(k_scan_int_single, dim3(1), dim3(1024), 0, st, hist, (int64_t)256 * n_blocks);
-        hipLaunchKernelGGL(k_radix_scatter, dim3(n_blocks), dim3(64), 0, st, key[cur], val[cur], N, shift, hist, n_blocks,
-                           key[cur ^ 1], val[cur ^ 1]);
-        cur ^= 1;
-    }
+    BA_HIP(buf.get(&hist, (size_t)256 * blocks_of(N, RS_ITEMS)));
+    const int cur = radix_sort_pairs(N, key, val, hist, bits_for(K), st);      // keys 0 .. K
     BA_HIP(hipMemcpyAsync(perm, val[cur], sizeof(int) * N, hipMemcpyDeviceToDevice, st));
 
     // the observation list in the new order: every point's observations keep their order and move as a block
@@ -386,6 +411,38 @@ int ba_order_points_by_first_camera(int64_t N, int64_t K, int64_t nV, const int3
     if (nV > 0)
         hipLaunchKernelGGL(k_scatter_observations, dim3(blocks_of(nV, 256)), dim3(256), 0, st, nV, i, j, (const double2 *)uv,
                            row_ptr, inv, row_ptr_new, i_out, j_out, (double2 *)uv_out);
+    BA_HIP(hipGetLastError());
+    BA_HIP(hipStreamSynchronize(st));       // the work buffers are freed on return
+    return BA_OK;
+}
+
+int ba_argsort_by_camera(int64_t nV, int64_t N, int64_t K, const int32_t *i, const int32_t *j, int32_t *order,
+                         void *stream) {
+    BA_REQUIRE(nV >= 0 && N > 0 && K > 0 && (nV == 0 || (i && j && order)), "ba_argsort_by_camera: bad argument");
+    BA_REQUIRE(nV < ((int64_t)1 << 31) && N < ((int64_t)1 << 31) && K < ((int64_t)1 << 31), "ba_argsort_by_camera: index range");
+    if (nV == 0) return BA_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceBuffers buf;
+    int *key[2] = {nullptr, nullptr}, *val[2] = {nullptr, nullptr}, *hist = nullptr, *flag = nullptr;
+    for (int b = 0; b < 2; ++b) {
+        BA_HIP(buf.get(&key[b], (size_t)nV));
+        BA_HIP(buf.get(&val[b], (size_t)nV));
+    }
+    BA_HIP(buf.get(&hist, (size_t)256 * blocks_of(nV, RS_ITEMS)));
+    BA_HIP(buf.get(&flag, 1));
+    BA_HIP(hipMemsetAsync(flag, 0, sizeof(int), st));
+    // is the list already in point order?  then one stable sort by camera gives (camera, point ascending)
+    hipLaunchKernelGGL(k_iota_check_order, dim3(blocks_of(nV, 256)), dim3(256), 0, st, nV, i, key[0], val[0], flag);
+    int unsorted = 0;
+    BA_HIP(hipMemcpyAsync(&unsorted, flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    BA_HIP(hipStreamSynchronize(st));
+    int cur = 0;
+    if (unsorted) cur = radix_sort_pairs(nV, key, val, hist, bits_for(N - 1), st);
+    // keys of the second sort: the cameras in the order reached so far
+    int *k2[2] = {key[cur], key[cur ^ 1]}, *v2[2] = {val[cur], val[cur ^ 1]};
+    hipLaunchKernelGGL(k_gather_int, dim3(blocks_of(nV, 256)), dim3(256), 0, st, nV, j, v2[0], k2[0]);
+    const int c2 = radix_sort_pairs(nV, k2, v2, hist, bits_for(K - 1), st);
+    BA_HIP(hipMemcpyAsync(order, v2[c2], sizeof(int) * nV, hipMemcpyDeviceToDevice, st));
     BA_HIP(hipGetLastError());
     BA_HIP(hipStreamSynchronize(st));       // the work buffers are freed on return
     return BA_OK;

@@ -841,6 +841,14 @@ def reprojection_error(pix_xy, model, device='cuda:0'):
     return float(s[0]), int(s[1])
 
 
+def _order_by_camera(oi, oj, N, K):
+    """Indices that sort the observation list by camera, points ascending inside a camera (ba_argsort_by_camera)."""
+    order = torch.empty(int(oi.numel()), dtype=torch.int32, device=oi.device)
+    with torch.cuda.device(oi.device):
+        check(_lib.load().ba_argsort_by_camera(int(oi.numel()), int(N), int(K), ptr(oi), ptr(oj), ptr(order), stream_ptr()))
+    return order.to(torch.int64)
+
+
 def _ranges(keys, n):
     """Offsets (int64, n + 1) of the runs of a sorted int key tensor with values in [0, n)."""
     counts = torch.bincount(keys.to(torch.int64), minlength=n)
@@ -887,7 +895,7 @@ def resect(oi, oj, uv, K, X, phi_x, W, H, normalize=False, device='cuda:0'):
     uv = _dev_tensor(uv, F64, dev).view(-1, 2)
     Xd = _dev_tensor(X, F64, dev)
     N = int(Xd.shape[0])
-    order = torch.argsort(oj.to(torch.int64), stable=True)
+    order = _order_by_camera(oi, oj, N, K)
     oj_s = oj[order]
     col_ptr, counts = _ranges(oj_s, K)
     if not bool((counts >= 6).any()):
@@ -912,7 +920,7 @@ def homography_diff_matrix(oi, oj, uv, N, K, normalize=False, W=None, H=None, mi
     oi = _dev_tensor(oi, torch.int32, dev)
     oj = _dev_tensor(oj, torch.int32, dev)
     uv = _dev_tensor(uv, F64, dev).view(-1, 2)
-    order = torch.argsort(oj.to(torch.int64) * int(N) + oi.to(torch.int64))       # by camera, points ascending
+    order = _order_by_camera(oi, oj, N, K)       # by camera, points ascending
     oj_s = oj[order]
     col_ptr, _ = _ranges(oj_s, K)
     oi_s, uv_s = oi[order].contiguous(), _take_rows(uv, order)

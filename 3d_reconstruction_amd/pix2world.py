@@ -172,8 +172,12 @@ def _pack_results(fit, shard, masks, gather_X=None):
         K3 = 3 * shard.K
         g = 0
         if X_mask:
-            back = (lambda h: h) if shard.perm is None else \
-                (lambda h, inv=torch.argsort(shard.perm).cpu().numpy(): h[inv])
+            if shard.perm is None:
+                back = lambda h: h
+            else:       # inverse of the engine's point order by a scatter
+                inv = np.empty(shard.N, dtype=np.int64)
+                inv[shard.perm.cpu().numpy()] = np.arange(shard.N)
+                back = lambda h, inv=inv: h[inv]
             snaps = []
             for h in hist[g]:
                 if h is not None:

@@ -88,6 +88,12 @@ int ba_order_points_by_first_camera(int64_t N, int64_t K, int64_t nV, const int3
                                     const double *uv, int32_t *perm, int32_t *i_out, int32_t *j_out, double *uv_out,
                                     int *h_identity, void *stream);
 
+/* ---- order[nV]: the observations sorted by camera, points ascending inside a camera, ties in the caller's order (the
+ * order ba_resect and ba_homography_diff_matrix take their lists in).  An own stable radix sort on the device; a list
+ * that is already sorted by point needs one sort, any other two. */
+int ba_argsort_by_camera(int64_t nV, int64_t N, int64_t K, const int32_t *i, const int32_t *j, int32_t *order,
+                         void *stream);
+
 /* ---- problem handle: the observation list of one GPU's shard (its points, all cameras).
  * Observations must be sorted by point (i non-decreasing); the arrays are copied.
  * Replaces the dense (N,K) temporaries fit_scene allocates at p2w:538-542, 555-573. */
