@@ -119,3 +119,98 @@ class MockShard:
             cam[:K3] = torch.from_numpy(np.ascontiguousarray(Cg)).reshape(-1)
             cam[K3:2 * K3] = torch.from_numpy(np.ascontiguousarray(Th)).reshape(-1)
         return X, cam, mom_x, mom_cam
+
+
+class FusedMockShard(MockShard):
+    """MockShard with the interface of the fused loop (eval_update, camera_update(finalize), arm_eval_update,
+    wait_energy_fire): the observation pass applies the point update itself, the rigid part of the gauge fix stays
+    pending on the points as a record, and the wait for the energy launches the pass armed for the next iteration
+    when the energy falls in the window it was given - INTO THE BUFFERS IT WAS TOLD TO OVERWRITE, like the device
+    path.  Lets the host-side window logic (fit_loop.SceneFit._arm_next) be checked against the schedule on a CPU."""
+    can_fuse = True
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self._X_gauge = None
+        self._armed = None
+        self.fired_log = []
+
+    _X_buf = property(lambda self: self.X)
+    cam_raw = property(lambda self: self.cam)
+
+    def snapshot(self):
+        return (self.X, self._X_gauge, self.cam)
+
+    def restore(self, snap):
+        self.X, self._X_gauge, self.cam = snap
+
+    def adopt(self, X, cam, X_gauge=None):
+        self.X, self.cam, self._X_gauge = X, cam, X_gauge
+
+    def _true_points(self, X, rec):
+        """The points a pending gauge record stands for: align + normalise with the cameras the record was made from."""
+        if rec is None:
+            return X
+        C_upd, Th_upd = rec
+        Xg, Cg, _ = orc.align_scene(X.numpy(), C_upd, Theta=Th_upd)
+        Xg, _ = orc.normalize_scene(Xg, Cg)
+        return torch.from_numpy(np.ascontiguousarray(Xg))
+
+    def _pass(self, X, rec, cam, rule, lr, bc1, bc2, mom_x):
+        """Gradients and energy at (true points, cam) into gX / red; returns the updated points and moments."""
+        Xt = self._true_points(X, rec)
+        keep = (self.X, self.cam)
+        self.X, self.cam = Xt, cam
+        MockShard.eval(self)
+        self.X, self.cam = keep
+        xn, mom = self._apply(rule, Xt.reshape(-1), self.gX.view(-1), mom_x, lr, (bc1, bc2))
+        return xn.view(self.N, 3), mom
+
+    def eval(self, *a, **kw):
+        self.X, self._X_gauge = self._true_points(self.X, self._X_gauge), None
+        MockShard.eval(self)
+
+    def eval_update(self, rule, lr, bc1, bc2, mom_x, grad_cam=True, grad_phi=True, timed=False, defer_finalize=False):
+        return self._pass(self.X, self._X_gauge, self.cam, rule, lr, bc1, bc2, mom_x)
+
+    def camera_update(self, rule, lr, bc1, bc2, cam_range, mom_cam, gauge, in_place=False, finalize=False):
+        lo, hi = cam_range
+        sl = None if mom_cam is None else (mom_cam[0][lo:hi], mom_cam[1][lo:hi])
+        cn, sl = self._apply(rule, self.cam[lo:hi], self.red[lo:hi], sl, lr, (bc1, bc2))
+        cam = self.cam.clone()
+        cam[lo:hi] = cn
+        if mom_cam is not None:
+            mom_cam = (mom_cam[0].clone(), mom_cam[1].clone())
+            mom_cam[0][lo:hi], mom_cam[1][lo:hi] = sl
+        rec = None
+        if gauge:
+            K3 = 3 * self.K
+            C_upd, Th_upd = cam[:K3].view(self.K, 3).numpy().copy(), cam[K3:2 * K3].view(self.K, 3).numpy().copy()
+            _, Cg, Th = orc.align_scene(np.zeros((1, 3)), C_upd, Theta=Th_upd)
+            _, Cg = orc.normalize_scene(np.zeros((1, 3)), Cg)
+            cam[:K3] = torch.from_numpy(np.ascontiguousarray(Cg)).reshape(-1)
+            cam[K3:2 * K3] = torch.from_numpy(np.ascontiguousarray(Th)).reshape(-1)
+            rec = (C_upd, Th_upd)
+        return cam, mom_cam, rec
+
+    def step_update(self, rule, lr, bc1, bc2, x_free, cam_range, mom_x, mom_cam, gauge, in_place=False):
+        self.X, self._X_gauge = self._true_points(self.X, self._X_gauge), None
+        return MockShard.step_update(self, rule, lr, bc1, bc2, x_free, cam_range, mom_x, mom_cam, gauge, in_place)
+
+    def arm_eval_update(self, rule, lr, bc1, bc2, X_in, X_gauge, cam_in, mom_x_in, outs, grad_cam=True, grad_phi=True,
+                        timed=False):
+        self._armed = (rule, lr, bc1, bc2, X_in, X_gauge, cam_in, mom_x_in, outs)
+
+    def wait_energy_fire(self, lo, hi, alt_lo):
+        E = self.energy()
+        fired = 1 if lo <= E < hi else (2 if (E >= hi and E >= alt_lo) else 0)
+        if fired:
+            rule, lr, bc1, bc2, X_in, rec, cam_in, mom_in, outs = self._armed
+            X_out, s_out, r_out, X_alt = outs
+            xn, mom = self._pass(X_in, rec, cam_in, rule, lr, bc1, bc2, mom_in)
+            (X_out if fired == 1 else X_alt).copy_(xn)          # overwritten in place, before the schedule has run
+            if mom is not None:
+                s_out.copy_(mom[0])
+                r_out.copy_(mom[1])
+        self.fired_log.append(fired)
+        return E, fired

@@ -245,6 +245,43 @@ def test_unknown_optimizer_message():
     assert set(p2w.gd_func_dict) == {'SGD', 'Adam'}
 
 
+def test_launch_ahead_window_agrees_with_the_schedule(golden):
+    """The wait for the energy may launch the next pass into buffers that are dead only if the schedule does not
+    intervene; the window (fit_loop.SceneFit._arm_next) is computed before the energy is known.  On a mock of the
+    fused device path that really overwrites those buffers: runs with LR increases, decreases with rollback,
+    stop_value and stop_diff exits reproduce, energy for energy and to the last bit, the runs without launch-ahead
+    (a fired pass the schedule then overruled raises inside step()), and passes were launched ahead in every run."""
+    from mock_shard import FusedMockShard
+    g = golden('f3_lr_events.npz')
+    i, j, uv = orc.visibility_coo(g['X_pix'])
+    N, K = g['X_pix'].shape[:2]
+    base = golden('f10_early_stops.npz')
+    cases = [dict(lr=1e-3, max_iters=120, patience=20), dict(lr=1e-3, max_iters=90, patience=3),
+             dict(lr=1e-3, max_iters=80, patience=1, factor=3.0), dict(lr=1e-7, max_iters=60, patience=2, optimizer='SGD'),
+             dict(lr=1e-3, max_iters=200, patience=20, stop_value=float(base['stop_value__arg_stop_value'])),
+             dict(lr=1e-3, max_iters=200, patience=3, stop_diff=10.0), dict(lr=1e-3, max_iters=200, patience=2, stop_diff=20.0)]
+    for kw in cases:
+        kw = dict(kw)
+        lr, max_iters = kw.pop('lr'), kw.pop('max_iters')
+        runs = []
+        for ahead in (True, False):
+            sh = FusedMockShard(i, j, uv, N, K, int(g['W']), int(g['H']))
+            sh.set_params(g['X_0'], g['C_0'], g['Theta_0'], float(g['phi_x_0']))
+            lines = []
+            fit = fit_loop.SceneFit(sh, lr, max_iters, printer=lines.append, **kw)
+            assert fit.fuse
+            fit.launch_ahead = ahead
+            fit.run()
+            runs.append((fit.energies(), sh._true_points(sh.X, sh._X_gauge).numpy().copy(), sh.cam.numpy().copy(), lines, fit.fired,
+                         fit.dropped))
+        (E1, X1, c1, l1, fired, dropped), (E0, X0, c0, l0, _, _) = runs
+        assert fired > 0, kw
+        assert np.array_equal(E1, E0) and np.array_equal(X1, X0) and np.array_equal(c1, c0), kw
+        assert l1 == l0, kw
+    # the schedule did intervene in these runs (LR events, early exits), i.e. windows were refused too
+    assert any('Decrease' in ln for ln in l0) or any('Reached stopping' in ln for ln in l0)
+
+
 # ---- partitioning ----------------------------------------------------------------------------------
 def test_partition_points_properties():
     rng = np.random.default_rng(1)
