@@ -532,6 +532,24 @@ def test_fit_scene_lm_converges_like_dense_lm(ba):
                             sc['C_0'], sc['Theta_0'], sc['phi_x_0'], optimizer='LM', phi_x_mask=False)
 
 
+def test_fit_scene_lm_on_the_recorded_scene_with_long_tracks(ba, golden):
+    """moscow_ride (93 points, 327 cameras, tracks of up to 196 observations: the chunked point kernel of the
+    Schur build) from the recorded start of the reference: the accept/reject trajectory of the dense NumPy loop,
+    and an energy below what the reference's Adam reached in 300 iterations."""
+    g = golden('f2_moscow_ride.npz')
+    sc = dict(i=g['obs_i'], j=g['obs_j'], uv=g['obs_xy'] + 0.5, W=int(g['W']), H=int(g['H']), X_0=g['free__X_0'],
+              C_0=g['C_0'], Theta_0=g['Theta_0'], phi_x_0=float(g['phi_x_0']))
+    assert np.bincount(sc['i']).max() > 128
+    iters = 12
+    out = ba.fit_scene_sparse(sc['i'], sc['j'], sc['uv'], int(g['N']), int(g['K']), sc['W'], sc['H'], 1e-3, iters,
+                              sc['X_0'], sc['C_0'], sc['Theta_0'], sc['phi_x_0'], optimizer='LM', print_step=10 ** 9)
+    Xr, Cr, Tr, pr, Er = _numpy_lm(sc, iters - 1, 1e-3)
+    assert out[4].shape == Er.shape
+    assert rel_err(out[4], Er) < 1e-6
+    assert out[4][-1] < g['free__E'][-1] < out[4][0]
+    assert np.abs(out[0] - Xr).max() < 1e-5 * np.abs(Xr).max() and np.abs(out[1] - Cr).max() < 1e-5
+
+
 def test_twenty_thousand_cameras_lm_step_at_full_size(ba):
     """The large-K configuration at its full size (K = 20 000 cameras, 1 M points, 10 M observations: reduced
     system of 120 001 unknowns, S = 115 GB in HBM) through size-independent properties of ONE damped
