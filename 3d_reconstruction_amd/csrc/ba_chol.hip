@@ -70,9 +70,11 @@ struct CholCache {
         size_t bytes = 0;
     };
     std::mutex mu;
-    Buf linv, tmp, info, newpos, moves, T, runs, first;
+    Buf linv, tmp, info, newpos, moves, T, runs, first, cfirst, guard;
     // what the lists in `newpos`, `moves` and `runs` were built for
     bool lists_valid = false;
+    bool guard_valid = false;       // `guard` holds `profile` (the queued form compares the caller's profile with it)
+    int *result_host = nullptr, *result_dev = nullptr;      // one word of mapped host memory: verdict of the queued form
     int64_t n = 0, ld = 0, chains = 0, chain_blocks = 0, sep_blocks = 0;
     int clear = 0;
     std::vector<int> profile;
@@ -774,12 +776,154 @@ __global__ void __launch_bounds__(256) k_solve_step(const double *__restrict__ A
     }
 }
 
+// ---- backward solve L^T x = y of the reordered factorisation in three launches instead of one per block ----------
+// A block step is a chain of two trips to memory and next to no arithmetic, so a launch per step costs its launch
+// latency 32 times at n = 12 001.  What is behind the chains (separators, rest of the band, border: `tail`) is a small
+// dense triangle that ONE workgroup walks through with the right-hand side in LDS (k_back_tail); its effect on the
+// chains' unknowns is one product over the whole chip (k_back_tail_to_chains); then every chain is walked by a
+// workgroup of its own (k_back_chains).
+constexpr int BACK_TAIL_MAX_BLOCKS = 48;      // tail blocks one workgroup takes (right-hand side: 24 KB of LDS)
+constexpr int BACK_CHAIN_MAX_BLOCKS = 96;     // blocks of a chain (48 KB of LDS)
+
+// x_k = Linv_k^T b_k for k = nb - 1 .. B0, b_i -= L_ki^T x_k for the tail's rows i before k; x -> out.
+// One workgroup of 1024 threads; dynamic LDS: (nb - B0) * 64 doubles.
+__global__ void __launch_bounds__(1024) k_back_tail(const double *__restrict__ A, int64_t ld, const double *__restrict__ Linv,
+                                                     const double *__restrict__ b, double *__restrict__ out, int64_t B0,
+                                                     int64_t nb) {
+    extern __shared__ double bt[];
+    __shared__ double xk[NB], part[16][NB + 1];
+    const int tid = threadIdx.x;
+    const int64_t base = B0 * NB;
+    const int nD = (int)(nb - B0);
+    for (int idx = tid; idx < nD * NB; idx += 1024) bt[idx] = b[base + idx];
+    const int r = tid & 63, q = tid >> 6;       // the product with the inverse: entry r, columns 4 q .. 4 q + 3
+    double lv[4];
+    {
+        const double *Lk = Linv + (nb - 1) * NB * NB;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) lv[c] = Lk[(4 * q + c) * NB + r];
+    }
+    __syncthreads();
+    for (int64_t k = nb - 1; k >= B0; --k) {
+        const int lk = (int)(k - B0) * NB;
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s += lv[c] * bt[lk + 4 * q + c];
+        part[q][r] = s;
+        if (k > B0) {       // the next block's inverse is on its way while this step's update runs
+            const double *Lk = Linv + (k - 1) * NB * NB;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) lv[c] = Lk[(4 * q + c) * NB + r];
+        }
+        __syncthreads();
+        if (tid < NB) {
+            double x = 0.0;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) x += part[g][tid];
+            xk[tid] = x;
+            out[k * NB + tid] = x;
+        }
+        __syncthreads();
+        // rows k0 .. k0 + 63 of L, columns base .. k0: thread (column tid & 255 of a pass of 256, rows 16 (tid >> 8) ..)
+        const int cg = tid & 255, rg = tid >> 8;
+        const double *Ar = A + (k * NB + 16 * rg) * ld + base;
+        for (int col = cg; col < lk; col += 256) {
+            double u = 0.0;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) u += Ar[(int64_t)c * ld + col] * xk[16 * rg + c];
+            atomicAdd(&bt[col], -u);
+        }
+        __syncthreads();
+    }
+}
+
+// b_i -= sum over the tail's rows of L_ri x_r for the chains' unknowns i.  Workgroup (slab of 128 columns, tail block):
+// a separator's rows hold entries in the columns of the chains on either side of it only.
+__global__ void __launch_bounds__(256) k_back_tail_to_chains(const double *__restrict__ A, int64_t ld, const double *__restrict__ x,
+                                                             double *__restrict__ b, int64_t B0, int64_t T0, int64_t bw,
+                                                             int64_t chain_rows) {
+    __shared__ double xs[NB];
+    const int tid = threadIdx.x;
+    const int64_t k = B0 + blockIdx.y, col0 = (int64_t)blockIdx.x * 128;
+    if (k < T0) {
+        const int64_t sep = (k - B0) / bw, c_first = col0 / chain_rows, c_last = (col0 + 127) / chain_rows;
+        if (c_last < sep || c_first > sep + 1) return;
+    }
+    if (tid < NB) xs[tid] = x[k * NB + tid];
+    __syncthreads();
+    const int col = tid & 127, half = tid >> 7;
+    if (col0 + col >= B0 * NB) return;
+    const double *Ar = A + (k * NB + 32 * half) * ld + col0 + col;
+    double u = 0.0;
+#pragma unroll 16
+    for (int c = 0; c < 32; ++c) u += Ar[(int64_t)c * ld] * xs[32 * half + c];
+    atomicAdd(b + col0 + col, -u);
+}
+
+// Chain blockIdx.x: x_l = Linv_l^T b_l for its blocks l = s_blocks - 1 .. 0, b_i -= L_li^T x_l for the chain's rows
+// from block first[l] on.  256 threads; dynamic LDS: s_blocks * 64 doubles.
+__global__ void __launch_bounds__(256) k_back_chains(const double *__restrict__ A, int64_t ld, const double *__restrict__ Linv,
+                                                      const double *__restrict__ b, double *__restrict__ out, int s_blocks,
+                                                      const int *__restrict__ first) {
+    extern __shared__ double bt[];
+    __shared__ double xk[NB], part[4][NB + 1];
+    const int tid = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * s_blocks * NB;
+    A += base * ld + base;
+    Linv += base * NB;
+    for (int idx = tid; idx < s_blocks * NB; idx += 256) bt[idx] = b[base + idx];
+    const int r = tid & 63, q = tid >> 6;
+    double lv[16];
+    {
+        const double *Lk = Linv + (int64_t)(s_blocks - 1) * NB * NB;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) lv[c] = Lk[(16 * q + c) * NB + r];
+    }
+    __syncthreads();
+    for (int l = s_blocks - 1; l >= 0; --l) {
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) s += lv[c] * bt[l * NB + 16 * q + c];
+        part[q][r] = s;
+        if (l > 0) {
+            const double *Lk = Linv + (int64_t)(l - 1) * NB * NB;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) lv[c] = Lk[(16 * q + c) * NB + r];
+        }
+        __syncthreads();
+        if (tid < NB) {
+            const double x = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+            xk[tid] = x;
+            out[base + l * NB + tid] = x;
+        }
+        __syncthreads();
+        const double *Ar = A + ((int64_t)l * NB + 16 * q) * ld;
+        for (int col = first[l] * NB + r; col < l * NB; col += NB) {
+            double u = 0.0;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) u += Ar[(int64_t)c * ld + col] * xk[16 * q + c];
+            atomicAdd(&bt[col], -u);
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace ba
 
 using namespace ba;
 
 // (the two clearing steps of a call, as kernels like everything else it queues)
 __global__ void k_zero_int(int *p) { *p = 0; }
+// The queued form assumed the profile `assumed`; the matrix has `now`.  Entries left of the assumed envelope would be
+// ignored: the verdict becomes PROFILE_MOVED before anything is factorised (the pivot check only replaces a zero).
+constexpr int PROFILE_MOVED = -0x7fffffff - 1;
+__global__ void k_profile_guard(const int *__restrict__ now, const int *__restrict__ assumed, int64_t nb, int *__restrict__ info) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < nb && now[k] < assumed[k]) *info = PROFILE_MOVED;
+}
+__global__ void k_publish_info(const int *__restrict__ info, int *__restrict__ host_word) {
+    __hip_atomic_store(host_word, *info, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __global__ void k_zero_doubles(double *__restrict__ p, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0.0;
 }
@@ -797,8 +941,42 @@ int ba_cholesky_solve(int64_t n, int64_t ld, double *S, double *rhs, int *h_info
     return ba_cholesky_solve_tracked(n, ld, S, rhs, nullptr, 0, h_info, stream);
 }
 
+static int solve_impl(int64_t n, int64_t ld, double *S, double *rhs, const int *block_first, int clear_on_return,
+                      int *h_info, void *stream, bool queued);
+
 int ba_cholesky_solve_tracked(int64_t n, int64_t ld, double *S, double *rhs, const int *block_first, int clear_on_return,
                               int *h_info, void *stream) {
+    return solve_impl(n, ld, S, rhs, block_first, clear_on_return, h_info, stream, false);
+}
+
+int ba_cholesky_solve_queued(int64_t n, int64_t ld, double *S, double *rhs, const int *block_first, int clear_on_return,
+                             void *stream) {
+    BA_REQUIRE(block_first, "ba_cholesky_solve_queued: block_first is required");
+    return solve_impl(n, ld, S, rhs, block_first, clear_on_return, nullptr, stream, true);
+}
+
+int ba_cholesky_queued_result(int *h_info) {
+    BA_REQUIRE(h_info, "ba_cholesky_queued_result: null pointer");
+    int device = 0;
+    BA_HIP(hipGetDevice(&device));
+    BA_REQUIRE(device >= 0 && device < 16, "ba_cholesky_solve: device number out of range");
+    CholCache &ws = g_chol_cache[device];
+    std::lock_guard<std::mutex> lock(ws.mu);
+    BA_REQUIRE(ws.result_host, "ba_cholesky_queued_result: no ba_cholesky_solve_queued call on this device yet");
+    const int v = *(volatile int *)ws.result_host;
+    if (v == PROFILE_MOVED) {
+        ws.lists_valid = false;     // the next call reads the profile again
+        *h_info = -1;
+    } else {
+        *h_info = v;
+    }
+    return BA_OK;
+}
+
+}  // extern "C"
+
+static int solve_impl(int64_t n, int64_t ld, double *S, double *rhs, const int *block_first, int clear_on_return,
+                      int *h_info, void *stream, bool queued) {
     BA_REQUIRE(S && rhs && n > 0 && ld >= n && ld % NB == 0, "ba_cholesky_solve: bad argument (ld must be a multiple of 64)");
     hipStream_t st = (hipStream_t)stream;
     const int64_t nb = ld / NB;
@@ -839,9 +1017,14 @@ int ba_cholesky_solve_tracked(int64_t n, int64_t ld, double *S, double *rhs, con
     std::vector<int> reach((size_t)nb), row_first((size_t)nb, 0);     // row_first[k]: first occupied column block of block row k
     for (int64_t k = 0; k < nb; ++k) reach[k] = (int)(nb - 1);
     std::vector<int> first;
+    bool assumed = false;
     if (e == hipSuccess && !getenv("BA_CHOL_DENSE") && border > 1) {
         first.resize((size_t)nb);
-        if (block_first) {      // the caller knows the profile (a lower bound of every row's first block will do)
+        if (queued && ws.lists_valid && ws.guard_valid && ws.n == n && ws.ld == ld && ws.clear == clear_on_return &&
+            ws.profile.size() == (size_t)nb) {
+            first = ws.profile;     // taken for granted, checked on the device (k_profile_guard): nothing to wait for
+            assumed = true;
+        } else if (block_first) {      // the caller knows the profile (a lower bound of every row's first block will do)
             e = hipMemcpyAsync(first.data(), block_first, sizeof(int) * nb, hipMemcpyDeviceToHost, st);
             if (e == hipSuccess) e = hipStreamSynchronize(st);
             for (int64_t k = 0; k < nb && e == hipSuccess; ++k)
@@ -895,7 +1078,7 @@ int ba_cholesky_solve_tracked(int64_t n, int64_t ld, double *S, double *rhs, con
     const int64_t S_rows = s_blocks * NB;                    // rows (and columns) of a chain
     const int64_t B0 = (int64_t)P * s_blocks;                // first block behind the chains (P > 1)
     const int64_t T0 = B0 + (int64_t)P * bw;                 // first block behind the separators
-    int *d_newpos = nullptr;
+    int *d_newpos = nullptr, *d_cfirst = nullptr;
     int4 *d_moves = nullptr;
     double *T = nullptr;
     std::vector<int> newpos;
@@ -918,7 +1101,8 @@ int ba_cholesky_solve_tracked(int64_t n, int64_t ld, double *S, double *rhs, con
         e = ws.grow(ws.moves, sizeof(int4) * moves.size());
         if (e == hipSuccess) e = ws.grow(ws.T, sizeof(double) * NB * NB * moves.size());
         if (e == hipSuccess) e = ws.grow(ws.newpos, sizeof(int) * nb);
-        d_moves = (int4 *)ws.moves.p, T = (double *)ws.T.p, d_newpos = (int *)ws.newpos.p;
+        if (e == hipSuccess) e = ws.grow(ws.cfirst, sizeof(int) * s_blocks);
+        d_moves = (int4 *)ws.moves.p, T = (double *)ws.T.p, d_newpos = (int *)ws.newpos.p, d_cfirst = (int *)ws.cfirst.p;
         // structure of a chain, over all chains: the first column block of local row l and from it the reach
         chain_first.assign((size_t)s_blocks, 0x7fffffff);
         for (int c = 0; c < P; ++c)
@@ -993,10 +1177,13 @@ int ba_cholesky_solve_tracked(int64_t n, int64_t ld, double *S, double *rhs, con
     }
     BA_HIP(e);
 
+    const int64_t split_limit = getenv("BA_CHOL_SPLIT_LIMIT") ? atoi(getenv("BA_CHOL_SPLIT_LIMIT")) : 256;
     // Everything the device does for this call, on stream q.
     auto issue = [&](hipStream_t q) -> hipError_t {
         hipError_t e = hipSuccess;
         hipLaunchKernelGGL(k_zero_int, dim3(1), dim3(1), 0, q, info);
+        if (assumed)
+            hipLaunchKernelGGL(k_profile_guard, dim3(cdiv_c(nb, 256)), dim3(256), 0, q, block_first, (const int *)ws.guard.p, nb, info);
         if (P > 1)
             for (int mode = 0; mode < 3; ++mode)
                 hipLaunchKernelGGL(k_move_blocks, dim3((unsigned)moves.size()), dim3(256), 0, q, S, ld, d_moves, T, mode);
@@ -1016,7 +1203,7 @@ int ba_cholesky_solve_tracked(int64_t n, int64_t ld, double *S, double *rhs, con
                 if (nct == 0) return;
                 const int64_t tiles = nct * (nct + 1) / 2 + (nt - nct) * nct;
                 int split = 1;      // workgroups per tile: as long as the launch stays within one round of the chip
-                while (tiles * n_chains * split * 2 <= 256 && kw % (split * 2 * NB) == 0) split *= 2;
+                while (tiles * n_chains * split * 2 <= split_limit && kw % (split * 2 * NB) == 0) split *= 2;
                 hipLaunchKernelGGL(k_syrk_trailing, dim3((unsigned)tiles, (unsigned)split, (unsigned)n_chains), dim3(256),
                                    lds_trailing, q, S, ld, k_first, (int)(kw / split), c0, nct, sel);
             };
@@ -1069,13 +1256,28 @@ int ba_cholesky_solve_tracked(int64_t n, int64_t ld, double *S, double *rhs, con
             e = hipMemcpyAsync(rhs, tmp, sizeof(double) * ld, hipMemcpyDeviceToDevice, q);
         }
         if (P > 1) {
-            for (int64_t k = nb - 1; k >= B0; --k)      // behind the chains: rows with entries in every chain
-                hipLaunchKernelGGL(k_solve_step, dim3(cdiv_c(k * NB, 256)), dim3(256), 0, q, S, ld, k * NB, Linv + k * NB * NB,
-                                   rhs, tmp, 1, (int64_t)0, (int64_t)0);
-            for (int64_t k = s_blocks - 1; k >= 0; --k) {       // block k of every chain
-                const int64_t i_begin = (int64_t)chain_first[k] * NB;
-                hipLaunchKernelGGL(k_solve_step, dim3(k * NB > i_begin ? cdiv_c(k * NB - i_begin, 256) : 1, P), dim3(256), 0, q,
-                                   S, ld, k * NB, Linv + k * NB * NB, rhs, tmp, 1, i_begin, S_rows);
+            // (see "backward solve ... in three launches" above; a launch per block step where a workgroup's LDS
+            // does not hold the right-hand side)
+            const bool step_by_step = getenv("BA_CHOL_BACK_STEPS") != nullptr;
+            if (nb - B0 <= BACK_TAIL_MAX_BLOCKS && !step_by_step) {
+                hipLaunchKernelGGL(k_back_tail, dim3(1), dim3(1024), sizeof(double) * NB * (nb - B0), q, S, ld, Linv, rhs, tmp,
+                                   B0, nb);
+                hipLaunchKernelGGL(k_back_tail_to_chains, dim3(cdiv_c(B0 * NB, 128), (unsigned)(nb - B0)), dim3(256), 0, q, S, ld,
+                                   tmp, rhs, B0, T0, bw, S_rows);
+            } else {
+                for (int64_t k = nb - 1; k >= B0; --k)      // behind the chains: rows with entries in every chain
+                    hipLaunchKernelGGL(k_solve_step, dim3(cdiv_c(k * NB, 256)), dim3(256), 0, q, S, ld, k * NB,
+                                       Linv + k * NB * NB, rhs, tmp, 1, (int64_t)0, (int64_t)0);
+            }
+            if (s_blocks <= BACK_CHAIN_MAX_BLOCKS && !step_by_step) {
+                hipLaunchKernelGGL(k_back_chains, dim3(P), dim3(256), sizeof(double) * NB * s_blocks, q, S, ld, Linv, rhs, tmp,
+                                   (int)s_blocks, d_cfirst);
+            } else {
+                for (int64_t k = s_blocks - 1; k >= 0; --k) {       // block k of every chain
+                    const int64_t i_begin = (int64_t)chain_first[k] * NB;
+                    hipLaunchKernelGGL(k_solve_step, dim3(k * NB > i_begin ? cdiv_c(k * NB - i_begin, 256) : 1, P), dim3(256), 0,
+                                       q, S, ld, k * NB, Linv + k * NB * NB, rhs, tmp, 1, i_begin, S_rows);
+                }
             }
             hipLaunchKernelGGL(k_solution_back, dim3(cdiv_c(ld, 256)), dim3(256), 0, q, tmp, ld, d_newpos, rhs);
         } else {
@@ -1105,14 +1307,32 @@ int ba_cholesky_solve_tracked(int64_t n, int64_t ld, double *S, double *rhs, con
         if (P > 1) {
             e = hipMemcpy(d_moves, moves.data(), sizeof(int4) * moves.size(), hipMemcpyHostToDevice);
             if (e == hipSuccess) e = hipMemcpy(d_newpos, newpos.data(), sizeof(int) * nb, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(d_cfirst, chain_first.data(), sizeof(int) * s_blocks, hipMemcpyHostToDevice);
         }
         if (e == hipSuccess && !runs.empty())
             e = hipMemcpy(d_runs, runs.data(), sizeof(int4) * runs.size(), hipMemcpyHostToDevice);
         BA_HIP(e);
-        ws.n = n, ws.ld = ld, ws.clear = clear_on_return, ws.profile = first, ws.lists_valid = true;
+        ws.n = n, ws.ld = ld, ws.clear = clear_on_return, ws.profile = first, ws.lists_valid = true, ws.guard_valid = false;
         ws.chains = P, ws.chain_blocks = s_blocks, ws.sep_blocks = bw;
     }
+    if (queued && !first.empty() && !ws.guard_valid) {      // the profile later queued calls are checked against
+        const bool valid = ws.lists_valid;
+        e = ws.grow(ws.guard, sizeof(int) * nb);        // (a buffer that grows invalidates the lists' flag: not these lists)
+        ws.lists_valid = valid;
+        if (e == hipSuccess) e = hipMemcpy(ws.guard.p, first.data(), sizeof(int) * nb, hipMemcpyHostToDevice);
+        BA_HIP(e);
+        ws.guard_valid = true;
+    }
+    if (queued && !ws.result_host) {
+        BA_HIP(hipHostMalloc((void **)&ws.result_host, 64, hipHostMallocMapped));
+        BA_HIP(hipHostGetDevicePointer((void **)&ws.result_dev, ws.result_host, 0));
+    }
     e = issue(st);
+    if (queued && e == hipSuccess) {
+        hipLaunchKernelGGL(k_publish_info, dim3(1), dim3(1), 0, st, info, ws.result_dev);
+        BA_HIP(hipGetLastError());
+        return BA_OK;
+    }
     if (e == hipSuccess) e = hipGetLastError();
     int hinfo = 0;
     if (e == hipSuccess) e = hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, st);
@@ -1125,5 +1345,3 @@ int ba_cholesky_solve_tracked(int64_t n, int64_t ld, double *S, double *rhs, con
     }
     return BA_OK;
 }
-
-}  // extern "C"

@@ -461,6 +461,16 @@ __global__ void __launch_bounds__(256) k_jtj_finalize(int64_t K, int n_partials,
     }
 }
 
+// The block profile of the reduced system before any point has contributed: every row starts at its own camera's
+// first column (a camera's six unknowns can lie across a block boundary), the row of phi_x at column 0, padding
+// rows on the diagonal.
+__device__ __forceinline__ int schur_first_of_block(int64_t ib, int64_t K) {
+    const int64_t row = 64 * ib;
+    if (row > 6 * K) return (int)ib;
+    if (row + 63 >= 6 * K) return 0;
+    return (int)((6 * (row / 6)) / 64);
+}
+
 // --------------------------------------------------------------------------------------------
 // K4: Schur complement onto the cameras.  S starts as the damped camera / phi blocks; every point
 // subtracts Y^T V'^-1 Y, where Y holds its 3x6 cross blocks W_ij and its 3x1 phi column.
@@ -468,8 +478,10 @@ __global__ void __launch_bounds__(256) k_jtj_finalize(int64_t K, int n_partials,
 __global__ void k_schur_init(int64_t K, int64_t n, int64_t ld, double lambda, const double *__restrict__ B,
                              const double *__restrict__ bphi, const double *__restrict__ hphi,
                              const double *__restrict__ gC, const double *__restrict__ gTheta,
-                             const double *__restrict__ gphi, double *__restrict__ S, double *__restrict__ rhs) {
+                             const double *__restrict__ gphi, double *__restrict__ S, double *__restrict__ rhs,
+                             int *__restrict__ first) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (first && j < ld / 64) first[j] = schur_first_of_block(j, K);       // (ld / 64 <= K: the grid covers it)
     if (j < K) {
         int idx = 0;
         for (int p = 0; p < 6; ++p)
@@ -552,16 +564,10 @@ __host__ __device__ inline size_t schur_tile_lds_doubles(int cam_cap, int max_de
            (size_t)waves * (max_deg + (max_deg < 10 ? max_deg : 10)) * 37 + (size_t)(cam_cap + 1) / 2;
 }
 
-// The block profile of the reduced system before any point has contributed: every row starts at its own camera's
-// first column (a camera's six unknowns can lie across a block boundary), the row of phi_x at column 0, padding
-// rows on the diagonal.
+// (the profile's starting values, for a rank that does not write the camera blocks: k_schur_init does it otherwise)
 __global__ void k_schur_first_init(int *__restrict__ first, int64_t nb, int64_t K) {
     const int64_t ib = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (ib >= nb) return;
-    const int64_t row = 64 * ib;
-    if (row > 6 * K) first[ib] = (int)ib;
-    else if (row + 63 >= 6 * K) first[ib] = 0;
-    else first[ib] = (int)((6 * (row / 6)) / 64);
+    if (ib < nb) first[ib] = schur_first_of_block(ib, K);
 }
 
 // rows of camera jr have an entry in the columns of camera jc <= jr
@@ -1718,13 +1724,14 @@ int ba_schur_build_tracked(ba_problem *p, const double *X, double lambda, const 
         return BA_ERR_ARG;
     }
     if (!S_is_zero) BA_HIP(hipMemsetAsync(S, 0, sizeof(double) * ld * ld, st));
-    if (block_first)
-        hipLaunchKernelGGL(k_schur_first_init, dim3(cdiv_i(ld / 64, 256)), dim3(256), 0, st, block_first, ld / 64, p->K);
-    if (with_camera_blocks)
-        hipLaunchKernelGGL(k_schur_init, dim3(cdiv_i(p->K, 256)), dim3(256), 0, st, p->K, n, ld, lambda, B, bphi, hphi,
-                           gC, gTheta, gphi, S, rhs);
-    else
+    if (with_camera_blocks) {
+        hipLaunchKernelGGL(k_schur_init, dim3(cdiv_i(std::max<int64_t>(p->K, ld / 64), 256)), dim3(256), 0, st, p->K, n, ld,
+                           lambda, B, bphi, hphi, gC, gTheta, gphi, S, rhs, block_first);
+    } else {
+        if (block_first)
+            hipLaunchKernelGGL(k_schur_first_init, dim3(cdiv_i(ld / 64, 256)), dim3(256), 0, st, block_first, ld / 64, p->K);
         BA_HIP(hipMemsetAsync(rhs, 0, sizeof(double) * ld, st));
+    }
     if (use_tile) {
         SchurTileArgs ta;
         ta.opack = p->opack;
@@ -1767,6 +1774,8 @@ int ba_schur_build_tracked(ba_problem *p, const double *X, double lambda, const 
                     BA_HIP(hipEventCreateWithFlags(&p->aux_fork, hipEventDisableTiming));
                     BA_HIP(hipEventCreateWithFlags(&p->aux_join, hipEventDisableTiming));
                 }
+                // (launched BEFORE the long kernel: behind it, its workgroups - a CU's whole LDS each - get no CU
+                // until the other launch has drained, 0.14 ms later at 2 000 cameras)
                 BA_HIP(hipEventRecord(p->aux_fork, st));
                 BA_HIP(hipStreamWaitEvent(p->aux_stream, p->aux_fork, 0));
                 SchurTileArgs tr = ta;

@@ -681,9 +681,23 @@ class Shard:
             self._sum_over_ranks(self.red)
             self._sum_over_ranks(self.jred)
 
-    def lm_step(self, lam, on_system=None, trial=False):
+    def lm_pivot(self):
+        """Verdict of the last lm_step(wait=False), once the stream has been waited for (an energy read-back does):
+        0, or 1 + index of the first non-positive pivot (the step and the trial point are void), or -1: the block
+        profile of S changed (void as well; S is cleared and the next step reads the profile again)."""
+        info = C.c_int(0)
+        with torch.cuda.device(self.device):
+            check(self.lib.ba_cholesky_queued_result(C.byref(info)))
+        if info.value == -1:
+            self.S.zero_()
+        return int(info.value)
+
+    def lm_step(self, lam, on_system=None, trial=False, wait=True):
         """Solve the damped normal equations (J^T J + lam diag) d = -J^T r by Schur complement and
         dense Cholesky; leaves dX and dcam = [dC | dTheta | dphi].  Returns the pivot info (0 = ok).
+        wait=False (one GPU): nothing waits for the device - the profile of S is taken from the previous step, the
+        back-substitution is queued whatever the factorisation finds, 0 is returned, and the verdict is read later
+        with lm_pivot().
         trial: the back-substitution also leaves the trial point in new tensors X_trial = X + dX and
         cam_trial = cam + dcam (the current parameters are not touched).
         With several GPUs every rank adds its points' part of S and rhs, the sums go over the
@@ -714,8 +728,12 @@ class Shard:
         mark()
         if on_system is not None:
             on_system(self.S, self.rhs)
-        status = self.lib.ba_cholesky_solve_tracked(self.n_red, self.ld_red, ptr(self.S), ptr(self.rhs), ptr(self.S_first),
-                                                    1, C.byref(info), self.stream)
+        if not wait and not self.distributed:
+            status = self.lib.ba_cholesky_solve_queued(self.n_red, self.ld_red, ptr(self.S), ptr(self.rhs), ptr(self.S_first),
+                                                       1, self.stream)
+        else:
+            status = self.lib.ba_cholesky_solve_tracked(self.n_red, self.ld_red, ptr(self.S), ptr(self.rhs),
+                                                        ptr(self.S_first), 1, C.byref(info), self.stream)
         self._S_is_zero = status in (0, -4)     # the solver ran to its end and cleared S
         mark()
         if self.distributed:

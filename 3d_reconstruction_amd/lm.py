@@ -62,7 +62,10 @@ class LMFit:
             if self.lam > self.lam_max:
                 self.print(f'{it} : Reached maximum damping')
                 break
-            if sh.lm_step(self.lam, trial=True) != 0:          # not positive definite at this damping
+            # One GPU: the step is queued without waiting for the factorisation's verdict, which is read after the
+            # trial point's energy has been waited for anyway (a failed factorisation leaves a void trial point).
+            queued = not sh.distributed
+            if sh.lm_step(self.lam, trial=True, wait=not queued) != 0:          # not positive definite at this damping
                 self.lam *= self.lam_up
                 continue
             kept = sh.snapshot()
@@ -71,6 +74,14 @@ class LMFit:
             sh.swap_evaluation()
             sh.eval_jtj()
             E_new = sh.energy()
+            pivot = sh.lm_pivot() if queued else 0
+            if pivot != 0:
+                sh.restore(kept)
+                sh.swap_evaluation()
+                sh.rebuild_table()
+                if pivot > 0:
+                    self.lam *= self.lam_up
+                continue
             self.stamps.append(time.perf_counter())
             it += 1
             if np.isfinite(E_new) and E_new < E:

@@ -340,6 +340,19 @@ int ba_schur_build_tracked(ba_problem *p, const double *X, double lambda, const 
                            double *S, double *rhs, int *block_first, int S_is_zero, void *stream);
 int ba_cholesky_solve_tracked(int64_t n, int64_t ld, double *S, double *rhs, const int *block_first,
                               int clear_on_return, int *h_info, void *stream);
+/* The same solve for a loop whose systems all have ONE block profile (an LM loop on one scene), without the two
+ * waits of the call above (for the profile before, for the pivot verdict after): everything is queued on `stream`
+ * and the call returns.  The first call on a device (and the first after n, ld or clear_on_return changed, or after
+ * a verdict of -1) reads block_first and waits for it once; later calls take that profile for granted and a kernel
+ * compares block_first with it before anything is factorised.
+ * ba_cholesky_queued_result: the verdict of the last queued call on the current device, to be called once `stream`
+ *   has been waited for by any means (the verdict travels through a word of mapped host memory, nothing is copied
+ *   or waited for here): *h_info = 0, or 1 + index of the first non-positive pivot, or -1: a row of S started left
+ *   of the assumed profile - S and rhs are then undefined, S must be cleared and built again, and the next queued
+ *   call reads the profile afresh.  Calls on one device share a workspace: queue them on one stream. */
+int ba_cholesky_solve_queued(int64_t n, int64_t ld, double *S, double *rhs, const int *block_first,
+                             int clear_on_return, void *stream);
+int ba_cholesky_queued_result(int *h_info);
 int ba_backsubstitute(ba_problem *p, const double *X, double lambda, const double *V, const double *Xphi,
                       const double *gX, const double *d, double *dcam_packed, double *dX, const double *cam,
                       double *X_trial, double *cam_trial, void *stream);

@@ -247,6 +247,69 @@ def test_cholesky_switch_order_does_not_reuse_stale_lists(ba, clear):
             assert float(Sd.abs().max()) == 0.0, switch
 
 
+def test_queued_cholesky_takes_the_last_profile_and_notices_when_it_moved(ba):
+    """ba_cholesky_solve_queued waits for nothing after its first call: the verdict (ba_cholesky_queued_result) is 0
+    with the right solution while the profile stays; a pivot index for a matrix that is not positive definite; -1 when
+    a row starts left of the assumed profile, after which the next call reads the profile again and solves."""
+    lib = ba.engine._lib.load()
+    import ctypes as C
+    rng = np.random.default_rng(11)
+    n = 9000
+    ld = (n + 63) // 64 * 64
+    nb = ld // 64
+
+    def system(bw):
+        S = np.zeros((n, n))
+        for d in range(1, bw + 1):
+            S[np.arange(d, n), np.arange(n - d)] = rng.normal(size=n - d)
+        S[n - 1, :n - 1] = rng.normal(size=n - 1)
+        S = S + S.T
+        S[np.diag_indices(n)] = np.abs(S).sum(axis=1) + 1.0
+        Sp = np.zeros((ld, ld))
+        Sp[:n, :n] = np.tril(S)
+        Sp[np.arange(n, ld), np.arange(n, ld)] = 1.0
+        first = np.array([max(0, (64 * ib - bw) // 64) for ib in range(nb)], dtype=np.int32)
+        first[(n - 1) // 64:] = 0
+        return S, Sp, torch.from_numpy(first).to(DEV)
+
+    def solve(Sp, first_d, b):
+        Sd = torch.from_numpy(Sp).to(DEV)
+        bd = torch.zeros(ld, dtype=torch.float64, device=DEV)
+        bd[:n] = torch.from_numpy(b)
+        ba.engine.check(lib.ba_cholesky_solve_queued(n, ld, C.c_void_p(Sd.data_ptr()), C.c_void_p(bd.data_ptr()),
+                                                     C.c_void_p(first_d.data_ptr()), 1, None))
+        torch.cuda.synchronize()
+        info = C.c_int(7)
+        ba.engine.check(lib.ba_cholesky_queued_result(C.byref(info)))
+        return info.value, bd.cpu().numpy()[:n], Sd
+
+    S1, Sp1, f1 = system(50)
+    S2, Sp2, f2 = system(50)            # other values, the same profile
+    S3, Sp3, f3 = system(150)           # rows that start two blocks further left
+    for S, Sp in ((S1, Sp1), (S2, Sp2), (S1, Sp1)):
+        b = rng.normal(size=n)
+        verdict, x, Sd = solve(Sp, f1, b)
+        assert verdict == 0
+        assert rel_err(x, np.linalg.solve(S, b)) < 1e-10
+        assert float(Sd.abs().max()) == 0.0
+    bad = Sp2.copy()
+    bad[4000, 4000] = -1.0
+    verdict, _, _ = solve(bad, f1, rng.normal(size=n))
+    assert verdict > 0
+    b = rng.normal(size=n)
+    verdict, _, _ = solve(Sp3, f3, b)
+    assert verdict == -1
+    verdict, x, Sd = solve(Sp3, f3, b)
+    assert verdict == 0
+    assert rel_err(x, np.linalg.solve(S3, b)) < 1e-10
+    assert float(Sd.abs().max()) == 0.0
+    # a narrower profile than the assumed one is fine (the assumed one is a lower bound)
+    b = rng.normal(size=n)
+    verdict, x, _ = solve(Sp1, f1, b)
+    assert verdict == 0
+    assert rel_err(x, np.linalg.solve(S1, b)) < 1e-10
+
+
 def test_tracked_build_and_solve_keep_S_clean(ba):
     """The pair of entry points an LM loop uses: the Schur build reports the block profile of S (a lower bound of every
     block row's first occupied block, exact here), the solver takes it instead of reading S, gives the solution of the
