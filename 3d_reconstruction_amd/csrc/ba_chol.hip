@@ -47,6 +47,15 @@
 // instead of 188 (9.1 -> 2.1 ms); n = 120 001: 5.5 ms.  The right-hand side enters and the solution leaves in the
 // caller's order (k_rhs_into_row, k_solution_back).  BA_CHOL_NO_CHAINS=1 keeps the natural order.
 //
+// Levels.  What is behind the chains is again a band with a border: a separator is coupled to its two neighbours only
+// (through the chain between them), the border stays the border.  Its block profile follows from the matrix's by
+// symbolic elimination on the host, and it is cut into chains of its own - a second symmetric reordering, of the
+// matrix behind the first level's chains only, done on the device when the first level's chains are finished - and
+// so on while a level saves four block steps or more (BA_CHOL_LEVELS=1: one level).  n = 12 001: 14 x 12, then 3 x 4
+// of the 14 separators, 8 blocks behind them: 24 dependent steps; n = 120 001: 48 x 38, then 5 x 8: 58 steps
+// instead of 90.  The backward solve walks the levels from the inside out (k_back_tail, then per level
+// k_back_tail_to_chains and k_back_chains).
+//
 #include "ba_device.h"
 
 #include <stdlib.h>
@@ -70,12 +79,13 @@ struct CholCache {
         size_t bytes = 0;
     };
     std::mutex mu;
-    Buf linv, tmp, info, newpos, moves, T, runs, first, cfirst, guard;
+    Buf linv, tmp, info, newpos, moves, T, runs, first, guard;
     // what the lists in `newpos`, `moves` and `runs` were built for
     bool lists_valid = false;
     bool guard_valid = false;       // `guard` holds `profile` (the queued form compares the caller's profile with it)
     int *result_host = nullptr, *result_dev = nullptr;      // one word of mapped host memory: verdict of the queued form
-    int64_t n = 0, ld = 0, chains = 0, chain_blocks = 0, sep_blocks = 0;
+    int64_t n = 0, ld = 0;
+    std::vector<int64_t> split;     // (first block, chains, blocks of a chain, blocks of a separator) of every level
     int clear = 0;
     std::vector<int> profile;
     hipError_t grow(Buf &b, size_t bytes) {
@@ -782,14 +792,15 @@ __global__ void __launch_bounds__(256) k_solve_step(const double *__restrict__ A
 // dense triangle that ONE workgroup walks through with the right-hand side in LDS (k_back_tail); its effect on the
 // chains' unknowns is one product over the whole chip (k_back_tail_to_chains); then every chain is walked by a
 // workgroup of its own (k_back_chains).
-constexpr int BACK_TAIL_MAX_BLOCKS = 48;      // tail blocks one workgroup takes (right-hand side: 24 KB of LDS)
+constexpr int BACK_TAIL_MAX_BLOCKS = 96;      // tail blocks one workgroup takes (right-hand side: 48 KB of LDS)
 constexpr int BACK_CHAIN_MAX_BLOCKS = 96;     // blocks of a chain (48 KB of LDS)
 
 // x_k = Linv_k^T b_k for k = nb - 1 .. B0, b_i -= L_ki^T x_k for the tail's rows i before k; x -> out.
+// tfirst[k - B0]: the first block (counted from B0) of block row k of L that holds anything.
 // One workgroup of 1024 threads; dynamic LDS: (nb - B0) * 64 doubles.
 __global__ void __launch_bounds__(1024) k_back_tail(const double *__restrict__ A, int64_t ld, const double *__restrict__ Linv,
                                                      const double *__restrict__ b, double *__restrict__ out, int64_t B0,
-                                                     int64_t nb) {
+                                                     int64_t nb, const int *__restrict__ tfirst) {
     extern __shared__ double bt[];
     __shared__ double xk[NB], part[16][NB + 1];
     const int tid = threadIdx.x;
@@ -827,7 +838,7 @@ __global__ void __launch_bounds__(1024) k_back_tail(const double *__restrict__ A
         // rows k0 .. k0 + 63 of L, columns base .. k0: thread (column tid & 255 of a pass of 256, rows 16 (tid >> 8) ..)
         const int cg = tid & 255, rg = tid >> 8;
         const double *Ar = A + (k * NB + 16 * rg) * ld + base;
-        for (int col = cg; col < lk; col += 256) {
+        for (int col = tfirst[k - B0] * NB + cg; col < lk; col += 256) {       // (L has nothing left of the row's first block)
             double u = 0.0;
 #pragma unroll
             for (int c = 0; c < 16; ++c) u += Ar[(int64_t)c * ld + col] * xk[16 * rg + c];
@@ -837,38 +848,41 @@ __global__ void __launch_bounds__(1024) k_back_tail(const double *__restrict__ A
     }
 }
 
-// b_i -= sum over the tail's rows of L_ri x_r for the chains' unknowns i.  Workgroup (slab of 128 columns, tail block):
-// a separator's rows hold entries in the columns of the chains on either side of it only.
+// b_i -= sum over the rows r behind a level's chains of L_ri x_r, for the unknowns i of the chains (columns from c_base
+// on; rows from block B0 on, separators up to block T0).  Workgroup (slab of 128 columns, block row): a separator's rows
+// hold entries in the columns of the chains on either side of it only.  rowpos (or null): where in x the solution of
+// block row B0 + y stands (a further level behind these chains has reordered those rows).
 __global__ void __launch_bounds__(256) k_back_tail_to_chains(const double *__restrict__ A, int64_t ld, const double *__restrict__ x,
-                                                             double *__restrict__ b, int64_t B0, int64_t T0, int64_t bw,
-                                                             int64_t chain_rows) {
+                                                             double *__restrict__ b, int64_t c_base, int64_t B0, int64_t T0,
+                                                             int64_t bw, int64_t chain_rows, const int *__restrict__ rowpos) {
     __shared__ double xs[NB];
     const int tid = threadIdx.x;
-    const int64_t k = B0 + blockIdx.y, col0 = (int64_t)blockIdx.x * 128;
+    const int64_t k = B0 + blockIdx.y, col0 = (int64_t)blockIdx.x * 128;       // col0: counted from c_base
     if (k < T0) {
         const int64_t sep = (k - B0) / bw, c_first = col0 / chain_rows, c_last = (col0 + 127) / chain_rows;
         if (c_last < sep || c_first > sep + 1) return;
     }
-    if (tid < NB) xs[tid] = x[k * NB + tid];
+    const int64_t xrow = rowpos ? rowpos[blockIdx.y] : k;
+    if (tid < NB) xs[tid] = x[xrow * NB + tid];
     __syncthreads();
     const int col = tid & 127, half = tid >> 7;
-    if (col0 + col >= B0 * NB) return;
-    const double *Ar = A + (k * NB + 32 * half) * ld + col0 + col;
+    if (c_base + col0 + col >= B0 * NB) return;
+    const double *Ar = A + (k * NB + 32 * half) * ld + c_base + col0 + col;
     double u = 0.0;
 #pragma unroll 16
     for (int c = 0; c < 32; ++c) u += Ar[(int64_t)c * ld] * xs[32 * half + c];
-    atomicAdd(b + col0 + col, -u);
+    atomicAdd(b + c_base + col0 + col, -u);
 }
 
-// Chain blockIdx.x: x_l = Linv_l^T b_l for its blocks l = s_blocks - 1 .. 0, b_i -= L_li^T x_l for the chain's rows
-// from block first[l] on.  256 threads; dynamic LDS: s_blocks * 64 doubles.
+// Chain blockIdx.x of the chains that start at block `off`: x_l = Linv_l^T b_l for its blocks l = s_blocks - 1 .. 0,
+// b_i -= L_li^T x_l for the chain's rows from block first[l] on.  256 threads; dynamic LDS: s_blocks * 64 doubles.
 __global__ void __launch_bounds__(256) k_back_chains(const double *__restrict__ A, int64_t ld, const double *__restrict__ Linv,
-                                                      const double *__restrict__ b, double *__restrict__ out, int s_blocks,
-                                                      const int *__restrict__ first) {
+                                                      const double *__restrict__ b, double *__restrict__ out, int64_t off,
+                                                      int s_blocks, const int *__restrict__ first) {
     extern __shared__ double bt[];
     __shared__ double xk[NB], part[4][NB + 1];
     const int tid = threadIdx.x;
-    const int64_t base = (int64_t)blockIdx.x * s_blocks * NB;
+    const int64_t base = (off + (int64_t)blockIdx.x * s_blocks) * NB;
     A += base * ld + base;
     Linv += base * NB;
     for (int idx = tid; idx < s_blocks * NB; idx += 256) bt[idx] = b[base + idx];
@@ -953,6 +967,19 @@ int ba_cholesky_solve_queued(int64_t n, int64_t ld, double *S, double *rhs, cons
                              void *stream) {
     BA_REQUIRE(block_first, "ba_cholesky_solve_queued: block_first is required");
     return solve_impl(n, ld, S, rhs, block_first, clear_on_return, nullptr, stream, true);
+}
+
+int ba_cholesky_last_plan(int64_t *levels, int capacity, int *n_levels) {
+    BA_REQUIRE(n_levels && (levels || capacity == 0), "ba_cholesky_last_plan: null pointer");
+    int device = 0;
+    BA_HIP(hipGetDevice(&device));
+    BA_REQUIRE(device >= 0 && device < 16, "ba_cholesky_solve: device number out of range");
+    CholCache &ws = g_chol_cache[device];
+    std::lock_guard<std::mutex> lock(ws.mu);
+    *n_levels = ws.lists_valid ? (int)(ws.split.size() / 4) : 0;
+    for (int k = 0; k < *n_levels && k < capacity; ++k)
+        for (int c = 0; c < 4; ++c) levels[4 * k + c] = ws.split[4 * k + c];
+    return BA_OK;
 }
 
 int ba_cholesky_queued_result(int *h_info) {
@@ -1059,66 +1086,131 @@ static int solve_impl(int64_t n, int64_t ld, double *S, double *rhs, const int *
         }
     }
 
-    // ---- independent chains (see the top of the file): P chains of s blocks, a separator of bw blocks behind each,
-    // what is left of the band, the border.  Chosen to make the number of dependent block steps, s + (blocks
-    // behind the chains), small.
-    int P = 1;
-    int64_t s_blocks = 0, bw = 1;
+    // ---- independent chains (see the top of the file), level by level: P chains of s blocks, a separator of bw blocks
+    // behind each, what is left of the band, the border; what lies behind the chains of a level is a banded matrix with
+    // a border again (its band: the separators, coupled to their neighbours through the chains between them) and is
+    // cut the same way.  Every level's matrix is a suffix of the reordered matrix.
+    struct Level {
+        int64_t off = 0;            // first block of the level's matrix
+        int P = 1;
+        int64_t s = 0, bw = 1;      // blocks of a chain, of a separator
+        int64_t B0 = 0, T0 = 0;     // counted from off: first block behind the chains, behind the separators
+        std::vector<int> chain_first, chain_reach;      // per block of a chain: first column and reach, over all chains
+        std::vector<int> newpos;    // position (counted from off) of the level's block ib in the level's order
+        size_t moves_at = 0, moves_n = 0, cfirst_at = 0, rowpos_at = 0;
+    };
+    std::vector<Level> levels;
+    std::vector<int4> moves;
+    std::vector<int> tail_first;    // profile of what lies behind the last level's chains, counted from its first block
+    const int max_levels = getenv("BA_CHOL_LEVELS") ? atoi(getenv("BA_CHOL_LEVELS")) : 3;
     if (!first.empty() && ride_along && !getenv("BA_CHOL_NO_CHAINS")) {
-        for (int64_t ib = 0; ib < border; ++ib) bw = std::max<int64_t>(bw, ib - first[ib]);
-        int64_t best = nb - nb / 3;       // worth it from a third fewer steps on
-        for (int cand = 2; cand <= 96; ++cand) {
-            int64_t sc = (border - (int64_t)cand * bw) / cand;
-            sc -= sc & 1;       // chains start on even blocks: the 128-row tiles of the update never straddle two chains
-            if (sc < 4 * bw || sc < 4) break;
-            const int64_t steps = sc + (nb - cand * sc);
-            if (steps < best) best = steps, P = cand, s_blocks = sc;
+        std::vector<int> cur = first;       // profile of the current level's matrix, blocks counted from its start
+        int64_t cur_nb = nb, cur_border = border, cur_off = 0;
+        while ((int)levels.size() < max_levels && cur_border > 8) {
+            Level L;
+            L.off = cur_off;
+            for (int64_t ib = 0; ib < cur_border; ++ib) L.bw = std::max<int64_t>(L.bw, ib - cur[ib]);
+            // worth it from a third fewer steps on (a further level: from four steps on - it costs the launches of its
+            // block moves and of its part of the backward solve)
+            int64_t best = levels.empty() ? cur_nb - cur_nb / 3 : cur_nb - 4;
+            for (int cand = 2; cand <= 96; ++cand) {
+                int64_t sc = (cur_border - (int64_t)cand * L.bw) / cand;
+                sc -= sc & 1;       // chains start on even blocks: the 128-row tiles of the update never straddle two chains
+                if (sc < 4 * L.bw || sc < 4) break;
+                const int64_t steps = sc + (cur_nb - cand * sc);
+                if (steps < best) best = steps, L.P = cand, L.s = sc;
+            }
+            if (L.P == 1) break;
+            L.B0 = (int64_t)L.P * L.s;
+            L.T0 = L.B0 + (int64_t)L.P * L.bw;
+            L.newpos.resize((size_t)cur_nb);
+            for (int64_t ib = 0; ib < cur_nb; ++ib) {
+                const int64_t c = ib / (L.s + L.bw), l = ib % (L.s + L.bw);
+                if (c >= L.P) L.newpos[ib] = (int)ib;                                   // rest of the band, border: where they were
+                else if (l < L.s) L.newpos[ib] = (int)(c * L.s + l);
+                else L.newpos[ib] = (int)(L.B0 + c * L.bw + (l - L.s));
+            }
+            // the occupied blocks (from the profile), gathered, cleared, stored at their new places (k_move_blocks, below)
+            L.moves_at = moves.size();
+            for (int64_t ib = 0; ib < cur_nb; ++ib)
+                for (int64_t jb = cur[ib]; jb <= ib; ++jb) {
+                    const int from_r = (int)(L.off + ib), from_c = (int)(L.off + jb);
+                    const int a = (int)(L.off + L.newpos[ib]), bcol = (int)(L.off + L.newpos[jb]);
+                    moves.push_back(a >= bcol ? make_int4(from_r, from_c, a, bcol) : make_int4(from_r, from_c, -bcol - 1, a));
+                }
+            L.moves_n = moves.size() - L.moves_at;
+            // structure of a chain, over all chains: the first column block of local row l and from it the reach
+            L.chain_first.assign((size_t)L.s, 0x7fffffff);
+            for (int c = 0; c < L.P; ++c)
+                for (int64_t l = 0; l < L.s; ++l) {
+                    const int64_t old_start = c * (L.s + L.bw);
+                    L.chain_first[l] = std::min(L.chain_first[l], (int)std::max<int64_t>(cur[old_start + l] - old_start, 0));
+                }
+            std::vector<int> last((size_t)L.s, -1);
+            for (int64_t l = 0; l < L.s; ++l) last[L.chain_first[l]] = (int)l;
+            L.chain_reach.resize((size_t)L.s);
+            int far = 0;
+            for (int64_t k = 0; k < L.s; ++k) {
+                far = std::max(far, std::max(last[k], (int)k));
+                L.chain_reach[k] = far;
+            }
+            // Profile of what lies behind the chains once they are eliminated (blocks counted from B0): the entries
+            // the matrix has there, the fill among the rows that hold entries in one and the same chain, and the fill
+            // of the factorisation itself (symbolic elimination on the block pattern).
+            const int64_t nt = cur_nb - L.B0;
+            std::vector<std::vector<char>> pat((size_t)nt, std::vector<char>((size_t)nt, 0)),
+                touch((size_t)L.P, std::vector<char>((size_t)nt, 0));
+            for (int64_t ib = 0; ib < cur_nb; ++ib) {
+                const int64_t a = L.newpos[ib];
+                for (int64_t jb = cur[ib]; jb <= ib; ++jb) {
+                    const int64_t bcol = L.newpos[jb];
+                    if (a >= L.B0 && bcol >= L.B0) pat[std::max(a, bcol) - L.B0][std::min(a, bcol) - L.B0] = 1;
+                    else if (a >= L.B0) touch[bcol / L.s][a - L.B0] = 1;
+                    else if (bcol >= L.B0) touch[a / L.s][bcol - L.B0] = 1;
+                }
+            }
+            std::vector<int> rows;
+            for (int c = 0; c < L.P; ++c) {
+                rows.clear();
+                for (int64_t t = 0; t < nt; ++t)
+                    if (touch[c][t]) rows.push_back((int)t);
+                for (size_t x = 0; x < rows.size(); ++x)
+                    for (size_t y = 0; y <= x; ++y) pat[rows[x]][rows[y]] = 1;
+            }
+            for (int64_t k = 0; k < nt; ++k) {
+                pat[k][k] = 1;
+                rows.clear();
+                for (int64_t i = k + 1; i < nt; ++i)
+                    if (pat[i][k]) rows.push_back((int)i);
+                for (size_t x = 0; x < rows.size(); ++x)
+                    for (size_t y = 0; y <= x; ++y) pat[rows[x]][rows[y]] = 1;
+            }
+            std::vector<int> next((size_t)nt);
+            for (int64_t t = 0; t < nt; ++t) {
+                int64_t j = 0;
+                while (!pat[t][j]) ++j;
+                next[t] = (int)j;
+            }
+            // its border: the level's border, and before it the rows that reach far further back than the typical one
+            int64_t next_border = std::max<int64_t>(cur_border - L.B0, 0);
+            if (next_border > 2) {
+                std::vector<int> width((size_t)next_border);
+                for (int64_t ib = 0; ib < next_border; ++ib) width[ib] = (int)ib - next[ib];
+                std::nth_element(width.begin(), width.begin() + next_border / 2, width.end());
+                const int typical = width[next_border / 2];
+                while (next_border > 2 && (next_border - 1) - next[next_border - 1] > 4 * typical + 4) --next_border;
+            }
+            cur_off += L.B0;
+            cur_nb = nt;
+            cur_border = next_border;
+            cur = next;
+            tail_first = next;
+            levels.push_back(std::move(L));
         }
     }
-    const int64_t S_rows = s_blocks * NB;                    // rows (and columns) of a chain
-    const int64_t B0 = (int64_t)P * s_blocks;                // first block behind the chains (P > 1)
-    const int64_t T0 = B0 + (int64_t)P * bw;                 // first block behind the separators
-    int *d_newpos = nullptr, *d_cfirst = nullptr;
-    int4 *d_moves = nullptr;
-    double *T = nullptr;
-    std::vector<int> newpos;
-    std::vector<int4> moves;
-    std::vector<int> chain_reach, chain_first;               // per block of a chain: reach and first column, over all chains
-    if (P > 1 && e == hipSuccess) {
-        newpos.resize((size_t)nb);
-        for (int64_t ib = 0; ib < nb; ++ib) {
-            const int64_t c = ib / (s_blocks + bw), l = ib % (s_blocks + bw);
-            if (c >= P) newpos[ib] = (int)ib;                                   // rest of the band, border: where they were
-            else if (l < s_blocks) newpos[ib] = (int)(c * s_blocks + l);
-            else newpos[ib] = (int)(B0 + c * bw + (l - s_blocks));
-        }
-        // the occupied blocks (from the profile), gathered, cleared, stored at their new places (k_move_blocks, below)
-        for (int64_t ib = 0; ib < nb; ++ib)
-            for (int64_t jb = first[ib]; jb <= ib; ++jb) {
-                const int a = newpos[ib], bcol = newpos[jb];
-                moves.push_back(a >= bcol ? make_int4((int)ib, (int)jb, a, bcol) : make_int4((int)ib, (int)jb, -bcol - 1, a));
-            }
-        e = ws.grow(ws.moves, sizeof(int4) * moves.size());
-        if (e == hipSuccess) e = ws.grow(ws.T, sizeof(double) * NB * NB * moves.size());
-        if (e == hipSuccess) e = ws.grow(ws.newpos, sizeof(int) * nb);
-        if (e == hipSuccess) e = ws.grow(ws.cfirst, sizeof(int) * s_blocks);
-        d_moves = (int4 *)ws.moves.p, T = (double *)ws.T.p, d_newpos = (int *)ws.newpos.p, d_cfirst = (int *)ws.cfirst.p;
-        // structure of a chain, over all chains: the first column block of local row l and from it the reach
-        chain_first.assign((size_t)s_blocks, 0x7fffffff);
-        for (int c = 0; c < P; ++c)
-            for (int64_t l = 0; l < s_blocks; ++l) {
-                const int64_t old_start = c * (s_blocks + bw);
-                chain_first[l] = std::min(chain_first[l], (int)std::max<int64_t>(first[old_start + l] - old_start, 0));
-            }
-        std::vector<int> last((size_t)s_blocks, -1);
-        for (int64_t l = 0; l < s_blocks; ++l) last[chain_first[l]] = (int)l;
-        chain_reach.resize((size_t)s_blocks);
-        int far = 0;
-        for (int64_t k = 0; k < s_blocks; ++k) {
-            far = std::max(far, std::max(last[k], (int)k));
-            chain_reach[k] = far;
-        }
-    } else if (!first.empty() && e == hipSuccess) {
+    const bool chained = !levels.empty();
+    const int64_t tail0 = chained ? levels.back().off + levels.back().B0 : 0;       // first block behind all chains
+    if (!chained && !first.empty() && e == hipSuccess) {
         std::vector<int> last((size_t)nb, -1);      // last[c]: the last block row (before the border) that starts at column block c
         for (int64_t ib = 0; ib < border; ++ib) last[first[ib]] = (int)ib;
         int far = 0;
@@ -1127,27 +1219,65 @@ static int solve_impl(int64_t n, int64_t ld, double *S, double *rhs, const int *
             reach[k] = far;
         }
     }
+    // Where a block ends up: pos is a block position in the order BEFORE level m's reordering.
+    auto final_pos = [&](int64_t pos, size_t m) -> int64_t {
+        for (; m < levels.size(); ++m)
+            if (pos >= levels[m].off) pos = levels[m].off + levels[m].newpos[pos - levels[m].off];
+        return pos;
+    };
+    // Integer lists of the kernels, in one buffer: [position of every block after level 0 | final position of every
+    // block | per level: first column of a chain's blocks | per level but the last: final position of the rows behind
+    // its chains | profile behind the last chains]
+    std::vector<int> ints;
+    size_t newpos0_at = 0, finalpos_at = 0, tfirst_at = 0;
+    if (chained) {
+        newpos0_at = ints.size();
+        ints.insert(ints.end(), levels[0].newpos.begin(), levels[0].newpos.end());
+        finalpos_at = ints.size();
+        for (int64_t ib = 0; ib < nb; ++ib) ints.push_back((int)final_pos(ib, 0));
+        for (size_t m = 0; m < levels.size(); ++m) {
+            Level &L = levels[m];
+            L.cfirst_at = ints.size();
+            ints.insert(ints.end(), L.chain_first.begin(), L.chain_first.end());
+            L.rowpos_at = ints.size();
+            if (m + 1 < levels.size())
+                for (int64_t r = L.off + L.B0; r < nb; ++r) ints.push_back((int)final_pos(r, m + 1));
+        }
+        tfirst_at = ints.size();
+        ints.insert(ints.end(), tail_first.begin(), tail_first.end());
+    }
+    int *d_ints = nullptr;
+    int4 *d_moves = nullptr;
+    double *T = nullptr;
+    if (chained && e == hipSuccess) {
+        size_t most = 0;
+        for (const Level &L : levels) most = std::max(most, L.moves_n);
+        e = ws.grow(ws.moves, sizeof(int4) * moves.size());
+        if (e == hipSuccess) e = ws.grow(ws.T, sizeof(double) * NB * NB * most);
+        if (e == hipSuccess) e = ws.grow(ws.newpos, sizeof(int) * ints.size());
+        d_moves = (int4 *)ws.moves.p, T = (double *)ws.T.p, d_ints = (int *)ws.newpos.p;
+    }
 
     // Rows a launch covers when its panel ends at column block k_last and its rows start at block `start`, in units of
     // `unit` blocks; returns their number.
-    //   one chain (P == 1): those up to reach[k_last], then the border
-    //   chains: blocks are counted inside the chain; those up to the chain's reach, the separators on either side
-    //           of the chain, everything behind the separators
-    //   behind the chains (dense == true): all rows
-    auto select_rows = [&](int64_t k_last, int64_t start, int unit, bool chains, bool dense, RowSel &sel) -> int64_t {
+    //   one chain (no levels): those up to reach[k_last], then the border
+    //   chains of level L: k_last and start are counted inside the chain; the blocks up to the chain's reach, the
+    //           separators on either side of the chain, everything behind the separators
+    //   behind the chains (dense == true): all rows (start: a block of the whole matrix)
+    auto select_rows = [&](int64_t k_last, int64_t start, int unit, const Level *L, bool dense, RowSel &sel) -> int64_t {
         sel = RowSel();
         if (dense) return cdiv_c(nb - start, unit);
         const int64_t unit_rows = (int64_t)unit * NB;
-        if (chains) {
-            const int64_t band_end = std::min<int64_t>(chain_reach[k_last] + 1, s_blocks);     // blocks of the chain kept: [start, band_end)
+        if (L) {
+            const int64_t band_end = std::min<int64_t>(L->chain_reach[k_last] + 1, L->s);     // blocks of the chain kept: [start, band_end)
             const int64_t band = std::max<int64_t>(cdiv_c(std::max<int64_t>(band_end - start, 0), unit), 0);
             sel.n1 = (int)band;
-            sel.n2 = (int)cdiv_c(2 * bw, unit);
-            sel.chain_rows = S_rows;
-            sel.win_rows = (B0 - start) * NB;
-            sel.win_step = bw * NB;
-            sel.tail_rows = (T0 - start) * NB;
-            return band + sel.n2 + cdiv_c(nb - T0, unit);
+            sel.n2 = (int)cdiv_c(2 * L->bw, unit);
+            sel.chain_rows = L->s * NB;
+            sel.win_rows = (L->B0 - start) * NB;
+            sel.win_step = L->bw * NB;
+            sel.tail_rows = (L->T0 - start) * NB;
+            return band + sel.n2 + cdiv_c(nb - (L->off + L->T0), unit);
         }
         const int64_t total = cdiv_c(nb, unit), border_u = border / unit, reach_u = reach[k_last] / unit, start_u = start / unit;
         if (start_u >= border_u || reach_u + 1 >= border_u) return total - start_u;
@@ -1157,17 +1287,31 @@ static int solve_impl(int64_t n, int64_t ld, double *S, double *rhs, const int *
         return band + (total - border_u);
     };
     // the blocks cleared on return: every block that can hold anything after the factorisation - the envelope in the
-    // order the factorisation worked in, whole rows behind the chains, the row that carried the right-hand side
+    // order the factorisation worked in, the row that carried the right-hand side
     std::vector<int4> runs;
     int4 *d_runs = nullptr;
     if (clear_on_return && !first.empty() && e == hipSuccess) {
         auto add_run = [&](int64_t row, int64_t c_begin, int64_t c_last) {
             for (int64_t c = c_begin; c <= c_last; c += 32) runs.push_back(make_int4((int)row, (int)c, (int)std::min(c + 31, c_last), 0));
         };
-        if (P > 1) {
-            for (int c = 0; c < P; ++c)
-                for (int64_t l = 0; l < s_blocks; ++l) add_run(c * s_blocks + l, c * s_blocks + chain_first[l], c * s_blocks + l);
-            for (int64_t r = B0; r < nb; ++r) add_run(r, 0, r);
+        if (chained) {
+            for (const Level &L : levels) {
+                for (int c = 0; c < L.P; ++c)
+                    for (int64_t l = 0; l < L.s; ++l)
+                        add_run(L.off + c * L.s + l, L.off + c * L.s + L.chain_first[l], L.off + c * L.s + l);
+                // the rows behind the level's chains, in the columns of its chains: a separator's rows hold entries in
+                // the columns of the chains on either side of it only (chain 0's rows kernel also passes over
+                // separator 1); the rows behind the separators are dense
+                for (int64_t r = L.off + L.B0; r < nb; ++r) {
+                    if (r < L.off + L.T0) {
+                        const int64_t sep = (r - L.off - L.B0) / L.bw;
+                        add_run(r, L.off + (sep > 1 ? sep : 0) * L.s, L.off + std::min<int64_t>((sep + 2) * L.s, L.B0) - 1);
+                    } else {
+                        add_run(r, L.off, L.off + L.B0 - 1);
+                    }
+                }
+            }
+            for (int64_t r = tail0; r < nb; ++r) add_run(r, tail0 + tail_first[r - tail0], r);
         } else {
             for (int64_t r = 0; r + 1 < nb; ++r) add_run(r, row_first[r], r);
             add_run(nb - 1, 0, nb - 1);
@@ -1184,20 +1328,17 @@ static int solve_impl(int64_t n, int64_t ld, double *S, double *rhs, const int *
         hipLaunchKernelGGL(k_zero_int, dim3(1), dim3(1), 0, q, info);
         if (assumed)
             hipLaunchKernelGGL(k_profile_guard, dim3(cdiv_c(nb, 256)), dim3(256), 0, q, block_first, (const int *)ws.guard.p, nb, info);
-        if (P > 1)
-            for (int mode = 0; mode < 3; ++mode)
-                hipLaunchKernelGGL(k_move_blocks, dim3((unsigned)moves.size()), dim3(256), 0, q, S, ld, d_moves, T, mode);
-        if (ride_along) hipLaunchKernelGGL(k_rhs_into_row, dim3(cdiv_c(ld, 256)), dim3(256), 0, q, S, ld, n, rhs, d_newpos);
-        // Factorisation of the columns [begin, end) - of every chain at once when n_chains > 1 (begin, end inside the
-        // chain then) - and update of everything behind them.
-        auto factor = [&](int64_t begin, int64_t end, int n_chains, bool dense) {
-            const bool chains = n_chains > 1;
-            const int64_t chain_rows = chains ? S_rows : 0;
+        // Factorisation of the columns [begin, end) - of every chain of level L at once when L is given (begin: the
+        // first chain's first column) - and update of everything behind them.
+        auto factor = [&](int64_t begin, int64_t end, const Level *L, bool dense) {
+            const int n_chains = L ? L->P : 1;
+            const int64_t chain_rows = L ? L->s * NB : 0;
+            const int64_t origin = L ? L->off : 0;      // select_rows counts a chain's blocks from the level's first block
             // tiles of the region C[c0.., c0 .. c_end): lower triangle of the first tile columns, whole rows below
             auto trailing = [&](int64_t k_first, int64_t kw, int64_t c0, int64_t c_end) {
                 if (c0 >= ld || c_end <= c0) return;
                 RowSel sel;
-                const int64_t nt = select_rows((k_first + kw - 1) / NB, c0 / NB, TS / NB, chains, dense, sel);   // tile rows kept
+                const int64_t nt = select_rows((k_first + kw - 1) / NB - origin, c0 / NB - origin, TS / NB, L, dense, sel);   // tile rows kept
                 int64_t nct = 0;        // tile columns: those of the rows kept that lie before c_end
                 while (nct < nt && sel(nct, TS, 0) < c_end - c0) ++nct;
                 if (nct == 0) return;
@@ -1226,7 +1367,7 @@ static int solve_impl(int64_t n, int64_t ld, double *S, double *rhs, const int *
                     }
                     if (p0 + pw < ld) {
                         RowSel sel;
-                        const int slabs = (int)select_rows((p0 + pw - 1) / NB, (p0 + pw) / NB, 1, chains, dense, sel);
+                        const int slabs = (int)select_rows((p0 + pw - 1) / NB - origin, (p0 + pw) / NB - origin, 1, L, dense, sel);
                         const dim3 grid(slabs, n_chains);
                         if (nbk == 4) hipLaunchKernelGGL(k_panel_rows<4>, grid, dim3(256), lds_rows, q, S, ld, p0, Li, sel);
                         else if (nbk == 3) hipLaunchKernelGGL(k_panel_rows<3>, grid, dim3(256), lds_rows, q, S, ld, p0, Li, sel);
@@ -1240,11 +1381,18 @@ static int solve_impl(int64_t n, int64_t ld, double *S, double *rhs, const int *
                 trailing(o0, o_end - o0, o_end, 2 * ld);
             }
         };
-        if (P > 1) {
-            factor(0, S_rows, P, false);            // the chains, side by side
-            factor(B0 * NB, ld, 1, true);           // separators, rest of the band, border: dense
+        if (chained) {
+            for (size_t m = 0; m < levels.size(); ++m) {
+                const Level &L = levels[m];
+                for (int mode = 0; mode < 3; ++mode)
+                    hipLaunchKernelGGL(k_move_blocks, dim3((unsigned)L.moves_n), dim3(256), 0, q, S, ld, d_moves + L.moves_at, T, mode);
+                if (m == 0) hipLaunchKernelGGL(k_rhs_into_row, dim3(cdiv_c(ld, 256)), dim3(256), 0, q, S, ld, n, rhs, d_ints + newpos0_at);
+                factor(L.off * NB, (L.off + L.s) * NB, &L, false);      // the level's chains, side by side
+            }
+            factor(tail0 * NB, ld, nullptr, true);      // what is behind the last chains: dense
         } else {
-            factor(0, ld, 1, false);
+            if (ride_along) hipLaunchKernelGGL(k_rhs_into_row, dim3(cdiv_c(ld, 256)), dim3(256), 0, q, S, ld, n, rhs, (const int *)nullptr);
+            factor(0, ld, nullptr, false);
         }
         // L y = b (unless it rode along), then L^T x = y; the result of every block step lands in tmp
         if (ride_along) {
@@ -1255,31 +1403,38 @@ static int solve_impl(int64_t n, int64_t ld, double *S, double *rhs, const int *
                                    ld, k * NB, Linv + k * NB * NB, rhs, tmp, 0, (int64_t)0, (int64_t)0);
             e = hipMemcpyAsync(rhs, tmp, sizeof(double) * ld, hipMemcpyDeviceToDevice, q);
         }
-        if (P > 1) {
+        if (chained) {
             // (see "backward solve ... in three launches" above; a launch per block step where a workgroup's LDS
             // does not hold the right-hand side)
             const bool step_by_step = getenv("BA_CHOL_BACK_STEPS") != nullptr;
-            if (nb - B0 <= BACK_TAIL_MAX_BLOCKS && !step_by_step) {
-                hipLaunchKernelGGL(k_back_tail, dim3(1), dim3(1024), sizeof(double) * NB * (nb - B0), q, S, ld, Linv, rhs, tmp,
-                                   B0, nb);
-                hipLaunchKernelGGL(k_back_tail_to_chains, dim3(cdiv_c(B0 * NB, 128), (unsigned)(nb - B0)), dim3(256), 0, q, S, ld,
-                                   tmp, rhs, B0, T0, bw, S_rows);
+            if (nb - tail0 <= BACK_TAIL_MAX_BLOCKS && !step_by_step) {
+                hipLaunchKernelGGL(k_back_tail, dim3(1), dim3(1024), sizeof(double) * NB * (nb - tail0), q, S, ld, Linv, rhs, tmp,
+                                   tail0, nb, d_ints + tfirst_at);
             } else {
-                for (int64_t k = nb - 1; k >= B0; --k)      // behind the chains: rows with entries in every chain
-                    hipLaunchKernelGGL(k_solve_step, dim3(cdiv_c(k * NB, 256)), dim3(256), 0, q, S, ld, k * NB,
-                                       Linv + k * NB * NB, rhs, tmp, 1, (int64_t)0, (int64_t)0);
-            }
-            if (s_blocks <= BACK_CHAIN_MAX_BLOCKS && !step_by_step) {
-                hipLaunchKernelGGL(k_back_chains, dim3(P), dim3(256), sizeof(double) * NB * s_blocks, q, S, ld, Linv, rhs, tmp,
-                                   (int)s_blocks, d_cfirst);
-            } else {
-                for (int64_t k = s_blocks - 1; k >= 0; --k) {       // block k of every chain
-                    const int64_t i_begin = (int64_t)chain_first[k] * NB;
-                    hipLaunchKernelGGL(k_solve_step, dim3(k * NB > i_begin ? cdiv_c(k * NB - i_begin, 256) : 1, P), dim3(256), 0,
-                                       q, S, ld, k * NB, Linv + k * NB * NB, rhs, tmp, 1, i_begin, S_rows);
+                for (int64_t k = nb - 1; k >= tail0; --k) {
+                    const int64_t i_begin = (tail0 + tail_first[k - tail0]) * NB;
+                    hipLaunchKernelGGL(k_solve_step, dim3(k * NB > i_begin ? cdiv_c(k * NB - i_begin, 256) : 1), dim3(256), 0, q, S,
+                                       ld, k * NB, Linv + k * NB * NB, rhs, tmp, 1, i_begin, (int64_t)0);
                 }
             }
-            hipLaunchKernelGGL(k_solution_back, dim3(cdiv_c(ld, 256)), dim3(256), 0, q, tmp, ld, d_newpos, rhs);
+            for (size_t m = levels.size(); m-- > 0;) {
+                const Level &L = levels[m];
+                const int64_t B0a = L.off + L.B0;
+                hipLaunchKernelGGL(k_back_tail_to_chains, dim3(cdiv_c(L.B0 * NB, 128), (unsigned)(nb - B0a)), dim3(256), 0, q, S, ld,
+                                   tmp, rhs, L.off * NB, B0a, L.off + L.T0, L.bw, L.s * NB,
+                                   m + 1 < levels.size() ? d_ints + L.rowpos_at : (const int *)nullptr);
+                if (L.s <= BACK_CHAIN_MAX_BLOCKS && !step_by_step) {
+                    hipLaunchKernelGGL(k_back_chains, dim3(L.P), dim3(256), sizeof(double) * NB * L.s, q, S, ld, Linv, rhs, tmp,
+                                       L.off, (int)L.s, d_ints + L.cfirst_at);
+                } else {
+                    for (int64_t k = L.s - 1; k >= 0; --k) {       // block k of every chain
+                        const int64_t k0 = (L.off + k) * NB, i_begin = (L.off + L.chain_first[k]) * NB;
+                        hipLaunchKernelGGL(k_solve_step, dim3(k0 > i_begin ? cdiv_c(k0 - i_begin, 256) : 1, L.P), dim3(256), 0, q,
+                                           S, ld, k0, Linv + (L.off + k) * NB * NB, rhs, tmp, 1, i_begin, L.s * NB);
+                    }
+                }
+            }
+            hipLaunchKernelGGL(k_solution_back, dim3(cdiv_c(ld, 256)), dim3(256), 0, q, tmp, ld, d_ints + finalpos_at, rhs);
         } else {
             for (int64_t k = nb - 1; k >= 0; --k) {
                 const int64_t i_begin = (int64_t)row_first[k] * NB;     // L has nothing left of the row's first entry
@@ -1300,20 +1455,21 @@ static int solve_impl(int64_t n, int64_t ld, double *S, double *rhs, const int *
     // the lists that steer the moves and the clearing: uploaded when the profile they follow is not the last call's
     // (waited for: the host vectors are this call's)
     // (the layout also depends on the split into chains, which a switch can change under one and the same profile)
+    std::vector<int64_t> split;
+    for (const Level &L : levels) split.insert(split.end(), {L.off, (int64_t)L.P, L.s, L.bw});
     const bool same = ws.lists_valid && ws.n == n && ws.ld == ld && ws.clear == clear_on_return && ws.profile == first &&
-                      ws.chains == P && ws.chain_blocks == s_blocks && ws.sep_blocks == bw;
+                      ws.split == split;
     if (!same) {
         ws.lists_valid = false;
-        if (P > 1) {
+        if (chained) {
             e = hipMemcpy(d_moves, moves.data(), sizeof(int4) * moves.size(), hipMemcpyHostToDevice);
-            if (e == hipSuccess) e = hipMemcpy(d_newpos, newpos.data(), sizeof(int) * nb, hipMemcpyHostToDevice);
-            if (e == hipSuccess) e = hipMemcpy(d_cfirst, chain_first.data(), sizeof(int) * s_blocks, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(d_ints, ints.data(), sizeof(int) * ints.size(), hipMemcpyHostToDevice);
         }
         if (e == hipSuccess && !runs.empty())
             e = hipMemcpy(d_runs, runs.data(), sizeof(int4) * runs.size(), hipMemcpyHostToDevice);
         BA_HIP(e);
         ws.n = n, ws.ld = ld, ws.clear = clear_on_return, ws.profile = first, ws.lists_valid = true, ws.guard_valid = false;
-        ws.chains = P, ws.chain_blocks = s_blocks, ws.sep_blocks = bw;
+        ws.split = split;
     }
     if (queued && !first.empty() && !ws.guard_valid) {      // the profile later queued calls are checked against
         const bool valid = ws.lists_valid;

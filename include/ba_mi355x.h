@@ -305,9 +305,10 @@ int ba_resect(int64_t N, int64_t K, const int64_t *col_ptr, const int32_t *oi_by
  *   (Cholesky creates no entries left of it), which costs one pass over the lower triangle and one host
  *   synchronisation; the environment variable BA_CHOL_DENSE=1 computes every tile.  A long narrow band is cut
  *   into independent chains that are factorised side by side (the 64-blocks of S are reordered in place: chains
- *   first, then the separators between them, then the border): what S holds on return is then the factor of the
- *   reordered matrix, and a pivot index in *h_info counts in that order; the solution comes back in the caller's
- *   order.  The sums into the blocks shared by the chains are atomic, so the last bits of the solution can differ
+ *   first, then the separators between them, then the border; the separators, a band again, are cut the same way
+ *   while that saves dependent steps - ba_cholesky_last_plan reports the split): what S holds on return is then
+ *   the factor of the reordered matrix, and a pivot index in *h_info counts in that order; the solution comes back
+ *   in the caller's order.  The sums into the blocks shared by the chains are atomic, so the last bits of the solution can differ
  *   from call to call.  BA_CHOL_NO_CHAINS=1 keeps the natural order (S = the factor L on return).
  * ba_backsubstitute: dX[N][3] = V'^-1 (-g_X - W d_cam - Xphi d_phi); dcam_packed (optional, 6K+1)
  *   receives d reordered to [dC (3K) | dTheta (3K) | dphi].  The trial point of the damped step comes out of
@@ -353,6 +354,11 @@ int ba_cholesky_solve_tracked(int64_t n, int64_t ld, double *S, double *rhs, con
 int ba_cholesky_solve_queued(int64_t n, int64_t ld, double *S, double *rhs, const int *block_first,
                              int clear_on_return, void *stream);
 int ba_cholesky_queued_result(int *h_info);
+/* How the last solve on the current device cut its band (for tests and reports): *n_levels levels of independent
+ * chains, one nested behind the other's chains; levels[4 k .. 4 k + 3] = first 64-block of level k's matrix, number of
+ * chains, 64-blocks per chain, 64-blocks per separator (at most `capacity` levels are written).  0 levels: the natural
+ * order was kept. */
+int ba_cholesky_last_plan(int64_t *levels, int capacity, int *n_levels);
 int ba_backsubstitute(ba_problem *p, const double *X, double lambda, const double *V, const double *Xphi,
                       const double *gX, const double *d, double *dcam_packed, double *dX, const double *cam,
                       double *X_trial, double *cam_trial, void *stream);

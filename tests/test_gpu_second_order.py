@@ -204,6 +204,118 @@ def test_cholesky_skips_structural_zeros_correctly(ba):
                 assert rel_err(np.tril(Sd.cpu().numpy()[:n, :n]), want_L) < 1e-11, (n, switch)
 
 
+def _banded_arrow_system(n, bw, closed):
+    """A diagonally dominant band of half-width bw with a dense last row (and, if closed, the last rows coupled with
+    the first columns) in lower band storage, a right-hand side, and the solution by LAPACK's banded Cholesky with
+    the border eliminated by blocks: (band, arrow, corner, b, x)."""
+    import scipy.linalg
+    rng = np.random.default_rng(n + bw)
+    # lower band storage for scipy (row d = d-th subdiagonal), plus an arrow row and, if closed, a corner block
+    band = rng.normal(size=(bw + 1, n))
+    for d in range(1, bw + 1):
+        band[d, n - d:] = 0.0
+    arrow = rng.normal(size=n - 1)
+    corner = rng.normal(size=(59, 50)) if closed else None
+    row_sum = np.abs(band[1:]).sum(axis=0)
+    for d in range(1, bw + 1):
+        row_sum[d:] += np.abs(band[d, :n - d])
+    row_sum[:n - 1] += np.abs(arrow)
+    row_sum[n - 1] += np.abs(arrow).sum()
+    if closed:
+        row_sum[n - 60:n - 1] += np.abs(corner).sum(axis=1)
+        row_sum[:50] += np.abs(corner).sum(axis=0)
+    band[0] = row_sum + 1.0
+    b = rng.normal(size=n)
+    # reference: the band by LAPACK, arrow and corner as a low-rank correction (Woodbury on S = B + U C U^T is more
+    # than a test needs: solve the bordered system by block elimination instead)
+    m = 60 if closed else 1                      # the last m unknowns form the border
+    nb_ = n - m
+    Bb = band[:, :nb_].copy()
+    for d in range(1, bw + 1):
+        Bb[d, max(nb_ - d, 0):] = 0.0
+    F = np.zeros((nb_, m))                      # coupling of the border's unknowns with the band's
+    D = np.zeros((m, m))
+    for jj in range(m):
+        col = nb_ + jj
+        for d in range(1, bw + 1):              # band entries that cross into the border: S[col, col - d]
+            if col - d < nb_ and col - d >= 0:
+                F[col - d, jj] += band[d, col - d]
+            elif col - d >= nb_:
+                D[jj, col - d - nb_] += band[d, col - d]
+        D[jj, jj] = band[0, col]
+    F[:, m - 1] += arrow[:nb_]
+    D[m - 1, :m - 1] += arrow[nb_:]
+    if closed:
+        F[:50, :59] += corner.T
+    D = np.tril(D) + np.tril(D, -1).T
+    cb = scipy.linalg.cholesky_banded(Bb, lower=True)
+    Y = scipy.linalg.cho_solve_banded((cb, True), np.c_[F, b[:nb_]])
+    Sc = D - F.T @ Y[:, :m]
+    x2 = np.linalg.solve(Sc, b[nb_:] - F.T @ Y[:, m])
+    want = np.r_[Y[:, m] - Y[:, :m] @ x2, x2]
+
+    return band, arrow, corner, b, want
+
+
+def _last_plan(lib):
+    import ctypes as C
+    buf, n_levels = (C.c_int64 * 16)(), C.c_int(0)
+    assert lib.ba_cholesky_last_plan(buf, 4, C.byref(n_levels)) == 0
+    return [tuple(buf[4 * k:4 * k + 4]) for k in range(n_levels.value)]
+
+
+@pytest.mark.parametrize('n,bw,closed', [(12001, 60, False), (12001, 60, True), (20000, 100, True), (30001, 40, False),
+                                         (30001, 40, True)])
+def test_cholesky_nested_levels_of_chains(ba, n, bw, closed):
+    """What lies behind the chains of a long narrow band is a band with a border again (the separators, coupled
+    through the chains between them) and is cut into chains of its own: one, two and three levels give the solution
+    of a banded LAPACK solve of the same system, the deeper splits really happen (ba_cholesky_last_plan), and S comes
+    back cleared.  closed: the last rows are coupled with the first columns, as on a closed camera path."""
+    import ctypes as C
+    lib = ba.engine._lib.load()
+    ld = (n + 63) // 64 * 64
+    nb = ld // 64
+    band, arrow, corner, b, want = _banded_arrow_system(n, bw, closed)
+    Sd0 = torch.zeros((ld, ld), dtype=torch.float64, device=DEV)
+    idx = torch.arange(n, device=DEV)
+    for d in range(0, bw + 1):
+        Sd0[idx[d:], idx[:n - d]] = torch.from_numpy(band[d, :n - d]).to(DEV)
+    Sd0[n - 1, :n - 1] += torch.from_numpy(arrow).to(DEV)
+    if closed:
+        Sd0[n - 60:n - 1, :50] += torch.from_numpy(corner).to(DEV)
+    pad = torch.arange(n, ld, device=DEV)
+    Sd0[pad, pad] = 1.0
+    first = np.array([max(0, (64 * ib - bw) // 64) for ib in range(nb)], dtype=np.int32)
+    first[(n - 60 if closed else n - 1) // 64:] = 0
+    first_d = torch.from_numpy(first).to(DEV)
+    plans = {}
+    for levels in (1, 2, 3):
+        Sd = Sd0.clone()
+        bd = torch.zeros(ld, dtype=torch.float64, device=DEV)
+        bd[:n] = torch.from_numpy(b)
+        info = C.c_int(7)
+        os.environ['BA_CHOL_LEVELS'] = str(levels)
+        try:
+            ba.engine.check(lib.ba_cholesky_solve_tracked(n, ld, C.c_void_p(Sd.data_ptr()), C.c_void_p(bd.data_ptr()),
+                                                          C.c_void_p(first_d.data_ptr()), 1, C.byref(info), None))
+        finally:
+            os.environ.pop('BA_CHOL_LEVELS', None)
+        assert info.value == 0
+        assert rel_err(bd.cpu().numpy()[:n], want) < 1e-10, levels
+        assert float(Sd.abs().max()) == 0.0, levels
+        plans[levels] = _last_plan(lib)
+        del Sd
+    # dependent block steps: the chains of every level, then what is left behind the last chains
+    steps = lambda plan: sum(p[2] for p in plan) + nb - (plan[-1][0] + plan[-1][1] * plan[-1][2])
+    assert len(plans[1]) == 1 and plans[2][0] == plans[1][0]
+    if n >= 30000:          # (n = 12 001: only eleven separators are left, a second level would not pay for itself;
+        assert len(plans[2]) == 2       # n = 20 000: separators of two blocks, coupled over three - too wide for chains of so few)
+    if len(plans[2]) == 2:
+        assert plans[2][1][0] == plans[1][0][1] * plans[1][0][2]      # the second level starts behind the first one's chains
+        assert steps(plans[2]) < steps(plans[1]) - 3
+    assert steps(plans[3]) <= steps(plans[2])
+
+
 @pytest.mark.parametrize('clear', [0, 1])
 def test_cholesky_switch_order_does_not_reuse_stale_lists(ba, clear):
     """The solver keeps the lists that steer its block moves and its clearing from call to call while the block
