@@ -887,11 +887,19 @@ __global__ void __launch_bounds__(256) k_back_chains(const double *__restrict__ 
     Linv += base * NB;
     for (int idx = tid; idx < s_blocks * NB; idx += 256) bt[idx] = b[base + idx];
     const int r = tid & 63, q = tid >> 6;
-    double lv[16];
+    // Nothing a step reads from memory depends on the steps before it: the inverse of block l - 1 and the block
+    // (l, l - 1) of L - the one the next step's right-hand side waits for - are requested a step ahead, so that a step
+    // is LDS traffic and arithmetic only.  Blocks further left (a band wider than one block) are read when needed.
+    double lv[16], nx[16];
     {
         const double *Lk = Linv + (int64_t)(s_blocks - 1) * NB * NB;
 #pragma unroll
         for (int c = 0; c < 16; ++c) lv[c] = Lk[(16 * q + c) * NB + r];
+        if (s_blocks > 1) {
+            const double *Ar = A + ((int64_t)(s_blocks - 1) * NB + 16 * q) * ld + (int64_t)(s_blocks - 2) * NB + r;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) nx[c] = Ar[(int64_t)c * ld];
+        }
     }
     __syncthreads();
     for (int l = s_blocks - 1; l >= 0; --l) {
@@ -899,10 +907,18 @@ __global__ void __launch_bounds__(256) k_back_chains(const double *__restrict__ 
 #pragma unroll
         for (int c = 0; c < 16; ++c) s += lv[c] * bt[l * NB + 16 * q + c];
         part[q][r] = s;
+        double cur[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) cur[c] = nx[c];
         if (l > 0) {
             const double *Lk = Linv + (int64_t)(l - 1) * NB * NB;
 #pragma unroll
             for (int c = 0; c < 16; ++c) lv[c] = Lk[(16 * q + c) * NB + r];
+            if (l > 1) {
+                const double *An = A + ((int64_t)(l - 1) * NB + 16 * q) * ld + (int64_t)(l - 2) * NB + r;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) nx[c] = An[(int64_t)c * ld];
+            }
         }
         __syncthreads();
         if (tid < NB) {
@@ -911,8 +927,14 @@ __global__ void __launch_bounds__(256) k_back_chains(const double *__restrict__ 
             out[base + l * NB + tid] = x;
         }
         __syncthreads();
+        if (l > 0 && first[l] < l) {
+            double u = 0.0;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) u += cur[c] * xk[16 * q + c];
+            atomicAdd(&bt[(l - 1) * NB + r], -u);
+        }
         const double *Ar = A + ((int64_t)l * NB + 16 * q) * ld;
-        for (int col = first[l] * NB + r; col < l * NB; col += NB) {
+        for (int col = first[l] * NB + r; col < (l - 1) * NB; col += NB) {
             double u = 0.0;
 #pragma unroll
             for (int c = 0; c < 16; ++c) u += Ar[(int64_t)c * ld + col] * xk[16 * q + c];
