@@ -84,6 +84,9 @@ struct CholCache {
     bool lists_valid = false;
     bool guard_valid = false;       // `guard` holds `profile` (the queued form compares the caller's profile with it)
     int *result_host = nullptr, *result_dev = nullptr;      // one word of mapped host memory: verdict of the queued form
+    // second stream of the chains' look-ahead (see factor() in solve_impl) and the events that tie it to the caller's
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_diag = nullptr, ev_rows = nullptr, ev_join = nullptr;
     int64_t n = 0, ld = 0;
     std::vector<int64_t> split;     // (first block, chains, blocks of a chain, blocks of a separator) of every level
     int clear = 0;
@@ -464,14 +467,15 @@ __global__ void __launch_bounds__(256) k_diag_syrk(double *__restrict__ A, int64
 // column block kb, T_kb = S_kb L_kk^-T, then S_jb -= T_kb L_jk^T for the blocks jb behind it.  Workgroup = 64 rows,
 // wave = 16 rows; the operand blocks (inverses from Linv, L_jk from the factorised diagonal block) pass through two
 // LDS buffers, the next one loaded while the matrix cores work on the current one.
+// l_begin: the launch's first 64-row unit of `sel` (a launch can take a part of the rows).
 template <int NBK>
 __global__ void __launch_bounds__(256) k_panel_rows(double *__restrict__ A, int64_t ld, int64_t p0,
-                                                    const double *__restrict__ Linv, RowSel sel) {
+                                                    const double *__restrict__ Linv, RowSel sel, int l_begin) {
     extern __shared__ double sm[];
     constexpr int NOPS = NBK * (NBK + 1) / 2;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int chain = blockIdx.y;
-    double *rows = A + (p0 + NB * NBK + sel(blockIdx.x, NB, chain) + 16 * w) * ld + p0 + chain * sel.chain_rows;
+    double *rows = A + (p0 + NB * NBK + sel(blockIdx.x + l_begin, NB, chain) + 16 * w) * ld + p0 + chain * sel.chain_rows;
     p0 += chain * sel.chain_rows;           // from here on: the panel's diagonal block, rows and columns of the chain
     Linv += chain * sel.chain_rows * NB;
     double *patch = sm + 2 * NB * LP + w * 16 * TP;
@@ -542,14 +546,14 @@ __global__ void __launch_bounds__(256) k_panel_rows(double *__restrict__ A, int6
 // row per lane makes every load instruction touch 64 cache lines and leaves the kernel bound by the
 // address pipeline of the vector memory unit.
 __global__ void __launch_bounds__(256, 2) k_syrk_trailing(double *__restrict__ A, int64_t ld, int64_t k0, int kw, int64_t c0,
-                                                          int64_t nct, RowSel sel) {
+                                                          int64_t nct, RowSel sel, int64_t t_begin) {
     extern __shared__ double smem[];
     double(*As)[LDT] = (double(*)[LDT])smem;
     double(*Bs)[LDT] = (double(*)[LDT])(smem + KC * LDT);
     // tile index -> (bi, bj), bj <= bi and bj < nct: the lower triangle of the first nct tile columns, then the rows
     // below it, nct tiles each.  (Grouping the tiles of an 8 x 8 super-tile on one XCD, to share panel rows through
     // its L2, was measured: no gain - the panel is served from the infinity cache either way.)
-    const int64_t t = blockIdx.x, tri = nct * (nct + 1) / 2;
+    const int64_t t = blockIdx.x + t_begin, tri = nct * (nct + 1) / 2;     // (t_begin: a launch can take a part of the tiles)
     int64_t bi, bj;
     if (t < tri) {
         bi = (int64_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
@@ -1344,6 +1348,13 @@ static int solve_impl(int64_t n, int64_t ld, double *S, double *rhs, const int *
     BA_HIP(e);
 
     const int64_t split_limit = getenv("BA_CHOL_SPLIT_LIMIT") ? atoi(getenv("BA_CHOL_SPLIT_LIMIT")) : 256;
+    const bool look_ahead = chained && !getenv("BA_CHOL_NO_LOOKAHEAD");
+    if (look_ahead && !ws.aux) {
+        BA_HIP(hipStreamCreateWithFlags(&ws.aux, hipStreamNonBlocking));
+        BA_HIP(hipEventCreateWithFlags(&ws.ev_diag, hipEventDisableTiming));
+        BA_HIP(hipEventCreateWithFlags(&ws.ev_rows, hipEventDisableTiming));
+        BA_HIP(hipEventCreateWithFlags(&ws.ev_join, hipEventDisableTiming));
+    }
     // Everything the device does for this call, on stream q.
     auto issue = [&](hipStream_t q) -> hipError_t {
         hipError_t e = hipSuccess;
@@ -1356,8 +1367,15 @@ static int solve_impl(int64_t n, int64_t ld, double *S, double *rhs, const int *
             const int n_chains = L ? L->P : 1;
             const int64_t chain_rows = L ? L->s * NB : 0;
             const int64_t origin = L ? L->off : 0;      // select_rows counts a chain's blocks from the level's first block
+            // Look-ahead (chains only).  The next diagonal block of a chain waits for the chain's own rows and their
+            // update only; the rows of the separators and of the border - the long strips - and every tile of the update
+            // that lies in them are needed when the chains are finished, not before: they run on a second stream, in
+            // the order of the panels, beside the chain of diagonal blocks.
+            const bool ahead = L && look_ahead;
             // tiles of the region C[c0.., c0 .. c_end): lower triangle of the first tile columns, whole rows below
-            auto trailing = [&](int64_t k_first, int64_t kw, int64_t c0, int64_t c_end) {
+            // which: 0 every tile; with look-ahead 1 = the tiles of the chain's own rows (caller's stream), 2 = the others
+            // (second stream)
+            auto trailing = [&](int64_t k_first, int64_t kw, int64_t c0, int64_t c_end, int which) {
                 if (c0 >= ld || c_end <= c0) return;
                 RowSel sel;
                 const int64_t nt = select_rows((k_first + kw - 1) / NB - origin, c0 / NB - origin, TS / NB, L, dense, sel);   // tile rows kept
@@ -1365,10 +1383,30 @@ static int solve_impl(int64_t n, int64_t ld, double *S, double *rhs, const int *
                 while (nct < nt && sel(nct, TS, 0) < c_end - c0) ++nct;
                 if (nct == 0) return;
                 const int64_t tiles = nct * (nct + 1) / 2 + (nt - nct) * nct;
-                int split = 1;      // workgroups per tile: as long as the launch stays within one round of the chip
-                while (tiles * n_chains * split * 2 <= split_limit && kw % (split * 2 * NB) == 0) split *= 2;
-                hipLaunchKernelGGL(k_syrk_trailing, dim3((unsigned)tiles, (unsigned)split, (unsigned)n_chains), dim3(256),
-                                   lds_trailing, q, S, ld, k_first, (int)(kw / split), c0, nct, sel);
+                auto launch = [&](hipStream_t sq, int64_t t_begin, int64_t count) {
+                    if (count <= 0) return;
+                    int split = 1;      // workgroups per tile: as long as the launch stays within one round of the chip
+                    while (count * n_chains * split * 2 <= split_limit && kw % (split * 2 * NB) == 0) split *= 2;
+                    hipLaunchKernelGGL(k_syrk_trailing, dim3((unsigned)count, (unsigned)split, (unsigned)n_chains), dim3(256),
+                                       lds_trailing, sq, S, ld, k_first, (int)(kw / split), c0, nct, sel, t_begin);
+                };
+                if (which == 0) {
+                    launch(q, 0, tiles);
+                } else {
+                    // tiles are counted row by row: those of the chain's own rows come first
+                    const int64_t band = std::min<int64_t>(sel.n1, nt);
+                    const int64_t own = band <= nct ? band * (band + 1) / 2 : nct * (nct + 1) / 2 + (band - nct) * nct;
+                    if (which == 1) launch(q, 0, own);
+                    else launch(ws.aux, own, tiles - own);
+                }
+            };
+            auto rows_launch = [&](hipStream_t sq, int nbk, int64_t p0, const double *Li, const RowSel &sel, int l_begin, int count) {
+                if (count <= 0) return;
+                const dim3 grid(count, n_chains);
+                if (nbk == 4) hipLaunchKernelGGL(k_panel_rows<4>, grid, dim3(256), lds_rows, sq, S, ld, p0, Li, sel, l_begin);
+                else if (nbk == 3) hipLaunchKernelGGL(k_panel_rows<3>, grid, dim3(256), lds_rows, sq, S, ld, p0, Li, sel, l_begin);
+                else if (nbk == 2) hipLaunchKernelGGL(k_panel_rows<2>, grid, dim3(256), lds_rows, sq, S, ld, p0, Li, sel, l_begin);
+                else hipLaunchKernelGGL(k_panel_rows<1>, grid, dim3(256), lds_rows, sq, S, ld, p0, Li, sel, l_begin);
             };
             for (int64_t o0 = begin; o0 < end; o0 += OB) {
                 const int64_t o_end = (end - o0 < OB) ? end : o0 + OB;
@@ -1390,17 +1428,42 @@ static int solve_impl(int64_t n, int64_t ld, double *S, double *rhs, const int *
                     if (p0 + pw < ld) {
                         RowSel sel;
                         const int slabs = (int)select_rows((p0 + pw - 1) / NB - origin, (p0 + pw) / NB - origin, 1, L, dense, sel);
-                        const dim3 grid(slabs, n_chains);
-                        if (nbk == 4) hipLaunchKernelGGL(k_panel_rows<4>, grid, dim3(256), lds_rows, q, S, ld, p0, Li, sel);
-                        else if (nbk == 3) hipLaunchKernelGGL(k_panel_rows<3>, grid, dim3(256), lds_rows, q, S, ld, p0, Li, sel);
-                        else if (nbk == 2) hipLaunchKernelGGL(k_panel_rows<2>, grid, dim3(256), lds_rows, q, S, ld, p0, Li, sel);
-                        else hipLaunchKernelGGL(k_panel_rows<1>, grid, dim3(256), lds_rows, q, S, ld, p0, Li, sel);
+                        if (ahead) {
+                            // the chain's own next rows at once (they start late in the panel: the sub-panel from their first
+                            // column block on does); separators and border on the second stream
+                            const int band = std::min(sel.n1, slabs);
+                            hipEventRecord(ws.ev_diag, q);
+                            hipStreamWaitEvent(ws.aux, ws.ev_diag, 0);
+                            if (band > 0) {
+                                const int64_t panel_first = p0 / NB - origin, next = (p0 + pw) / NB - origin;
+                                int fk = nbk - 1;
+                                for (int l = 0; l < band; ++l)
+                                    fk = std::min<int64_t>(fk, std::max<int64_t>(L->chain_first[next + l] - panel_first, 0));
+                                rows_launch(q, nbk - fk, p0 + (int64_t)fk * NB, Li + (int64_t)fk * NB * NB, sel, 0, band);
+                            }
+                            hipEventRecord(ws.ev_rows, q);
+                            rows_launch(ws.aux, nbk, p0, Li, sel, band, slabs - band);
+                            hipStreamWaitEvent(ws.aux, ws.ev_rows, 0);
+                        } else {
+                            rows_launch(q, nbk, p0, Li, sel, 0, slabs);
+                        }
                     }
                     // inside the outer panel: only its remaining columns see this 256-wide panel now
-                    trailing(p0, pw, p0 + pw, o_end);
+                    if (!ahead) {
+                        trailing(p0, pw, p0 + pw, o_end, 0);
+                    } else {
+                        // (the rows of separators and border take every panel at once, in all their columns: their
+                        // updates run beside the chain, and nothing long is left for the chain's end)
+                        trailing(p0, pw, p0 + pw, o_end, 1);
+                        trailing(p0, pw, p0 + pw, 2 * ld, 2);
+                    }
                 }
                 // behind the outer panel: one update with all its columns as the inner dimension
-                trailing(o0, o_end - o0, o_end, 2 * ld);
+                trailing(o0, o_end - o0, o_end, 2 * ld, ahead ? 1 : 0);
+            }
+            if (ahead) {
+                hipEventRecord(ws.ev_join, ws.aux);
+                hipStreamWaitEvent(q, ws.ev_join, 0);
             }
         };
         if (chained) {
