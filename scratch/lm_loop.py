@@ -20,3 +20,7 @@ later = st[2:] if len(st) > 2 else st[1:]
 print(f'K={K} N={N} |V|={sc["i"].size}: {fit.iters} LM iterations ({fit.accepted} accepted, {fit.rejected} rejected) in {dt*1e3:.1f} ms; '
       f'first evaluation {st[0]:.1f} ms, first iteration {st[1]:.1f} ms (with the set-up of S), the others {later.mean():.2f} ms each '
       f'(min {later.min():.2f}, max {later.max():.2f}); E ' + ' '.join(f'{e:.5g}' for e in E), flush=True)
+import ctypes as C
+buf, nl = (C.c_int64 * 16)(), C.c_int(0)
+sh.lib.ba_cholesky_last_plan(buf, 4, C.byref(nl))
+print('plan (first block, chains, blocks per chain, separator blocks):', [tuple(buf[4 * k:4 * k + 4]) for k in range(nl.value)], 'of', sh.ld_red // 64, 'blocks', flush=True)

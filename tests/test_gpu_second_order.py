@@ -725,6 +725,34 @@ def test_fit_scene_lm_on_the_recorded_scene_with_long_tracks(ba, golden):
     assert np.abs(out[0] - Xr).max() < 1e-5 * np.abs(Xr).max() and np.abs(out[1] - Cr).max() < 1e-5
 
 
+def test_lm_loop_recovers_when_the_assumed_profile_is_too_narrow(ba):
+    """The LM loop queues its solves on the profile of the solve before.  A scene with the same number of cameras
+    but longer tracks (a wider band) right after a scene with short ones: the device-side guard voids the first
+    step, the loop clears S, reads the profile again and goes on - same energies as a second run of that scene."""
+    K = 260
+    narrow = ba.scenes.orbit_scene(N=1500, K=K, track_len=4, seed=2)
+    wide = ba.scenes.orbit_scene(N=1500, K=K, track_len=30, seed=3)
+
+    def run(sc, iters=5):
+        sh = ba.engine.Shard(sc['i'], sc['j'], sc['uv'], sc['N_local'], K, sc['W'], sc['H'], DEV)
+        sh.set_params(sc['X_0'], sc['C_0'], sc['Theta_0'], sc['phi_x_0'])
+        voided = []
+        pivot = sh.lm_pivot
+        sh.lm_pivot = lambda: (voided.append(pivot()), voided[-1])[1]
+        fit = ba.lm.LMFit(sh, iters + 1, lam=1e-3, print_step=10 ** 9, printer=lambda *a: None).run()
+        E = fit.energies()
+        sh.close()
+        return E, voided
+
+    E_n, v_n = run(narrow)
+    E_w1, v_w1 = run(wide)
+    E_w2, v_w2 = run(wide)
+    assert -1 in v_w1 and v_w1.count(-1) == 1          # noticed once, then the profile was read again
+    assert -1 not in v_w2 and -1 not in v_n
+    assert E_w1.shape == E_w2.shape and rel_err(E_w1, E_w2) < 1e-9
+    assert E_w1[-1] < 1e-2 * E_w1[0]
+
+
 def test_twenty_thousand_cameras_lm_step_at_full_size(ba):
     """The large-K configuration at its full size (K = 20 000 cameras, 1 M points, 10 M observations: reduced
     system of 120 001 unknowns, S = 115 GB in HBM) through size-independent properties of ONE damped
