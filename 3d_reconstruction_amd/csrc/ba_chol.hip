@@ -1347,7 +1347,7 @@ static int solve_impl(int64_t n, int64_t ld, double *S, double *rhs, const int *
     }
     BA_HIP(e);
 
-    const int64_t split_limit = getenv("BA_CHOL_SPLIT_LIMIT") ? atoi(getenv("BA_CHOL_SPLIT_LIMIT")) : 256;
+    const int64_t split_limit = getenv("BA_CHOL_SPLIT_LIMIT") ? atoi(getenv("BA_CHOL_SPLIT_LIMIT")) : 512;     // workgroup slots of the chip (two per CU)
     const bool look_ahead = chained && !getenv("BA_CHOL_NO_LOOKAHEAD");
     if (look_ahead && !ws.aux) {
         BA_HIP(hipStreamCreateWithFlags(&ws.aux, hipStreamNonBlocking));
