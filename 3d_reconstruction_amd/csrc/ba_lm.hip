@@ -994,19 +994,26 @@ __global__ void __launch_bounds__(SCHUR_TILE_BLOCK) k_schur_tile(SchurTileArgs a
 // whole register file of a SIMD for one wave and was slower).
 // --------------------------------------------------------------------------------------------
 constexpr int SCHUR_GEMM_BLOCK = 256;
-constexpr int SCHUR_GEMM_PTS = 4;       // points per trip of a wave: 12 rows = three steps of four
+// Points per trip of a wave: four (sixteen lanes each, 12 rows = three steps of four) or, where no point has more than
+// ten observations, six (ten lanes each, 18 rows in five steps): the lanes that form the rows are then 60 of 64 busy
+// instead of 40, for one matrix-core step in six spent on two rows of zeros.
+constexpr int SCHUR_GEMM_ROWS_MAX = 20;
 
 __host__ __device__ inline int schur_gemm_nbt(int cam_cap) { return (6 * cam_cap + 2 + 15) / 16; }
 __host__ __device__ inline size_t schur_gemm_lds_doubles(int cam_cap) {
     const int nbt = schur_gemm_nbt(cam_cap) < 4 ? 4 : schur_gemm_nbt(cam_cap), mp = 16 * nbt;      // (the smallest kernel has NBT = 4)
-    return (size_t)cam_cap * (CAM_ROW + 18) + (size_t)(SCHUR_GEMM_BLOCK / 64) * (3 * SCHUR_GEMM_PTS * (mp + 1)) +
-           (size_t)nbt * (nbt + 1) / 2 * 256 + (size_t)(cam_cap + 1) / 2;
+    // (the waves' patches and, after the last trip, the tiles their sums meet in share one region)
+    return (size_t)cam_cap * (CAM_ROW + 18) +
+           std::max((size_t)(SCHUR_GEMM_BLOCK / 64) * (SCHUR_GEMM_ROWS_MAX * (mp + 1)), (size_t)nbt * (nbt + 1) / 2 * 256) +
+           (size_t)(cam_cap + 1) / 2;
 }
 
-template <int NBT>
+template <int NBT, int PTS>
 __global__ void __launch_bounds__(SCHUR_GEMM_BLOCK, 2) k_schur_gemm(SchurTileArgs a) {
     extern __shared__ double lds[];
-    constexpr int MP = 16 * NBT, NT = NBT * (NBT + 1) / 2, ROWS = 3 * SCHUR_GEMM_PTS, PITCH = MP;
+    constexpr int LPP = PTS == 4 ? 16 : 10;             // lanes per point
+    constexpr int MP = 16 * NBT, NT = NBT * (NBT + 1) / 2, ROWS = (3 * PTS + 3) / 4 * 4, PITCH = MP;
+    static_assert(PTS * LPP <= 64 && ROWS <= SCHUR_GEMM_ROWS_MAX, "points of a trip: one lane group each");
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     // a range of points of a tile and the window of the tile's camera slots they see
     const int4 sub = a.sub[blockIdx.x];
@@ -1016,10 +1023,13 @@ __global__ void __launch_bounds__(SCHUR_GEMM_BLOCK, 2) k_schur_gemm(SchurTileArg
     const int m = 6 * nc;       // columns: 6 per camera slot of the window, then phi_x (m), then g (m + 1)
     double *rows = lds;                                   // cam_cap x CAM_ROW
     double *Tt = rows + (size_t)a.cam_cap * CAM_ROW;      // cam_cap x 6 x 3 (see k_schur_tile)
-    double *patch = Tt + (size_t)a.cam_cap * 18 + (size_t)wid * (ROWS * (PITCH + 1));   // ROWS x PITCH, then ROWS sums for w_phi
+    double *patch = Tt + (size_t)a.cam_cap * 18 + (size_t)wid * (SCHUR_GEMM_ROWS_MAX * (PITCH + 1));   // ROWS x PITCH, then ROWS sums for w_phi
     double *wsum = patch + ROWS * PITCH;
-    double *Gt = Tt + (size_t)a.cam_cap * 18 + (size_t)(SCHUR_GEMM_BLOCK / 64) * (ROWS * (PITCH + 1));   // NT tiles of 16 x 16
-    int *low = (int *)(Gt + (size_t)NT * 256);
+    double *Gt = Tt + (size_t)a.cam_cap * 18;       // NT tiles of 16 x 16, in place of the patches once the trips are over
+    constexpr size_t SHARED = (size_t)(SCHUR_GEMM_BLOCK / 64) * (SCHUR_GEMM_ROWS_MAX * (PITCH + 1)) > (size_t)NT * 256
+                                  ? (size_t)(SCHUR_GEMM_BLOCK / 64) * (SCHUR_GEMM_ROWS_MAX * (PITCH + 1))
+                                  : (size_t)NT * 256;
+    int *low = (int *)(Gt + SHARED);
     for (int idx = tid; idx < a.cam_cap; idx += SCHUR_GEMM_BLOCK) low[idx] = 0x7fffffff;
     for (int idx = tid; idx < nc * (CAM_ROW / 2); idx += SCHUR_GEMM_BLOCK) {
         const int row = idx / (CAM_ROW / 2), piece = idx - row * (CAM_ROW / 2);
@@ -1035,7 +1045,6 @@ __global__ void __launch_bounds__(SCHUR_GEMM_BLOCK, 2) k_schur_gemm(SchurTileArg
         else v = k == 2 ? 1.0 : 0.0;
         Tt[idx] = v;
     }
-    for (int idx = tid; idx < NT * 256; idx += SCHUR_GEMM_BLOCK) Gt[idx] = 0.0;
     const double f = a.scalars[SC_F], pcx = a.scalars[SC_CX], pcy = a.scalars[SC_CY], dphi = a.scalars[SC_DPHI];
     __syncthreads();
 
@@ -1068,11 +1077,11 @@ __global__ void __launch_bounds__(SCHUR_GEMM_BLOCK, 2) k_schur_gemm(SchurTileArg
         asm volatile("" ::: "memory");
     };
     const int nbt_tile = (m + 2 + 15) / 16;     // tile rows of this tile of points
-    // Sixteen lanes per point, lane o16 of them for the point's observation o16 (more than sixteen: further trips).
+    // LPP lanes per point, lane o16 of them for the point's observation o16 (more than LPP: further trips).
     // What a trip reads from memory is requested one trip ahead, the observation ranges it needs for that two trips
     // ahead: with two waves per SIMD nothing else would cover the two dependent trips to memory per group of points.
-    constexpr int GSTEP = SCHUR_GEMM_PTS * (SCHUR_GEMM_BLOCK / 64);
-    const int pl = lane >> 4, o16 = lane & 15;
+    constexpr int GSTEP = PTS * (SCHUR_GEMM_BLOCK / 64);
+    const int pl = lane / LPP, o16 = lane - LPP * pl;       // (pl == PTS: a lane without a point)
     struct GroupIn {
         uint32_t pk;
         double2 uv;
@@ -1080,7 +1089,7 @@ __global__ void __launch_bounds__(SCHUR_GEMM_BLOCK, 2) k_schur_gemm(SchurTileArg
     };
     auto range_of = [&](int first_pt, int64_t &eb, int &deg) {
         eb = 0, deg = 0;
-        if (first_pt + pl < np) {
+        if (pl < PTS && first_pt + pl < np) {
             eb = a.row_ptr[p0 + first_pt + pl];
             deg = (int)(a.row_ptr[p0 + first_pt + pl + 1] - eb);
         }
@@ -1108,7 +1117,7 @@ __global__ void __launch_bounds__(SCHUR_GEMM_BLOCK, 2) k_schur_gemm(SchurTileArg
             }
         }
     };
-    for (int pt0 = SCHUR_GEMM_PTS * wid; pt0 < np; pt0 += GSTEP) {
+    for (int pt0 = PTS * wid; pt0 < np; pt0 += GSTEP) {
         int64_t eb_c;
         int deg_c;
         GroupIn cur;
@@ -1142,9 +1151,9 @@ __global__ void __launch_bounds__(SCHUR_GEMM_BLOCK, 2) k_schur_gemm(SchurTileArg
             }
         };
         if (o16 < deg_c) one_observation(cur.pk, cur.uv);
-        for (int o = o16 + 16; o < deg_c; o += 16) one_observation(a.opack[eb_c + o], a.ouv[eb_c + o]);
+        for (int o = o16 + LPP; o < deg_c; o += LPP) one_observation(a.opack[eb_c + o], a.ouv[eb_c + o]);
         lanes_sync();
-        if (o16 == 0 && pt0 + pl < np) {       // the point's own two columns: phi_x and g
+        if (o16 == 0 && pl < PTS && pt0 + pl < np) {       // the point's own two columns: phi_x and g
             const bool seen = deg_c > 0;
             const double wp[3] = {wsum[3 * pl], wsum[3 * pl + 1], wsum[3 * pl + 2]};
 #pragma unroll
@@ -1187,6 +1196,9 @@ __global__ void __launch_bounds__(SCHUR_GEMM_BLOCK, 2) k_schur_gemm(SchurTileArg
         lanes_sync();
     }
     // the waves' sums meet in LDS: entry (16 tr + 4 I + (lane >> 4), 16 tc + (lane & 15)) of the Gram matrix
+    __syncthreads();        // every wave is through with its patch
+    for (int idx = tid; idx < NT * 256; idx += SCHUR_GEMM_BLOCK) Gt[idx] = 0.0;
+    __syncthreads();
 #pragma unroll
     for (int tr = 0; tr < NBT; ++tr)
 #pragma unroll
@@ -1791,9 +1803,13 @@ int ba_schur_build_tracked(ba_problem *p, const double *X, double lambda, const 
                 tg.cam_cap = SCHUR_GEMM_WINDOW;
                 constexpr int NBT = (6 * SCHUR_GEMM_WINDOW + 2 + 15) / 16;
                 const size_t lds_gemm = sizeof(double) * schur_gemm_lds_doubles(tg.cam_cap);
+                // six points per trip where no point has more than ten observations, else four
+                const bool six = p->max_degree <= 10 && !getenv("BA_SCHUR_FOUR_POINTS");
+                const void *kernel = six ? (const void *)k_schur_gemm<NBT, 6> : (const void *)k_schur_gemm<NBT, 4>;
                 if (lds_gemm > 64 * 1024)
-                    BA_HIP(hipFuncSetAttribute((const void *)k_schur_gemm<NBT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_gemm));
-                hipLaunchKernelGGL(k_schur_gemm<NBT>, dim3(p->n_schur_sub), dim3(SCHUR_GEMM_BLOCK), lds_gemm, st, tg);
+                    BA_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_gemm));
+                if (six) hipLaunchKernelGGL((k_schur_gemm<NBT, 6>), dim3(p->n_schur_sub), dim3(SCHUR_GEMM_BLOCK), lds_gemm, st, tg);
+                else hipLaunchKernelGGL((k_schur_gemm<NBT, 4>), dim3(p->n_schur_sub), dim3(SCHUR_GEMM_BLOCK), lds_gemm, st, tg);
             }
             if (rest) BA_HIP(hipStreamWaitEvent(st, p->aux_join, 0));
             BA_HIP(hipGetLastError());
