@@ -164,131 +164,6 @@ __device__ __forceinline__ double rcp_cubic(double x) {
     return fma(r, fma(e, e, e), r);
 }
 
-// L_kk = chol(A_kk) in place and Linv = L_kk^-1 (64 x 64, row-major), one workgroup of four waves.
-//
-// What a column costs here is not arithmetic but the trip of the finished column from the wave that owns it to the
-// other three (LDS write, barrier, LDS read: about 440 cycles, measured) and the chain of dependent instructions from
-// the pivot to the next column.  So the kernel takes TWO columns per barrier, and keeps square roots and divisions off
-// the chain: the columns stay unscaled (a_ik as the elimination leaves it; L_ik = a_ik / sqrt(d_k) is formed once, at
-// the end), the update of a later entry is a_ij -= a_ik a_jk / d_k, the reciprocal of the second pivot of a pair comes
-// from the determinant of the 2 x 2 pivot block (d_k' = det / d_k), so that both reciprocals start at once.
-// The inverse rides along: the 64 rows of the identity go through the same column operations as the rows of A
-// (row i of Y = I L^-T, i.e. column i of the inverse), two more multiply-adds per entry and step instead of a
-// separate substitution phase (which took a third of the kernel before).
-// Thread (row i = tid % 64, wave q = tid / 64) keeps, of row i of A and of row i of Y, the columns
-// j(u) = 8 (u / 2) + 2 q + (u & 1), u = 0..15: pairs of neighbouring columns dealt out to the waves in turn.
-// Entries above the diagonal are never used as inputs (they may hold anything, NaN included): what is computed from
-// them stays above the diagonal.
-constexpr int POTRF_LDS_DOUBLES = 2 * NB * (NB + 1) + 2 * 2 * 2 * NB + 3 * NB;
-__global__ void __launch_bounds__(256) k_potrf64(double *__restrict__ A, int64_t ld, int64_t k0, double *__restrict__ Linv,
-                                                 int *__restrict__ info, int64_t chain_rows) {
-    extern __shared__ double sm[];
-    k0 += blockIdx.y * chain_rows;                      // workgroup y: the same block of chain y
-    Linv += blockIdx.y * chain_rows * NB;
-    double(*Ls)[NB + 1] = (double(*)[NB + 1])sm;                      // the block on its way in and out
-    double(*Xs)[NB + 1] = (double(*)[NB + 1])(sm + NB * (NB + 1));    // the inverse on its way out
-    double2(*rawA)[NB] = (double2(*)[NB])(sm + 2 * NB * (NB + 1));    // [step & 1][row]: the step's two columns of A
-    double2(*rawY)[NB] = rawA + 2;                                    // ... and of Y
-    double *piv = (double *)(rawY + 2), *invs = piv + NB, *dsq = invs + NB;
-    const int tid = threadIdx.x, i = tid & 63, q = tid >> 6;
-    {
-        double2 tmp[8];
-        const int r0 = tid >> 5, c0 = 2 * (tid & 31);
-#pragma unroll
-        for (int m = 0; m < 8; ++m) tmp[m] = *(const double2 *)(A + (k0 + r0 + 8 * m) * ld + k0 + c0);
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            Ls[r0 + 8 * m][c0] = tmp[m].x;
-            Ls[r0 + 8 * m][c0 + 1] = tmp[m].y;
-        }
-    }
-    __syncthreads();
-    double reg[16], y[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-        const int j = 8 * (u >> 1) + 2 * q + (u & 1);
-        reg[u] = Ls[i][j];
-        y[u] = (j == i) ? 1.0 : 0.0;
-    }
-    if (q == 0) {
-        rawA[0][i] = make_double2(reg[0], reg[1]);
-        rawY[0][i] = make_double2(y[0], y[1]);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int s = 0; s < NB / 2; ++s) {
-        // columns k, k + 1, owned by wave qs in its registers u0, u0 + 1; the next pair belongs to wave qn
-        const int k = 2 * s, qs = s & 3, u0 = 2 * (s >> 2), buf = s & 1;
-        const int qn = (s + 1) & 3, un = 2 * ((s + 1) >> 2);
-        // every read of the step goes out right behind the barrier (left to itself the compiler sinks them to their
-        // uses, one LDS latency after the other)
-        const double2 P = rawA[buf][k], Q = rawA[buf][k + 1];       // pivot block: P.x = d_k, Q = (a_k+1,k , a_k+1,k+1)
-        const double2 Ri = rawA[buf][i], Yi = rawY[buf][i];
-        double2 Rj[16];
-#pragma unroll
-        for (int u = u0; u < 16; ++u) Rj[u] = rawA[buf][8 * (u >> 1) + 2 * q + (u & 1)];
-        __builtin_amdgcn_sched_barrier(0);
-        const double det = fma(P.x, Q.y, -(Q.x * Q.x));
-        const double r0 = rcp_cubic(P.x);           // 1 / d_k
-        const double r1 = P.x * rcp_cubic(det);     // 1 / d_k+1
-        const double t = Q.x * r0;
-        const double ai1 = fma(-Ri.x, t, Ri.y), yi1 = fma(-Yi.x, t, Yi.y);     // column k + 1 after column k
-        const double w0 = Ri.x * r0, w1 = ai1 * r1, v0 = Yi.x * r0, v1 = yi1 * r1;
-        const bool behind = q > qs, own = q == qs;
-#pragma unroll
-        for (int u = u0; u < 16; ++u) {
-            const double aj1 = fma(-Rj[u].x, t, Rj[u].y);
-            const double rn = fma(-w1, aj1, fma(-w0, Rj[u].x, reg[u]));
-            const double yn = fma(-v1, aj1, fma(-v0, Rj[u].x, y[u]));
-            if (u >= u0 + 2) {
-                reg[u] = rn;
-                y[u] = yn;
-            } else if (u == u0) {       // registers of the current pair: columns behind the step's in the waves after qs
-                reg[u] = behind ? rn : reg[u];
-                y[u] = behind ? yn : y[u];
-            } else {                    // the finished column k + 1 stays in its owner's registers, unscaled
-                reg[u] = behind ? rn : (own ? ai1 : reg[u]);
-                y[u] = behind ? yn : (own ? yi1 : y[u]);
-            }
-            if (s + 1 < NB / 2 && u == un + 1 && q == qn) {     // the next pair leaves as soon as it is complete
-                rawA[buf ^ 1][i] = make_double2(reg[un], reg[un + 1]);
-                rawY[buf ^ 1][i] = make_double2(y[un], y[un + 1]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        __syncthreads();
-    }
-    // pivots = the unscaled diagonal entries; their square roots and reciprocal square roots, once
-#pragma unroll
-    for (int u = 0; u < 16; ++u)
-        if (8 * (u >> 1) + 2 * q + (u & 1) == i) piv[i] = reg[u];
-    __syncthreads();
-    if (tid < NB) {
-        const double p = piv[tid];
-        const double inv = fast_rsqrt(p);
-        double d = p * inv;
-        d = fma(0.5 * inv, fma(-d, d, p), d);
-        invs[tid] = inv;
-        dsq[tid] = d;
-        const unsigned long long bad = __ballot(!(p > 0.0));
-        if (bad && tid == 0) atomicCAS(info, 0, (int)(k0 + __ffsll((long long)bad)));
-    }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-        const int j = 8 * (u >> 1) + 2 * q + (u & 1);
-        const double sc = invs[j];
-        Ls[i][j] = (j < i) ? reg[u] * sc : (j == i ? dsq[i] : 0.0);
-        Xs[j][i] = y[u] * sc;
-    }
-    __syncthreads();
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-        const int rr = idx >> 6, cc = idx & 63;
-        if (cc <= rr) A[(k0 + rr) * ld + k0 + cc] = Ls[rr][cc];
-        Linv[idx] = Xs[rr][cc];
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // Panel factorisation.
 //
@@ -413,6 +288,161 @@ __device__ __forceinline__ void stage_block(const double *__restrict__ g, int64_
     double2 st[8];
     block_fetch(g, pitch, st, tid);
     block_put(sm, st, tid);
+}
+
+// L_kk = chol(A_kk) in place and Linv = L_kk^-1 (64 x 64, row-major), one workgroup of four waves.
+//
+// What a column costs here is not arithmetic but the trip of the finished column from the wave that owns it to the
+// other three (LDS write, barrier, LDS read: about 440 cycles, measured) and the chain of dependent instructions from
+// the pivot to the next column.  So the kernel takes TWO columns per barrier, and keeps square roots and divisions off
+// the chain: the columns stay unscaled (a_ik as the elimination leaves it; L_ik = a_ik / sqrt(d_k) is formed once, at
+// the end), the update of a later entry is a_ij -= a_ik a_jk / d_k, the reciprocal of the second pivot of a pair comes
+// from the determinant of the 2 x 2 pivot block (d_k' = det / d_k), so that both reciprocals start at once.
+// The inverse rides along: the 64 rows of the identity go through the same column operations as the rows of A
+// (row i of Y = I L^-T, i.e. column i of the inverse), two more multiply-adds per entry and step instead of a
+// separate substitution phase (which took a third of the kernel before).
+// Thread (row i = tid % 64, wave q = tid / 64) keeps, of row i of A and of row i of Y, the columns
+// j(u) = 8 (u / 2) + 2 q + (u & 1), u = 0..15: pairs of neighbouring columns dealt out to the waves in turn.
+// Entries above the diagonal are never used as inputs (they may hold anything, NaN included): what is computed from
+// them stays above the diagonal.
+constexpr int POTRF_LDS_DOUBLES = 2 * NB * (NB + 1) + 2 * 2 * 2 * NB + 3 * NB;
+//
+// with_prev (a block-tridiagonal chain: block row k holds nothing left of block k - 1): the kernel first does what
+// two launches of their own do otherwise, L_k,k-1 = A_k,k-1 L_k-1,k-1^-T (stored) and A_kk -= L_k,k-1 L_k,k-1^T (kept in
+// LDS for the factorisation), a wave per strip of 16 rows on the matrix cores; Linv - 4096 is the inverse the launch
+// for block k - 1 left.
+__global__ void __launch_bounds__(256) k_potrf64(double *__restrict__ A, int64_t ld, int64_t k0, double *__restrict__ Linv,
+                                                 int *__restrict__ info, int64_t chain_rows, int with_prev) {
+    extern __shared__ double sm[];
+    k0 += blockIdx.y * chain_rows;                      // workgroup y: the same block of chain y
+    Linv += blockIdx.y * chain_rows * NB;
+    double(*Ls)[NB + 1] = (double(*)[NB + 1])sm;                      // the block on its way in and out
+    double(*Xs)[NB + 1] = (double(*)[NB + 1])(sm + NB * (NB + 1));    // the inverse on its way out
+    double2(*rawA)[NB] = (double2(*)[NB])(sm + 2 * NB * (NB + 1));    // [step & 1][row]: the step's two columns of A
+    double2(*rawY)[NB] = rawA + 2;                                    // ... and of Y
+    double *piv = (double *)(rawY + 2), *invs = piv + NB, *dsq = invs + NB;
+    const int tid = threadIdx.x, i = tid & 63, q = tid >> 6;
+    if (with_prev) {
+        const int lane = tid & 63, w = tid >> 6;
+        double *patch = sm + NB * LP + w * 16 * TP;     // (operand block and patches lie inside the kernel's own LDS)
+        double *prev = A + (k0 + 16 * w) * ld + k0 - NB, *mine = A + (k0 + 16 * w) * ld + k0;
+        double t0[16], t1[16], b[16], acc[16], d[16];
+        strip_request(prev, ld, t0, lane);
+        strip_request(mine, ld, t1, lane);
+        stage_block(Linv - NB * NB, NB, sm, tid);
+        strip_from_rows(t0, patch, b, lane);
+        strip_from_rows(t1, patch, d, lane);
+        lds_barrier();
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.0;
+        strip_mma(sm, b, acc, lane);                    // this strip of L_k,k-1
+        lds_barrier();                                  // every wave has read the inverse
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sm[(16 * w + (lane & 15)) * LP + 4 * e + (lane >> 4)] = acc[e];
+        strip_store_lds(prev, ld, patch, acc, lane);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = -acc[e];
+        lds_barrier();                                  // L_k,k-1 stands in LDS, whole
+        strip_mma(sm, acc, d, lane);                    // A_kk - L_k,k-1 L_k,k-1^T, this strip
+        __syncthreads();                                // ... and nobody reads it any more: the block takes its place
+#pragma unroll
+        for (int e = 0; e < 16; ++e) Ls[16 * w + (lane & 15)][4 * e + (lane >> 4)] = d[e];
+    } else {
+        double2 tmp[8];
+        const int r0 = tid >> 5, c0 = 2 * (tid & 31);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) tmp[m] = *(const double2 *)(A + (k0 + r0 + 8 * m) * ld + k0 + c0);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            Ls[r0 + 8 * m][c0] = tmp[m].x;
+            Ls[r0 + 8 * m][c0 + 1] = tmp[m].y;
+        }
+    }
+    __syncthreads();
+    double reg[16], y[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int j = 8 * (u >> 1) + 2 * q + (u & 1);
+        reg[u] = Ls[i][j];
+        y[u] = (j == i) ? 1.0 : 0.0;
+    }
+    if (q == 0) {
+        rawA[0][i] = make_double2(reg[0], reg[1]);
+        rawY[0][i] = make_double2(y[0], y[1]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < NB / 2; ++s) {
+        // columns k, k + 1, owned by wave qs in its registers u0, u0 + 1; the next pair belongs to wave qn
+        const int k = 2 * s, qs = s & 3, u0 = 2 * (s >> 2), buf = s & 1;
+        const int qn = (s + 1) & 3, un = 2 * ((s + 1) >> 2);
+        // every read of the step goes out right behind the barrier (left to itself the compiler sinks them to their
+        // uses, one LDS latency after the other)
+        const double2 P = rawA[buf][k], Q = rawA[buf][k + 1];       // pivot block: P.x = d_k, Q = (a_k+1,k , a_k+1,k+1)
+        const double2 Ri = rawA[buf][i], Yi = rawY[buf][i];
+        double2 Rj[16];
+#pragma unroll
+        for (int u = u0; u < 16; ++u) Rj[u] = rawA[buf][8 * (u >> 1) + 2 * q + (u & 1)];
+        __builtin_amdgcn_sched_barrier(0);
+        const double det = fma(P.x, Q.y, -(Q.x * Q.x));
+        const double r0 = rcp_cubic(P.x);           // 1 / d_k
+        const double r1 = P.x * rcp_cubic(det);     // 1 / d_k+1
+        const double t = Q.x * r0;
+        const double ai1 = fma(-Ri.x, t, Ri.y), yi1 = fma(-Yi.x, t, Yi.y);     // column k + 1 after column k
+        const double w0 = Ri.x * r0, w1 = ai1 * r1, v0 = Yi.x * r0, v1 = yi1 * r1;
+        const bool behind = q > qs, own = q == qs;
+#pragma unroll
+        for (int u = u0; u < 16; ++u) {
+            const double aj1 = fma(-Rj[u].x, t, Rj[u].y);
+            const double rn = fma(-w1, aj1, fma(-w0, Rj[u].x, reg[u]));
+            const double yn = fma(-v1, aj1, fma(-v0, Rj[u].x, y[u]));
+            if (u >= u0 + 2) {
+                reg[u] = rn;
+                y[u] = yn;
+            } else if (u == u0) {       // registers of the current pair: columns behind the step's in the waves after qs
+                reg[u] = behind ? rn : reg[u];
+                y[u] = behind ? yn : y[u];
+            } else {                    // the finished column k + 1 stays in its owner's registers, unscaled
+                reg[u] = behind ? rn : (own ? ai1 : reg[u]);
+                y[u] = behind ? yn : (own ? yi1 : y[u]);
+            }
+            if (s + 1 < NB / 2 && u == un + 1 && q == qn) {     // the next pair leaves as soon as it is complete
+                rawA[buf ^ 1][i] = make_double2(reg[un], reg[un + 1]);
+                rawY[buf ^ 1][i] = make_double2(y[un], y[un + 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+    }
+    // pivots = the unscaled diagonal entries; their square roots and reciprocal square roots, once
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+        if (8 * (u >> 1) + 2 * q + (u & 1) == i) piv[i] = reg[u];
+    __syncthreads();
+    if (tid < NB) {
+        const double p = piv[tid];
+        const double inv = fast_rsqrt(p);
+        double d = p * inv;
+        d = fma(0.5 * inv, fma(-d, d, p), d);
+        invs[tid] = inv;
+        dsq[tid] = d;
+        const unsigned long long bad = __ballot(!(p > 0.0));
+        if (bad && tid == 0) atomicCAS(info, 0, (int)(k0 + __ffsll((long long)bad)));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int j = 8 * (u >> 1) + 2 * q + (u & 1);
+        const double sc = invs[j];
+        Ls[i][j] = (j < i) ? reg[u] * sc : (j == i ? dsq[i] : 0.0);
+        Xs[j][i] = y[u] * sc;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < NB * NB; idx += 256) {
+        const int rr = idx >> 6, cc = idx & 63;
+        if (cc <= rr) A[(k0 + rr) * ld + k0 + cc] = Ls[rr][cc];
+        Linv[idx] = Xs[rr][cc];
+    }
 }
 
 // Inside the diagonal block of a panel (64 nbk columns from p0), after potrf64 of its block kb: the blocks below it
@@ -1372,6 +1402,12 @@ static int solve_impl(int64_t n, int64_t ld, double *S, double *rhs, const int *
             // that lies in them are needed when the chains are finished, not before: they run on a second stream, in
             // the order of the panels, beside the chain of diagonal blocks.
             const bool ahead = L && look_ahead;
+            // Block-tridiagonal chains (a band one block wide): the diagonal-block kernel itself takes block (k, k - 1)
+            // through the inverse before it and updates its own block (with_prev), so the chain of a chain is one launch
+            // per block - no launches for the blocks below inside the panel, none for the chain's next rows behind it.
+            bool tridiagonal = ahead && L->bw == 1 && !getenv("BA_CHOL_NO_FUSED_DIAG");
+            if (tridiagonal)
+                for (int64_t l = 0; l < L->s; ++l) tridiagonal = tridiagonal && L->chain_first[l] >= std::max<int64_t>(l - 1, 0);
             // tiles of the region C[c0.., c0 .. c_end): lower triangle of the first tile columns, whole rows below
             // which: 0 every tile; with look-ahead 1 = the tiles of the chain's own rows (caller's stream), 2 = the others
             // (second stream)
@@ -1408,7 +1444,34 @@ static int solve_impl(int64_t n, int64_t ld, double *S, double *rhs, const int *
                 else if (nbk == 2) hipLaunchKernelGGL(k_panel_rows<2>, grid, dim3(256), lds_rows, sq, S, ld, p0, Li, sel, l_begin);
                 else hipLaunchKernelGGL(k_panel_rows<1>, grid, dim3(256), lds_rows, sq, S, ld, p0, Li, sel, l_begin);
             };
-            for (int64_t o0 = begin; o0 < end; o0 += OB) {
+            if (tridiagonal) {
+                int64_t prev_p0 = -1, prev_pw = 0;      // the panel whose update on the second stream is still to be queued
+                for (int64_t p0 = begin; p0 < end; p0 += PB) {
+                    const int64_t pw = (end - p0 < PB) ? end - p0 : PB;
+                    const int nbk = (int)(pw / NB);
+                    double *Li = Linv + (p0 / NB) * NB * NB;
+                    for (int kb = 0; kb < nbk; ++kb) {
+                        hipLaunchKernelGGL(k_potrf64, dim3(1, n_chains), dim3(256), sizeof(double) * POTRF_LDS_DOUBLES, q, S, ld,
+                                           p0 + NB * kb, Li + (int64_t)kb * NB * NB, info, chain_rows, p0 + NB * kb > begin ? 1 : 0);
+                        if (kb == 0 && prev_p0 >= 0) {
+                            // the panel before: its update reads block (this panel's first, that panel's last) of L,
+                            // which the launch above has just stored
+                            hipEventRecord(ws.ev_rows, q);
+                            hipStreamWaitEvent(ws.aux, ws.ev_rows, 0);
+                            trailing(prev_p0, prev_pw, prev_p0 + prev_pw, 2 * ld, 2);
+                        }
+                    }
+                    RowSel sel;
+                    const int slabs = (int)select_rows((p0 + pw - 1) / NB - origin, (p0 + pw) / NB - origin, 1, L, dense, sel);
+                    const int band = std::min(sel.n1, slabs);
+                    hipEventRecord(ws.ev_diag, q);
+                    hipStreamWaitEvent(ws.aux, ws.ev_diag, 0);
+                    rows_launch(ws.aux, nbk, p0, Li, sel, band, slabs - band);
+                    prev_p0 = p0, prev_pw = pw;
+                }
+                trailing(prev_p0, prev_pw, prev_p0 + prev_pw, 2 * ld, 2);
+            }
+            for (int64_t o0 = begin; o0 < end && !tridiagonal; o0 += OB) {
                 const int64_t o_end = (end - o0 < OB) ? end : o0 + OB;
                 for (int64_t p0 = o0; p0 < o_end; p0 += PB) {
                     const int64_t pw = (o_end - p0 < PB) ? o_end - p0 : PB;
@@ -1416,7 +1479,7 @@ static int solve_impl(int64_t n, int64_t ld, double *S, double *rhs, const int *
                     double *Li = Linv + (p0 / NB) * NB * NB;
                     for (int kb = 0; kb < nbk; ++kb) {
                         hipLaunchKernelGGL(k_potrf64, dim3(1, n_chains), dim3(256), sizeof(double) * POTRF_LDS_DOUBLES, q, S, ld,
-                                           p0 + NB * kb, Li + (int64_t)kb * NB * NB, info, chain_rows);
+                                           p0 + NB * kb, Li + (int64_t)kb * NB * NB, info, chain_rows, 0);
                         const int below = nbk - 1 - kb;
                         if (below > 0) {
                             hipLaunchKernelGGL(k_diag_trsm, dim3(below, n_chains), dim3(256), lds_diag, q, S, ld, p0, kb,
