@@ -85,8 +85,8 @@ struct CholCache {
     bool guard_valid = false;       // `guard` holds `profile` (the queued form compares the caller's profile with it)
     int *result_host = nullptr, *result_dev = nullptr;      // one word of mapped host memory: verdict of the queued form
     // second stream of the chains' look-ahead (see factor() in solve_impl) and the events that tie it to the caller's
-    hipStream_t aux = nullptr;
-    hipEvent_t ev_diag = nullptr, ev_rows = nullptr, ev_join = nullptr;
+    hipStream_t aux = nullptr, aux2 = nullptr;
+    hipEvent_t ev_diag = nullptr, ev_rows = nullptr, ev_join = nullptr, ev_nc_rows = nullptr, ev_join2 = nullptr;
     int64_t n = 0, ld = 0;
     std::vector<int64_t> split;     // (first block, chains, blocks of a chain, blocks of a separator) of every level
     int clear = 0;
@@ -576,7 +576,7 @@ __global__ void __launch_bounds__(256) k_panel_rows(double *__restrict__ A, int6
 // row per lane makes every load instruction touch 64 cache lines and leaves the kernel bound by the
 // address pipeline of the vector memory unit.
 __global__ void __launch_bounds__(256, 2) k_syrk_trailing(double *__restrict__ A, int64_t ld, int64_t k0, int kw, int64_t c0,
-                                                          int64_t nct, RowSel sel, int64_t t_begin) {
+                                                          int64_t nct, RowSel sel, int64_t t_begin, int64_t bj_lo, int64_t bj_hi) {
     extern __shared__ double smem[];
     double(*As)[LDT] = (double(*)[LDT])smem;
     double(*Bs)[LDT] = (double(*)[LDT])(smem + KC * LDT);
@@ -594,6 +594,7 @@ __global__ void __launch_bounds__(256, 2) k_syrk_trailing(double *__restrict__ A
         bi = nct + (t - tri) / nct;
         bj = (t - tri) % nct;
     }
+    if (bj < bj_lo || bj >= bj_hi) return;      // (a launch can take the tiles of some tile columns only)
     const int chain = blockIdx.z;
     const int64_t i0 = c0 + sel(bi, TS, chain), j0 = c0 + sel(bj, TS, chain);     // tiles counted without the rows left out
     // With few tiles (a banded matrix) the panel's columns are split over gridDim.y workgroups per tile, kw columns
@@ -1381,6 +1382,9 @@ static int solve_impl(int64_t n, int64_t ld, double *S, double *rhs, const int *
     const bool look_ahead = chained && !getenv("BA_CHOL_NO_LOOKAHEAD");
     if (look_ahead && !ws.aux) {
         BA_HIP(hipStreamCreateWithFlags(&ws.aux, hipStreamNonBlocking));
+        BA_HIP(hipStreamCreateWithFlags(&ws.aux2, hipStreamNonBlocking));
+        BA_HIP(hipEventCreateWithFlags(&ws.ev_nc_rows, hipEventDisableTiming));
+        BA_HIP(hipEventCreateWithFlags(&ws.ev_join2, hipEventDisableTiming));
         BA_HIP(hipEventCreateWithFlags(&ws.ev_diag, hipEventDisableTiming));
         BA_HIP(hipEventCreateWithFlags(&ws.ev_rows, hipEventDisableTiming));
         BA_HIP(hipEventCreateWithFlags(&ws.ev_join, hipEventDisableTiming));
@@ -1410,7 +1414,9 @@ static int solve_impl(int64_t n, int64_t ld, double *S, double *rhs, const int *
                 for (int64_t l = 0; l < L->s; ++l) tridiagonal = tridiagonal && L->chain_first[l] >= std::max<int64_t>(l - 1, 0);
             // tiles of the region C[c0.., c0 .. c_end): lower triangle of the first tile columns, whole rows below
             // which: 0 every tile; with look-ahead 1 = the tiles of the chain's own rows (caller's stream), 2 = the others
-            // (second stream)
+            // (second stream), or those in two launches: 3 = the tiles of separators' and border's rows in the chain's
+            // columns (second stream: the next panel's rows kernel reads them), 4 = in their own columns (third stream:
+            // nothing reads them before the chains are finished)
             auto trailing = [&](int64_t k_first, int64_t kw, int64_t c0, int64_t c_end, int which) {
                 if (c0 >= ld || c_end <= c0) return;
                 RowSel sel;
@@ -1419,21 +1425,26 @@ static int solve_impl(int64_t n, int64_t ld, double *S, double *rhs, const int *
                 while (nct < nt && sel(nct, TS, 0) < c_end - c0) ++nct;
                 if (nct == 0) return;
                 const int64_t tiles = nct * (nct + 1) / 2 + (nt - nct) * nct;
-                auto launch = [&](hipStream_t sq, int64_t t_begin, int64_t count) {
-                    if (count <= 0) return;
+                auto launch = [&](hipStream_t sq, int64_t t_begin, int64_t count, int64_t bj_lo, int64_t bj_hi, int64_t active) {
+                    if (count <= 0 || active <= 0) return;
                     int split = 1;      // workgroups per tile: as long as the launch stays within one round of the chip
-                    while (count * n_chains * split * 2 <= split_limit && kw % (split * 2 * NB) == 0) split *= 2;
+                    while (active * n_chains * split * 2 <= split_limit && kw % (split * 2 * NB) == 0) split *= 2;
                     hipLaunchKernelGGL(k_syrk_trailing, dim3((unsigned)count, (unsigned)split, (unsigned)n_chains), dim3(256),
-                                       lds_trailing, sq, S, ld, k_first, (int)(kw / split), c0, nct, sel, t_begin);
+                                       lds_trailing, sq, S, ld, k_first, (int)(kw / split), c0, nct, sel, t_begin, bj_lo, bj_hi);
                 };
+                const int64_t all = (int64_t)1 << 40;
                 if (which == 0) {
-                    launch(q, 0, tiles);
+                    launch(q, 0, tiles, 0, all, tiles);
                 } else {
                     // tiles are counted row by row: those of the chain's own rows come first
                     const int64_t band = std::min<int64_t>(sel.n1, nt);
                     const int64_t own = band <= nct ? band * (band + 1) / 2 : nct * (nct + 1) / 2 + (band - nct) * nct;
-                    if (which == 1) launch(q, 0, own);
-                    else launch(ws.aux, own, tiles - own);
+                    const int64_t rest_rows = nt - band;     // tile rows of separators and border
+                    const int64_t in_band_cols = rest_rows * std::min(band, nct);
+                    if (which == 1) launch(q, 0, own, 0, all, own);
+                    else if (which == 2) launch(ws.aux, own, tiles - own, 0, all, tiles - own);
+                    else if (which == 3) launch(ws.aux, own, tiles - own, 0, band, in_band_cols);               // in the chain's columns
+                    else launch(ws.aux2, own, tiles - own, band, all, tiles - own - in_band_cols);              // in their own
                 }
             };
             auto rows_launch = [&](hipStream_t sq, int nbk, int64_t p0, const double *Li, const RowSel &sel, int l_begin, int count) {
@@ -1445,6 +1456,12 @@ static int solve_impl(int64_t n, int64_t ld, double *S, double *rhs, const int *
                 else hipLaunchKernelGGL(k_panel_rows<1>, grid, dim3(256), lds_rows, sq, S, ld, p0, Li, sel, l_begin);
             };
             if (tridiagonal) {
+                // With many chains the second stream has more to do per panel than the chain of diagonal blocks: the
+                // tiles nothing reads before the chains are finished (separators' and border's rows in their own columns)
+                // go to a third stream then.  (With 14 chains that made the chain's kernels slower than it saved:
+                // 2.20 -> 2.27 ms per LM iteration at 2 000 cameras; with 48 chains 5.23 -> 5.12 ms at 20 000.)
+                const char *sides = getenv("BA_CHOL_SIDE_STREAMS");
+                const bool two_side = sides ? atoi(sides) > 1 : L->P > 24;
                 int64_t prev_p0 = -1, prev_pw = 0;      // the panel whose update on the second stream is still to be queued
                 for (int64_t p0 = begin; p0 < end; p0 += PB) {
                     const int64_t pw = (end - p0 < PB) ? end - p0 : PB;
@@ -1458,7 +1475,7 @@ static int solve_impl(int64_t n, int64_t ld, double *S, double *rhs, const int *
                             // which the launch above has just stored
                             hipEventRecord(ws.ev_rows, q);
                             hipStreamWaitEvent(ws.aux, ws.ev_rows, 0);
-                            trailing(prev_p0, prev_pw, prev_p0 + prev_pw, 2 * ld, 2);
+                            trailing(prev_p0, prev_pw, prev_p0 + prev_pw, 2 * ld, two_side ? 3 : 2);
                         }
                     }
                     RowSel sel;
@@ -1467,9 +1484,16 @@ static int solve_impl(int64_t n, int64_t ld, double *S, double *rhs, const int *
                     hipEventRecord(ws.ev_diag, q);
                     hipStreamWaitEvent(ws.aux, ws.ev_diag, 0);
                     rows_launch(ws.aux, nbk, p0, Li, sel, band, slabs - band);
+                    if (two_side) {
+                        hipEventRecord(ws.ev_nc_rows, ws.aux);
+                        hipStreamWaitEvent(ws.aux2, ws.ev_nc_rows, 0);
+                        trailing(p0, pw, p0 + pw, 2 * ld, 4);
+                    }
                     prev_p0 = p0, prev_pw = pw;
                 }
-                trailing(prev_p0, prev_pw, prev_p0 + prev_pw, 2 * ld, 2);
+                trailing(prev_p0, prev_pw, prev_p0 + prev_pw, 2 * ld, two_side ? 3 : 2);
+                hipEventRecord(ws.ev_join2, ws.aux2);
+                hipStreamWaitEvent(q, ws.ev_join2, 0);
             }
             for (int64_t o0 = begin; o0 < end && !tridiagonal; o0 += OB) {
                 const int64_t o_end = (end - o0 < OB) ? end : o0 + OB;

@@ -1,6 +1,8 @@
 """Wall time of whole LM iterations (lm.LMFit) at cfg3 / cfg5 sizes: lm_loop.py [K] [N] [iterations]"""
 import importlib, os, sys, time, numpy as np
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '.'))
+if os.environ.get('BA_LIB'):
+    importlib.import_module('3d_reconstruction_amd._lib').LIB_PATH = os.path.abspath(os.environ['BA_LIB'])
 import torch
 ba = importlib.import_module('3d_reconstruction_amd')
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
