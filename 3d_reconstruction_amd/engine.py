@@ -664,7 +664,7 @@ class Shard:
         check(self.lib.ba_build_camera_table(self.handle, c, c + K24, c + 2 * K24, self.stream))
         self._table_cam = cam
 
-    def eval_jtj(self, timed=False, point_major=False, dense_blocks=False):
+    def eval_jtj(self, timed=False, point_major=False, dense_blocks=False, post=False):
         """Fused pass that also leaves the Gauss-Newton blocks V (this shard's points) and
         B, bphi, hphi (summed over the GPUs together with the gradient block)."""
         self._lm_buffers()
@@ -680,6 +680,8 @@ class Shard:
         if self.distributed:
             self._sum_over_ranks(self.red)
             self._sum_over_ranks(self.jred)
+        if post:        # the energy also goes to the host mailbox (wait_energy picks it up without a copy or a stream wait)
+            check(self.lib.ba_post_energy(self.handle, self._out_ptrs[0], self.stream))
 
     def lm_pivot(self):
         """Verdict of the last lm_step(wait=False), once the stream has been waited for (an energy read-back does):

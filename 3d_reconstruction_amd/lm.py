@@ -48,8 +48,8 @@ class LMFit:
         sh = self.sh
         self.stamps = [time.perf_counter()]
         sh.gauge_fix()
-        sh.eval_jtj()
-        E = sh.energy()
+        sh.eval_jtj(post=True)
+        E = sh.wait_energy()
         self.stamps.append(time.perf_counter())
         self.E[0] = E
         it = 0
@@ -72,8 +72,8 @@ class LMFit:
             sh.adopt(sh.X_trial, sh.cam_trial)
             sh.gauge_fix()                  # in place on the trial tensors
             sh.swap_evaluation()
-            sh.eval_jtj()
-            E_new = sh.energy()
+            sh.eval_jtj(post=True)
+            E_new = sh.wait_energy()        # (from the host mailbox: no copy, no wait for the stream)
             pivot = sh.lm_pivot() if queued else 0
             if pivot != 0:
                 sh.restore(kept)
