@@ -125,7 +125,45 @@ __global__ void __launch_bounds__(64) k_radix_hist(const int *__restrict__ key, 
     for (int d = lane; d < 256; d += 64) hist[(int64_t)d * n_blocks + blockIdx.x] = cnt[d];
 }
 
-// exclusive scan of an int array by one workgroup (the digit-major histogram: 256 x blocks entries)
+// Exclusive scan of the digit-major histogram (256 x blocks entries; 1.25 M at ten million items), three launches: a
+// scan per 4096 entries, the scan of the block sums by one workgroup (k_scan_int_single), their addition.
+constexpr int S32_ITEMS = 16, S32_BLOCK = 256, S32_TILE = S32_ITEMS * S32_BLOCK;
+
+__global__ void __launch_bounds__(S32_BLOCK) k_scan_int_blocks(int *__restrict__ a, int64_t n, int *__restrict__ block_sums) {
+    __shared__ int wsum[S32_BLOCK / 64];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int64_t base = (int64_t)blockIdx.x * S32_TILE + (int64_t)threadIdx.x * S32_ITEMS;
+    int v[S32_ITEMS], s = 0;
+#pragma unroll
+    for (int k = 0; k < S32_ITEMS; ++k) {
+        v[k] = base + k < n ? a[base + k] : 0;
+        s += v[k];
+    }
+    int inc = s;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int u = __shfl_up(inc, off);
+        if (lane >= off) inc += u;
+    }
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    int before = 0;
+    for (int w = 0; w < wid; ++w) before += wsum[w];
+    int ex = before + inc - s;
+#pragma unroll
+    for (int k = 0; k < S32_ITEMS; ++k) {
+        if (base + k < n) a[base + k] = ex;
+        ex += v[k];
+    }
+    if (threadIdx.x == S32_BLOCK - 1) block_sums[blockIdx.x] = ex;
+}
+
+__global__ void k_scan_int_add(int *__restrict__ a, int64_t n, const int *__restrict__ block_sums) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) a[t] += block_sums[t / S32_TILE];
+}
+
+// exclusive scan of an int array by one workgroup
 __global__ void __launch_bounds__(1024) k_scan_int_single(int *a, int64_t n) {
     __shared__ int wsum[16];
     __shared__ int carry_s;
@@ -289,14 +327,28 @@ struct DeviceBuffers {      // frees what it holds when the call returns, whiche
     }
 };
 
+// ints of the histogram buffer of a sort of n items: the histogram and the block sums of its scan
+size_t radix_hist_ints(int64_t n) {
+    const size_t h = (size_t)256 * blocks_of(n, RS_ITEMS);
+    return h + blocks_of((int64_t)h, S32_TILE);
+}
+
 // Stable sort of the pairs (key[cur], val[cur]) by the low `bits` bits of the keys; returns the index of the buffer
-// pair that holds the result.  hist: 256 x blocks_of(n, RS_ITEMS) ints.
+// pair that holds the result.  hist: radix_hist_ints(n) ints.
 int radix_sort_pairs(int64_t n, int *key[2], int *val[2], int *hist, int bits, hipStream_t st) {
     const int n_blocks = (int)blocks_of(n, RS_ITEMS);
+    const int64_t n_hist = (int64_t)256 * n_blocks, scan_blocks = blocks_of(n_hist, S32_TILE);
+    int *block_sums = hist + n_hist;
     int cur = 0;
     for (int shift = 0; shift < bits; shift += 8) {
         hipLaunchKernelGGL(k_radix_hist, dim3(n_blocks), dim3(64), 0, st, key[cur], n, shift, hist, n_blocks);
-        hipLaunchKernelGGL(k_scan_int_single, dim3(1), dim3(1024), 0, st, hist, (int64_t)256 * n_blocks);
+        if (scan_blocks <= 1) {
+            hipLaunchKernelGGL(k_scan_int_single, dim3(1), dim3(1024), 0, st, hist, n_hist);
+        } else {
+            hipLaunchKernelGGL(k_scan_int_blocks, dim3((unsigned)scan_blocks), dim3(S32_BLOCK), 0, st, hist, n_hist, block_sums);
+            hipLaunchKernelGGL(k_scan_int_single, dim3(1), dim3(1024), 0, st, block_sums, scan_blocks);
+            hipLaunchKernelGGL(k_scan_int_add, dim3((unsigned)blocks_of(n_hist, 256)), dim3(256), 0, st, hist, n_hist, block_sums);
+        }
         hipLaunchKernelGGL(k_radix_scatter, dim3(n_blocks), dim3(64), 0, st, key[cur], val[cur], n, shift, hist, n_blocks,
                            key[cur ^ 1], val[cur ^ 1]);
         cur ^= 1;
@@ -391,7 +443,7 @@ int ba_order_points_by_first_camera(int64_t N, int64_t K, int64_t nV, const int3
     BA_HIP(buf.get(&key[1], (size_t)N));
     BA_HIP(buf.get(&val[1], (size_t)N));
     int *hist = nullptr;
-    BA_HIP(buf.get(&hist, (size_t)256 * blocks_of(N, RS_ITEMS)));
+    BA_HIP(buf.get(&hist, radix_hist_ints(N)));
     const int cur = radix_sort_pairs(N, key, val, hist, bits_for(K), st);      // keys 0 .. K
     BA_HIP(hipMemcpyAsync(perm, val[cur], sizeof(int) * N, hipMemcpyDeviceToDevice, st));
 
@@ -428,7 +480,7 @@ int ba_argsort_by_camera(int64_t nV, int64_t N, int64_t K, const int32_t *i, con
         BA_HIP(buf.get(&key[b], (size_t)nV));
         BA_HIP(buf.get(&val[b], (size_t)nV));
     }
-    BA_HIP(buf.get(&hist, (size_t)256 * blocks_of(nV, RS_ITEMS)));
+    BA_HIP(buf.get(&hist, radix_hist_ints(nV)));
     BA_HIP(buf.get(&flag, 1));
     BA_HIP(hipMemsetAsync(flag, 0, sizeof(int), st));
     // is the list already in point order?  then one stable sort by camera gives (camera, point ascending)

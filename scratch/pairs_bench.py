@@ -1,7 +1,8 @@
 """Timing of the camera-pair homography kernel at cfg3 size (1 M points, 2 k cameras, 10 M observations)."""
 import importlib, sys, time
 import numpy as np, torch
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '.'))
 ba = importlib.import_module('3d_reconstruction_amd')
 sc = ba.scenes.orbit_scene(1_000_000, 2000, track_len=10, seed=0)
 print('obs', sc['i'].size, flush=True)
