@@ -49,6 +49,8 @@ SIGNATURES = {
     'ba_cholesky_solve_queued': (_int, [_i64, _i64, _p, _p, _p, _int, _p]),
     'ba_cholesky_queued_result': (_int, [C.POINTER(_int)]),
     'ba_cholesky_last_plan': (_int, [C.POINTER(_i64), _int, C.POINTER(_int)]),
+    'ba_schur_envelope': (_int, [_i64, _p, _p, C.POINTER(_i64), _p]),
+    'ba_schur_envelope_copy': (_int, [_i64, _p, _p, _p, _i64, _p, _int, _p]),
     'ba_backsubstitute': (_int, [_p, _p, _dbl, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'ba_build_camera_table': (_int, [_p, _p, _p, _p, _p]),
     'ba_can_fuse_update': (_int, [_p]),

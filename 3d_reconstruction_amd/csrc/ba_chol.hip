@@ -983,6 +983,55 @@ __global__ void __launch_bounds__(256) k_back_chains(const double *__restrict__ 
 
 using namespace ba;
 
+// ---- the occupied blocks of S as one contiguous buffer (what several GPUs add up instead of the whole matrix) ----
+// offsets[ib] = number of 64-blocks in the block rows before ib, block row ib holding the blocks first[ib] .. ib
+__global__ void k_envelope_offsets(const int *__restrict__ first, int64_t nb, int64_t *__restrict__ offsets) {
+    __shared__ int64_t wsum[16];
+    __shared__ int64_t carry_s;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < nb; base += 1024) {
+        const int64_t t = base + threadIdx.x;
+        const int64_t v = t < nb ? t - first[t] + 1 : 0;
+        int64_t inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int64_t u = __shfl_up(inc, off);
+            if (lane >= off) inc += u;
+        }
+        if (lane == 63) wsum[wid] = inc;
+        __syncthreads();
+        int64_t before = carry_s;
+        for (int w = 0; w < wid; ++w) before += wsum[w];
+        if (t < nb) offsets[t] = before + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = before + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) offsets[nb] = carry_s;
+}
+
+// workgroup b: block b of the envelope (block row found by bisection of the offsets) to or from packed[b][64][64]
+__global__ void __launch_bounds__(256) k_envelope_copy(double *__restrict__ S, int64_t ld, const int *__restrict__ first,
+                                                       const int64_t *__restrict__ offsets, int64_t nb,
+                                                       double *__restrict__ packed, int to_packed) {
+    const int64_t b = blockIdx.x;
+    int64_t lo = 0, hi = nb - 1;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi + 1) >> 1;
+        if (offsets[mid] <= b) lo = mid;
+        else hi = mid - 1;
+    }
+    const int64_t ib = lo, jb = first[ib] + (b - offsets[ib]);
+    double *blk = S + ib * NB * ld + jb * NB, *pk = packed + b * NB * NB;
+    for (int idx = threadIdx.x; idx < NB * NB; idx += 256) {
+        double *e = blk + (int64_t)(idx >> 6) * ld + (idx & 63);
+        if (to_packed) pk[idx] = *e;
+        else *e = pk[idx];
+    }
+}
+
 // (the two clearing steps of a call, as kernels like everything else it queues)
 __global__ void k_zero_int(int *p) { *p = 0; }
 // The queued form assumed the profile `assumed`; the matrix has `now`.  Entries left of the assumed envelope would be
@@ -1024,6 +1073,28 @@ int ba_cholesky_solve_queued(int64_t n, int64_t ld, double *S, double *rhs, cons
                              void *stream) {
     BA_REQUIRE(block_first, "ba_cholesky_solve_queued: block_first is required");
     return solve_impl(n, ld, S, rhs, block_first, clear_on_return, nullptr, stream, true);
+}
+
+int ba_schur_envelope(int64_t ld, const int *block_first, int64_t *offsets, int64_t *h_blocks, void *stream) {
+    BA_REQUIRE(ld > 0 && ld % NB == 0 && block_first && offsets && h_blocks, "ba_schur_envelope: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t nb = ld / NB;
+    hipLaunchKernelGGL(k_envelope_offsets, dim3(1), dim3(1024), 0, st, block_first, nb, offsets);
+    BA_HIP(hipGetLastError());
+    BA_HIP(hipMemcpyAsync(h_blocks, offsets + nb, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    BA_HIP(hipStreamSynchronize(st));
+    return BA_OK;
+}
+
+int ba_schur_envelope_copy(int64_t ld, double *S, const int *block_first, const int64_t *offsets, int64_t blocks,
+                           double *packed, int to_packed, void *stream) {
+    BA_REQUIRE(ld > 0 && ld % NB == 0 && S && block_first && offsets && packed && blocks >= 0,
+               "ba_schur_envelope_copy: bad argument");
+    if (blocks > 0)
+        hipLaunchKernelGGL(k_envelope_copy, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, S, ld, block_first,
+                           offsets, ld / NB, packed, to_packed);
+    BA_HIP(hipGetLastError());
+    return BA_OK;
 }
 
 int ba_cholesky_last_plan(int64_t *levels, int capacity, int *n_levels) {

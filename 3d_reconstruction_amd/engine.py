@@ -724,9 +724,22 @@ class Shard:
                                               ptr(self.gTheta), ptr(self.gphi), first, ptr(self.S), ptr(self.rhs),
                                               ptr(self.S_first), int(S_is_zero), self.stream))
         if self.distributed:
-            self._sum_over_ranks(self.S)
-            self._sum_over_ranks(self.rhs)
+            # what the ranks add up is the envelope of S (the blocks from every block row's first occupied one to the
+            # diagonal, by the profile all ranks agree on), not the matrix: 48 MB instead of 1.2 GB at 2 000 cameras,
+            # 0.5 GB instead of 115 GB at 20 000
             self._min_over_ranks(self.S_first)
+            nb = self.ld_red // 64
+            if getattr(self, '_env_offsets', None) is None:
+                self._env_offsets = torch.empty(nb + 1, dtype=torch.int64, device=self.device)
+            blocks = C.c_int64(0)
+            check(self.lib.ba_schur_envelope(self.ld_red, ptr(self.S_first), ptr(self._env_offsets), C.byref(blocks), self.stream))
+            packed = torch.empty(blocks.value * 4096, dtype=F64, device=self.device)
+            check(self.lib.ba_schur_envelope_copy(self.ld_red, ptr(self.S), ptr(self.S_first), ptr(self._env_offsets), blocks.value,
+                                                  ptr(packed), 1, self.stream))
+            self._sum_over_ranks(packed)
+            check(self.lib.ba_schur_envelope_copy(self.ld_red, ptr(self.S), ptr(self.S_first), ptr(self._env_offsets), blocks.value,
+                                                  ptr(packed), 0, self.stream))
+            self._sum_over_ranks(self.rhs)
         mark()
         if on_system is not None:
             on_system(self.S, self.rhs)

@@ -354,6 +354,13 @@ int ba_cholesky_solve_tracked(int64_t n, int64_t ld, double *S, double *rhs, con
 int ba_cholesky_solve_queued(int64_t n, int64_t ld, double *S, double *rhs, const int *block_first,
                              int clear_on_return, void *stream);
 int ba_cholesky_queued_result(int *h_info);
+/* Several GPUs add up S.  Only its envelope holds anything (block row ib: the 64-blocks block_first[ib] .. ib, with
+ * block_first the minimum over the ranks of what ba_schur_build_tracked reported), so that is what travels:
+ * ba_schur_envelope: offsets[ld / 64 + 1] (device) = blocks before every block row; *h_blocks = their total (waits).
+ * ba_schur_envelope_copy: the envelope's blocks to packed[blocks][64][64] (to_packed != 0) or back into S. */
+int ba_schur_envelope(int64_t ld, const int *block_first, int64_t *offsets, int64_t *h_blocks, void *stream);
+int ba_schur_envelope_copy(int64_t ld, double *S, const int *block_first, const int64_t *offsets, int64_t blocks,
+                           double *packed, int to_packed, void *stream);
 /* How the last solve on the current device cut its band (for tests and reports): *n_levels levels of independent
  * chains, one nested behind the other's chains; levels[4 k .. 4 k + 3] = first 64-block of level k's matrix, number of
  * chains, 64-blocks per chain, 64-blocks per separator (at most `capacity` levels are written).  0 levels: the natural
