@@ -953,6 +953,20 @@ def homography_diff_matrix(oi, oj, uv, N, K, normalize=False, W=None, H=None, mi
     oi = _dev_tensor(oi, torch.int32, dev)
     oj = _dev_tensor(oj, torch.int32, dev)
     uv = _dev_tensor(uv, F64, dev).view(-1, 2)
+    # The kernel leaves a pair at once when the point ranges of its two cameras do not overlap.  That only tells pairs
+    # apart when points that are seen together are numbered together, so the points are first renumbered by their first
+    # camera (the engine's own order; the result does not depend on the numbering).  Randomly numbered points of a video
+    # with 2 000 cameras: 98 ms -> a few ms for the whole call.
+    by_point = _order_by_camera(oj, oi, K, N)    # (roles swapped: by point, cameras ascending)
+    oi, oj, uv = oi[by_point].contiguous(), oj[by_point].contiguous(), _take_rows(uv, by_point)
+    perm = torch.empty(int(N), dtype=torch.int32, device=dev)
+    new_i, new_j, new_uv = torch.empty_like(oi), torch.empty_like(oj), torch.empty_like(uv)
+    identity = C.c_int(0)
+    with torch.cuda.device(dev):
+        check(lib.ba_order_points_by_first_camera(int(N), int(K), int(oi.numel()), ptr(oi), ptr(oj), ptr(uv), ptr(perm),
+                                                  ptr(new_i), ptr(new_j), ptr(new_uv), C.byref(identity), stream_ptr()))
+    if not identity.value:
+        oi, oj, uv = new_i, new_j, new_uv
     order = _order_by_camera(oi, oj, N, K)       # by camera, points ascending
     oj_s = oj[order]
     col_ptr, _ = _ranges(oj_s, K)
