@@ -37,6 +37,7 @@ SIGNATURES = {
     'ba_visibility_components': (_int, [_i64, _i64, _i64, _p, _p, _p, C.POINTER(_i64), C.POINTER(_i64), _p]),
     'ba_order_points_by_first_camera': (_int, [_i64, _i64, _i64] + [_p] * 7 + [C.POINTER(_int), _p]),
     'ba_argsort_by_camera': (_int, [_i64, _i64, _i64, _p, _p, _p, _p]),
+    'ba_ranges_of_sorted_keys': (_int, [_i64, _i64, _p, _p, _p]),
     'ba_problem_create': (_int, [_i64, _i64, _i64, _p, _p, _p, _dbl, _dbl, _int, C.POINTER(_p)]),
     'ba_problem_destroy': (_int, [_p]),
     'ba_eval': (_int, [_p, _p, _p, _p, _p, _int, _p, _p, _p, _p, _p, _p]),

@@ -500,4 +500,11 @@ int ba_argsort_by_camera(int64_t nV, int64_t N, int64_t K, const int32_t *i, con
     return BA_OK;
 }
 
+int ba_ranges_of_sorted_keys(int64_t n, int64_t n_keys, const int32_t *keys, int64_t *ranges, void *stream) {
+    BA_REQUIRE(n >= 0 && n_keys >= 0 && (n == 0 || keys) && ranges, "ba_ranges_of_sorted_keys: bad argument");
+    hipLaunchKernelGGL(k_point_ranges, dim3(blocks_of(n + 1, 256)), dim3(256), 0, (hipStream_t)stream, keys, n, n_keys, ranges);
+    BA_HIP(hipGetLastError());
+    return BA_OK;
+}
+
 }  // extern "C"

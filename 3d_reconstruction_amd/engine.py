@@ -883,11 +883,13 @@ def _order_by_camera(oi, oj, N, K):
 
 
 def _ranges(keys, n):
-    """Offsets (int64, n + 1) of the runs of a sorted int key tensor with values in [0, n)."""
-    counts = torch.bincount(keys.to(torch.int64), minlength=n)
-    ptr = torch.zeros(n + 1, dtype=torch.int64, device=keys.device)
-    ptr[1:] = torch.cumsum(counts, 0)
-    return ptr, counts
+    """Offsets (int64, n + 1) of the runs of a sorted int32 key tensor with values in [0, n), and the run lengths
+    (ba_ranges_of_sorted_keys)."""
+    keys = keys.to(torch.int32).contiguous()
+    rp = torch.empty(n + 1, dtype=torch.int64, device=keys.device)
+    with torch.cuda.device(keys.device):
+        check(_lib.load().ba_ranges_of_sorted_keys(int(keys.numel()), int(n), ptr(keys), ptr(rp), stream_ptr()))
+    return rp, rp[1:] - rp[:-1]
 
 
 def triangulate(oi, oj, uv, N, C_, Theta, phi_x, W, H, normalize=False, device='cuda:0', row_ptr=None):

@@ -93,6 +93,9 @@ int ba_order_points_by_first_camera(int64_t N, int64_t K, int64_t nV, const int3
  * that is already sorted by point needs one sort, any other two. */
 int ba_argsort_by_camera(int64_t nV, int64_t N, int64_t K, const int32_t *i, const int32_t *j, int32_t *order,
                          void *stream);
+/* ranges[n_keys + 1]: ranges[k] .. ranges[k + 1] = the run of key k in an ascending key list (keys 0 .. n_keys - 1;
+ * row_ptr / col_ptr of the calls below from a sorted index list). */
+int ba_ranges_of_sorted_keys(int64_t n, int64_t n_keys, const int32_t *keys, int64_t *ranges, void *stream);
 
 /* ---- problem handle: the observation list of one GPU's shard (its points, all cameras).
  * Observations must be sorted by point (i non-decreasing); the arrays are copied.
