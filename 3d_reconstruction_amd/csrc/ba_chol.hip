@@ -1463,6 +1463,9 @@ static int solve_impl(int64_t n, int64_t ld, double *S, double *rhs, const int *
     // Everything the device does for this call, on stream q.
     auto issue = [&](hipStream_t q) -> hipError_t {
         hipError_t e = hipSuccess;
+        auto keep = [&](hipError_t x) {     // the first failure of the calls that tie the streams together
+            if (e == hipSuccess) e = x;
+        };
         hipLaunchKernelGGL(k_zero_int, dim3(1), dim3(1), 0, q, info);
         if (assumed)
             hipLaunchKernelGGL(k_profile_guard, dim3(cdiv_c(nb, 256)), dim3(256), 0, q, block_first, (const int *)ws.guard.p, nb, info);
@@ -1544,27 +1547,27 @@ static int solve_impl(int64_t n, int64_t ld, double *S, double *rhs, const int *
                         if (kb == 0 && prev_p0 >= 0) {
                             // the panel before: its update reads block (this panel's first, that panel's last) of L,
                             // which the launch above has just stored
-                            hipEventRecord(ws.ev_rows, q);
-                            hipStreamWaitEvent(ws.aux, ws.ev_rows, 0);
+                            keep(hipEventRecord(ws.ev_rows, q));
+                            keep(hipStreamWaitEvent(ws.aux, ws.ev_rows, 0));
                             trailing(prev_p0, prev_pw, prev_p0 + prev_pw, 2 * ld, two_side ? 3 : 2);
                         }
                     }
                     RowSel sel;
                     const int slabs = (int)select_rows((p0 + pw - 1) / NB - origin, (p0 + pw) / NB - origin, 1, L, dense, sel);
                     const int band = std::min(sel.n1, slabs);
-                    hipEventRecord(ws.ev_diag, q);
-                    hipStreamWaitEvent(ws.aux, ws.ev_diag, 0);
+                    keep(hipEventRecord(ws.ev_diag, q));
+                    keep(hipStreamWaitEvent(ws.aux, ws.ev_diag, 0));
                     rows_launch(ws.aux, nbk, p0, Li, sel, band, slabs - band);
                     if (two_side) {
-                        hipEventRecord(ws.ev_nc_rows, ws.aux);
-                        hipStreamWaitEvent(ws.aux2, ws.ev_nc_rows, 0);
+                        keep(hipEventRecord(ws.ev_nc_rows, ws.aux));
+                        keep(hipStreamWaitEvent(ws.aux2, ws.ev_nc_rows, 0));
                         trailing(p0, pw, p0 + pw, 2 * ld, 4);
                     }
                     prev_p0 = p0, prev_pw = pw;
                 }
                 trailing(prev_p0, prev_pw, prev_p0 + prev_pw, 2 * ld, two_side ? 3 : 2);
-                hipEventRecord(ws.ev_join2, ws.aux2);
-                hipStreamWaitEvent(q, ws.ev_join2, 0);
+                keep(hipEventRecord(ws.ev_join2, ws.aux2));
+                keep(hipStreamWaitEvent(q, ws.ev_join2, 0));
             }
             for (int64_t o0 = begin; o0 < end && !tridiagonal; o0 += OB) {
                 const int64_t o_end = (end - o0 < OB) ? end : o0 + OB;
@@ -1590,8 +1593,8 @@ static int solve_impl(int64_t n, int64_t ld, double *S, double *rhs, const int *
                             // the chain's own next rows at once (they start late in the panel: the sub-panel from their first
                             // column block on does); separators and border on the second stream
                             const int band = std::min(sel.n1, slabs);
-                            hipEventRecord(ws.ev_diag, q);
-                            hipStreamWaitEvent(ws.aux, ws.ev_diag, 0);
+                            keep(hipEventRecord(ws.ev_diag, q));
+                            keep(hipStreamWaitEvent(ws.aux, ws.ev_diag, 0));
                             if (band > 0) {
                                 const int64_t panel_first = p0 / NB - origin, next = (p0 + pw) / NB - origin;
                                 int fk = nbk - 1;
@@ -1599,9 +1602,9 @@ static int solve_impl(int64_t n, int64_t ld, double *S, double *rhs, const int *
                                     fk = std::min<int64_t>(fk, std::max<int64_t>(L->chain_first[next + l] - panel_first, 0));
                                 rows_launch(q, nbk - fk, p0 + (int64_t)fk * NB, Li + (int64_t)fk * NB * NB, sel, 0, band);
                             }
-                            hipEventRecord(ws.ev_rows, q);
+                            keep(hipEventRecord(ws.ev_rows, q));
                             rows_launch(ws.aux, nbk, p0, Li, sel, band, slabs - band);
-                            hipStreamWaitEvent(ws.aux, ws.ev_rows, 0);
+                            keep(hipStreamWaitEvent(ws.aux, ws.ev_rows, 0));
                         } else {
                             rows_launch(q, nbk, p0, Li, sel, 0, slabs);
                         }
@@ -1620,8 +1623,8 @@ static int solve_impl(int64_t n, int64_t ld, double *S, double *rhs, const int *
                 trailing(o0, o_end - o0, o_end, 2 * ld, ahead ? 1 : 0);
             }
             if (ahead) {
-                hipEventRecord(ws.ev_join, ws.aux);
-                hipStreamWaitEvent(q, ws.ev_join, 0);
+                keep(hipEventRecord(ws.ev_join, ws.aux));
+                keep(hipStreamWaitEvent(q, ws.ev_join, 0));
             }
         };
         if (chained) {
