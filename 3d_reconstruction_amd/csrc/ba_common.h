@@ -128,6 +128,7 @@ struct ba_problem {
     int4 *schur_sub = nullptr;
     int *schur_rest = nullptr;
     int n_schur_sub = 0, n_schur_rest = -1;
+    int schur_window = 13;        // camera slots the Gram kernel's accumulators hold for these ranges
     // timing ring
     std::vector<hipEvent_t> ev_begin, ev_end;
     int ev_count = 0;
