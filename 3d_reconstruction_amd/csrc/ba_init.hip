@@ -109,58 +109,53 @@ __device__ __forceinline__ void pivots_4x4(const double (&M)[10], double &d1, do
     d3 = piv[2];
 }
 
-// Four lanes per point: lane q of a point's quad takes its observations q, q + 4, q + 8, ... (the four lanes read four
-// consecutive records, a wave's 16 points one contiguous stretch of the list), keeps its share of the ten sums of
-// [A b]^T [A b] in registers, and the quad adds the shares up with two DPP exchanges per sum.  A track of ten
-// observations is a chain of three dependent (record, projection row) load pairs per lane instead of ten, with four
-// times as many loads in flight, and nothing is staged in LDS, so the registers alone bound the resident waves -
-// the loop is bound by that latency chain, not by arithmetic (one thread per point with the records staged in LDS:
-// 126 us at 1 M points / 10 M observations in random point order, 90 us in the engine's order; this form 94 / 83 us.
-// Measured on top of it and dropped: the rows of a workgroup's camera window staged in LDS (100 us), and four rounds
-// of sixteen points per wave so that the rank test and the solve run on all lanes instead of one in four (87 / 100)).
-__device__ __forceinline__ double quad_sum(double v) {
-    {
-        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xB1, 0xf, 0xf, false);     // quad_perm [1,0,3,2]
-        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xB1, 0xf, 0xf, false);
-        v += __hiloint2double(hi, lo);
-    }
-    {
-        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x4E, 0xf, 0xf, false);     // quad_perm [2,3,0,1]
-        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x4E, 0xf, 0xf, false);
-        v += __hiloint2double(hi, lo);
-    }
-    return v;
-}
-
+// LPP lanes per point: lane q of a point's group takes its observations q, q + LPP, q + 2 LPP, ... (the group reads
+// consecutive records, a wave's points one contiguous stretch of the list), TRIP of them per trip with their camera
+// numbers requested together and then their projection rows and pixels together, and keeps its share of the ten sums
+// of [A b]^T [A b] in registers.  The shares meet in LDS, where the workgroup's first 256 / LPP threads pick up one
+// point each: the rank test and the 3 x 3 solve, some six hundred instructions per point, run on full waves.
+// What the kernel costs at 1 M points / 10 M observations is a mixture, none of it dominant: the launch of its waves
+// (15 us for the 62 500 waves of four lanes per point even when they return at once), 330 vector instructions per
+// wave (half the kernel's time busy), and per wave a chain of memory latencies (ranges, camera numbers, then rows and
+// pixels per trip) times the waves a SIMD holds.  Measured, caller's points in random order / in the engine's order
+// (by first camera), us: one lane per point 155 / 89; four lanes, three observations per trip, shares added by DPP
+// 91 / 82; four lanes through LDS, 3 / 2 / 1 per trip (126 / 96 / 66 registers) 91 / 75 / 70 and 89 at best in random
+// order, where every row comes from L2 (a quarter of L2's bandwidth in 96-byte pieces); two lanes, 3 / 2 / 1 per trip
+// 66 / 63 / 71 but 105-110 in random order (a lane's chain is five observations long); eight lanes 91-99.  Hence two
+// lanes, two per trip where the points are known to be ordered by first camera (a problem's own list) and four lanes,
+// one per trip otherwise.  Dropped: camera numbers of a whole track requested ahead of the trips (no change), the
+// rows of a workgroup's camera window staged in LDS (100 us), larger workgroups (87 / 105 us at 512 / 1024 threads).
+template <int LPP, int TRIP>
 __global__ void __launch_bounds__(256) k_triangulate(int64_t N, const int64_t *__restrict__ row_ptr,
                                                      const int32_t *__restrict__ oj, const double2 *__restrict__ uv,
                                                      const double *__restrict__ P, Intrinsics in, double rank_thr,
                                                      double *__restrict__ X) {
-    const int tid = threadIdx.x, q4 = tid & 3;
-    const int64_t i_raw = (int64_t)blockIdx.x * 64 + (tid >> 2);
-    const int64_t i = i_raw < N ? i_raw : N - 1;            // every lane of a quad stays in the exchange below
+    constexpr int PPB = 256 / LPP;
+    constexpr int PSTRIDE = LPP * 10 + 2;          // doubles per point: a stride of 20 / 12 banks between the solver's lanes
+    __shared__ double2 s_part[PPB * PSTRIDE / 2];
+    __shared__ int s_deg[PPB];
+    const int tid = threadIdx.x, ql = tid % LPP, pl = tid / LPP;
+    const int64_t i_raw = (int64_t)blockIdx.x * PPB + pl;
+    const int64_t i = i_raw < N ? i_raw : N - 1;
     const int64_t e0 = row_ptr[i], e1 = row_ptr[i + 1];
     double M[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};               // upper triangle of [A b]^T [A b], row-major
-    // three of the lane's observations per trip (a track of up to twelve in one): their camera numbers are requested
-    // together, then their rows and pixels together - three memory latencies per trip whatever it holds
-    constexpr int TRIP = 3;
-    for (int64_t base = e0 + q4; base < e1; base += 4 * TRIP) {
+    for (int64_t base = e0 + ql; base < e1; base += LPP * TRIP) {
         int jn[TRIP];
 #pragma unroll
-        for (int t = 0; t < TRIP; ++t) jn[t] = base + 4 * t < e1 ? oj[base + 4 * t] : 0;
+        for (int t = 0; t < TRIP; ++t) jn[t] = base + LPP * t < e1 ? oj[base + LPP * t] : 0;
         double2 Pt[TRIP][6], ct[TRIP];
 #pragma unroll
         for (int t = 0; t < TRIP; ++t) {
-            if (base + 4 * t < e1) {
+            if (base + LPP * t < e1) {
                 const double2 *Pv = (const double2 *)(P + 12 * (int64_t)jn[t]);
 #pragma unroll
                 for (int q = 0; q < 6; ++q) Pt[t][q] = Pv[q];
-                ct[t] = uv[base + 4 * t];
+                ct[t] = uv[base + LPP * t];
             }
         }
 #pragma unroll
         for (int t = 0; t < TRIP; ++t) {
-            if (base + 4 * t < e1) {
+            if (base + LPP * t < e1) {
                 double Pj[12];
 #pragma unroll
                 for (int q = 0; q < 6; ++q) {
@@ -182,24 +177,31 @@ __global__ void __launch_bounds__(256) k_triangulate(int64_t N, const int64_t *_
             }
         }
     }
+    {
+        double2 *dst = s_part + (pl * PSTRIDE + ql * 10) / 2;
 #pragma unroll
-    for (int k = 0; k < 10; ++k) M[k] = quad_sum(M[k]);
-    // The rank test and the 3 x 3 solve are some six hundred instructions per point: done by the quads' first lanes
-    // they would run at a quarter of the lanes in every wave (three quarters of this kernel's time, measured with the
-    // loads taken out).  The sums of the workgroup's 64 points go through LDS to its first wave instead.
-    __shared__ double s_M[10][64];
-    __shared__ int s_deg[64];
-    if (q4 == 0) {
-#pragma unroll
-        for (int k = 0; k < 10; ++k) s_M[k][tid >> 2] = M[k];
-        s_deg[tid >> 2] = (int)(e1 - e0);
+        for (int k = 0; k < 5; ++k) dst[k] = make_double2(M[2 * k], M[2 * k + 1]);
+        if (ql == 0) s_deg[pl] = (int)(e1 - e0);
     }
     __syncthreads();
-    if (tid >= 64) return;
-    const int64_t i_mine = (int64_t)blockIdx.x * 64 + tid;
+    if (tid >= PPB) return;
+    const int64_t i_mine = (int64_t)blockIdx.x * PPB + tid;
     if (i_mine >= N) return;
+    {
+        const double2 *src = s_part + tid * PSTRIDE / 2;
 #pragma unroll
-    for (int k = 0; k < 10; ++k) M[k] = s_M[k][tid];
+        for (int k = 0; k < 5; ++k) {
+            double2 v = src[k];
+#pragma unroll
+            for (int q = 1; q < LPP; ++q) {
+                const double2 w = src[5 * q + k];
+                v.x += w.x;
+                v.y += w.y;
+            }
+            M[2 * k] = v.x;
+            M[2 * k + 1] = v.y;
+        }
+    }
     const int deg = s_deg[tid];
     const double nan = __builtin_nan("");
     double x0 = nan, x1 = nan, x2 = nan;
@@ -454,11 +456,10 @@ static int cdiv_n(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 using namespace ba;
 
-extern "C" {
-
-int ba_triangulate(int64_t N, int64_t K, const int64_t *row_ptr, const int32_t *oj, const double *uv, const double *C,
-                   const double *Theta, double phi_x, double W, double H, int normalize, int64_t rank_rows, double *P_work,
-                   double *X_out, void *stream) {
+// points_by_first_camera: the caller vouches that neighbouring points see neighbouring cameras (a problem's own list)
+static int triangulate_list(int64_t N, int64_t K, const int64_t *row_ptr, const int32_t *oj, const double *uv,
+                            const double *C, const double *Theta, double phi_x, double W, double H, int normalize,
+                            int64_t rank_rows, double *P_work, double *X_out, void *stream, bool points_by_first_camera) {
     BA_REQUIRE(N > 0 && K > 0 && row_ptr && oj && uv && C && Theta && P_work && X_out, "ba_triangulate: bad argument");
     BA_REQUIRE(phi_x > 0.0 && phi_x < 3.14159265358979323846, "ba_triangulate: phi_x outside (0, pi)");
     hipStream_t st = (hipStream_t)stream;
@@ -466,10 +467,22 @@ int ba_triangulate(int64_t N, int64_t K, const int64_t *row_ptr, const int32_t *
     const double tol = (double)(rank_rows > 4 ? rank_rows : 4) * 2.220446049250313e-16;
     const double thr = tol * tol > RANK_FLOOR ? tol * tol : RANK_FLOOR;
     hipLaunchKernelGGL(k_projection_matrices, dim3(cdiv_n(K, 256)), dim3(256), 0, st, K, C, Theta, in, P_work);
-    hipLaunchKernelGGL(k_triangulate, dim3(cdiv_n(N, 64)), dim3(256), 0, st, N, row_ptr, oj, (const double2 *)uv, P_work, in, thr,
-                       X_out);
+    if (points_by_first_camera)
+        hipLaunchKernelGGL((k_triangulate<2, 2>), dim3(cdiv_n(N, 128)), dim3(256), 0, st, N, row_ptr, oj, (const double2 *)uv,
+                           P_work, in, thr, X_out);
+    else
+        hipLaunchKernelGGL((k_triangulate<4, 1>), dim3(cdiv_n(N, 64)), dim3(256), 0, st, N, row_ptr, oj, (const double2 *)uv,
+                           P_work, in, thr, X_out);
     BA_HIP(hipGetLastError());
     return BA_OK;
+}
+
+extern "C" {
+
+int ba_triangulate(int64_t N, int64_t K, const int64_t *row_ptr, const int32_t *oj, const double *uv, const double *C,
+                   const double *Theta, double phi_x, double W, double H, int normalize, int64_t rank_rows, double *P_work,
+                   double *X_out, void *stream) {
+    return triangulate_list(N, K, row_ptr, oj, uv, C, Theta, phi_x, W, H, normalize, rank_rows, P_work, X_out, stream, false);
 }
 
 int ba_problem_triangulate(ba_problem *p, const double *C, const double *Theta, double phi_x, int normalize,
@@ -491,8 +504,8 @@ int ba_problem_triangulate(ba_problem *p, const double *C, const double *Theta, 
         p->tri_selected_cameras = n;
     }
     const int64_t rank_rows = 2 * (int64_t)p->tri_selected_cameras > 4 ? 2 * (int64_t)p->tri_selected_cameras : 4;
-    return ba_triangulate(p->N, p->K, p->row_ptr, p->oj, (const double *)p->ouv, C, Theta, phi_x, p->W, p->H, normalize,
-                          rank_rows, P_work, X_out, stream);
+    return triangulate_list(p->N, p->K, p->row_ptr, p->oj, (const double *)p->ouv, C, Theta, phi_x, p->W, p->H, normalize,
+                            rank_rows, P_work, X_out, stream, true);
 }
 
 int ba_resect(int64_t N, int64_t K, const int64_t *col_ptr, const int32_t *oi_by_camera, const double *uv_by_camera,

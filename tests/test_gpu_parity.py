@@ -655,7 +655,7 @@ def test_triangulation_and_resection_vs_oracle_and_round_trip(ba):
 
 # ---- full-size properties (N = 1 M points, K = 2 k cameras, ~10 M observations) ---------------
 def test_shard_triangulates_its_own_list(ba, golden):
-    """Shard.triangulate (the kernel on the engine's own point order, projection rows staged in LDS) gives what the
+    """Shard.triangulate (the kernel on the engine's own point order, two lanes per point) gives what the
     reference's get_X_from_C_Theta gives (golden F7, NaN pattern included) and what the stand-alone call gives on a
     scene whose points come in random order."""
     import torch
