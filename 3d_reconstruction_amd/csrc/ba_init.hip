@@ -243,7 +243,7 @@ __global__ void k_count_marks(int64_t K, const int *__restrict__ mark, int *__re
 }
 
 // ---------------------------------------------------------------------------------------------
-// resection: one wave per camera
+// resection: one workgroup per camera
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void inv3(const double (&m)[3][3], double (&o)[3][3]) {
     const double c00 = m[1][1] * m[2][2] - m[1][2] * m[2][1], c01 = m[1][2] * m[2][0] - m[1][0] * m[2][2],
@@ -272,18 +272,28 @@ struct ResectArgs {
     double *C, *Theta;        // K x 3 each
 };
 
-__global__ void __launch_bounds__(64) k_resect(ResectArgs a) {
+// NW waves share a camera's observations; the eigen-solver rotates six disjoint index pairs of the 12 x 12 matrix at a
+// time (round-robin ordering: eleven rounds per sweep instead of 66 rotations one after the other, each a chain of a
+// root, a reciprocal and a reciprocal root and three trips through LDS).  At 2 000 cameras x 5 000 observations, points
+// numbered at random: 415 us with one rotation at a time -> 226 us, of which the sums take 150 (whatever NW is, 1 to
+// 4: the gather of 24-byte point rows from all over a 24 MB array is what they wait for), the eigen-solver 60, the
+// rest 14.
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) k_resect(ResectArgs a) {
+    constexpr int NT = 64 * NW;
     __shared__ double G[12][13];   // Gram matrix A^T A, overwritten by the Jacobi iteration
     __shared__ double V[12][13];   // accumulated rotations: eigenvectors in the columns
-    __shared__ double cs[2];
+    __shared__ double part[NW][40];
+    __shared__ double rc[12], rs[12];   // per index: cosine and signed sine of the rotation of its pair in this round
+    __shared__ int partner[12];
     const int64_t j = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double nan = __builtin_nan("");
     const int64_t e0 = a.col_ptr[j], e1 = a.col_ptr[j + 1];
     if (e1 - e0 < a.min_points) {                                  // p2w:1739
-        if (lane < 3) {
-            a.C[3 * j + lane] = nan;
-            a.Theta[3 * j + lane] = nan;
+        if (tid < 3) {
+            a.C[3 * j + tid] = nan;
+            a.Theta[3 * j + tid] = nan;
         }
         return;
     }
@@ -294,86 +304,130 @@ __global__ void __launch_bounds__(64) k_resect(ResectArgs a) {
     for (int b = 0; b < 4; ++b)
 #pragma unroll
         for (int k = 0; k < 10; ++k) acc[b][k] = 0.0;
-    for (int64_t e = e0 + lane; e < e1; e += 64) {
-        const int64_t i = a.oi[e];
-        const double xh[4] = {a.X[3 * i], a.X[3 * i + 1], a.X[3 * i + 2], 1.0};
-        if (xh[0] != xh[0] || xh[1] != xh[1] || xh[2] != xh[2]) continue;      // rows with NaN are zeroed (p2w:1771-1772)
-        const double2 c = a.uv[e];
-        const double u = (c.x - a.in.sx) * a.in.scale, v = (c.y - a.in.sy) * a.in.scale;
-        const double w = u * u + v * v;
-        int idx = 0;
+    for (int64_t e = e0 + tid; e < e1; e += 2 * NT) {
+        // two observations per trip, their loads in flight together
+        const bool two = e + NT < e1;
+        const int64_t i0 = a.oi[e], i1 = two ? a.oi[e + NT] : i0;
+        const double2 c0 = a.uv[e], c1 = a.uv[two ? e + NT : e];
+        const double x0[3] = {a.X[3 * i0], a.X[3 * i0 + 1], a.X[3 * i0 + 2]};
+        const double x1[3] = {a.X[3 * i1], a.X[3 * i1 + 1], a.X[3 * i1 + 2]};
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
+        for (int h = 0; h < 2; ++h) {
+            const double *x = h ? x1 : x0;
+            const double2 c = h ? c1 : c0;
+            // rows with NaN are zeroed (p2w:1771-1772)
+            const bool live = (h == 0 || two) && x[0] == x[0] && x[1] == x[1] && x[2] == x[2];
+            const double xh[4] = {live ? x[0] : 0.0, live ? x[1] : 0.0, live ? x[2] : 0.0, live ? 1.0 : 0.0};
+            const double u = (c.x - a.in.sx) * a.in.scale, v = (c.y - a.in.sy) * a.in.scale;
+            const double w = u * u + v * v;
+            int idx = 0;
 #pragma unroll
-            for (int q = p; q < 4; ++q) {
-                const double s = xh[p] * xh[q];
-                acc[0][idx] += s;
-                acc[1][idx] += u * s;
-                acc[2][idx] += v * s;
-                acc[3][idx] += w * s;
-                ++idx;
-            }
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int q = p; q < 4; ++q) {
+                    const double s = xh[p] * xh[q];
+                    acc[0][idx] += s;
+                    acc[1][idx] += u * s;
+                    acc[2][idx] += v * s;
+                    acc[3][idx] += w * s;
+                    ++idx;
+                }
+        }
     }
 #pragma unroll
     for (int b = 0; b < 4; ++b)
 #pragma unroll
-        for (int k = 0; k < 10; ++k) acc[b][k] = wave_sum(acc[b][k]);
-    if (lane == 0) {
-        int idx = 0;
+        for (int k = 0; k < 10; ++k) {
+            const double t = wave_sum(acc[b][k]);
+            if (lane == 0) part[wave][10 * b + k] = t;
+        }
+    __syncthreads();
+    if (wave != 0) return;          // waves that have ended do not count at the barriers below
+    if (lane < 40) {
+        double t = part[0][lane];
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
-#pragma unroll
-            for (int q = p; q < 4; ++q) {
-                const double s = acc[0][idx], su = acc[1][idx], sv = acc[2][idx], sw = acc[3][idx];
-                ++idx;
-                for (int t = 0; t < 2; ++t) {      // both (p, q) and (q, p)
-                    const int r = t ? q : p, c = t ? p : q;
-                    G[r][c] = s;
-                    G[4 + r][4 + c] = s;
-                    G[8 + r][8 + c] = sw;
-                    G[r][4 + c] = 0.0;
-                    G[4 + r][c] = 0.0;
-                    G[r][8 + c] = -su;
-                    G[8 + c][r] = -su;
-                    G[4 + r][8 + c] = -sv;
-                    G[8 + c][4 + r] = -sv;
-                }
-            }
+        for (int w = 1; w < NW; ++w) t += part[w][lane];
+        part[0][lane] = t;
     }
-    if (lane < 12)
-        for (int k = 0; k < 12; ++k) V[lane][k] = lane == k ? 1.0 : 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int el = lane + 64 * t;
+        if (el < 144) {
+            const int r = el / 12, c = el - 12 * r, br = r >> 2, bc = c >> 2;
+            const int p = min(r & 3, c & 3), q = max(r & 3, c & 3);
+            const int idx = 4 * p - p * (p - 1) / 2 + (q - p);          // (p, q), p <= q, in the row-major upper triangle
+            double g;
+            if (br == bc) g = part[0][(br == 2 ? 30 : 0) + idx];
+            else if (br + bc == 1) g = 0.0;
+            else g = -part[0][(br + bc == 2 ? 10 : 20) + idx];        // blocks (0, 2), (2, 0): -Su; (1, 2), (2, 1): -Sv
+            G[r][c] = g;
+            V[r][c] = r == c ? 1.0 : 0.0;
+        }
+    }
     __syncthreads();
 
-    // cyclic Jacobi, lane k < 12 owns row / column k of the updates; rotation angle computed by every lane
-    // (a rotation is skipped when |g_pq| <= 1e-16 sqrt(g_pp g_qq), the criterion that keeps the relative accuracy
-    // of the small eigenpairs; every lane reads the same values, so the control flow is uniform)
+    // Jacobi iteration.  A rotation is skipped when |g_pq| <= 1e-16 sqrt(g_pp g_qq), the criterion that keeps the
+    // relative accuracy of the small eigenpairs.  Round r pairs index 11 with r and (r + m) mod 11 with (r - m) mod 11,
+    // m = 1 .. 5: every index is in exactly one pair per round and meets every other index once per sweep.  With
+    // (c_x, s_x) the cosine and the signed sine of the pair of index x (minus for the pair's lower index) and x' its
+    // partner, G <- J^T G J is  g'_rc = c_r (c_c g_rc + s_c g_rc') + s_r (c_c g_r'c + s_c g_r'c'),  V <- V J likewise.
     for (int sweep = 0; sweep < 30; ++sweep) {
         bool rotated = false;
-        for (int p = 0; p < 11; ++p)
-            for (int q = p + 1; q < 12; ++q) {
+        for (int round = 0; round < 11; ++round) {
+            bool did = false;
+            if (lane < 6) {
+                int p = lane == 0 ? 11 : (round + lane) % 11, q = lane == 0 ? round : (round + 11 - lane) % 11;
+                if (p > q) {
+                    const int t = p;
+                    p = q;
+                    q = t;
+                }
                 const double apq = G[p][q], app = G[p][p], aqq = G[q][q];
-                if (apq * apq <= 1e-32 * fabs(app * aqq)) continue;
-                rotated = true;
-                const double theta = (aqq - app) / (2.0 * apq);
-                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-                __syncthreads();
-                if (lane < 12) {
-                    const double akp = G[lane][p], akq = G[lane][q];
-                    G[lane][p] = c * akp - s * akq;
-                    G[lane][q] = s * akp + c * akq;
-                    const double vkp = V[lane][p], vkq = V[lane][q];
-                    V[lane][p] = c * vkp - s * vkq;
-                    V[lane][q] = s * vkp + c * vkq;
+                double c = 1.0, s = 0.0;
+                if (!(apq * apq <= 1e-32 * fabs(app * aqq))) {
+                    did = true;
+                    // t = sign(theta) / (|theta| + sqrt(theta^2 + 1)), theta = (g_qq - g_pp) / (2 g_pq), without the
+                    // quotient theta: one root, one reciprocal, one reciprocal root, each a Newton iteration from the
+                    // hardware's estimate (this chain is what a round waits for)
+                    const double d = aqq - app, b = 2.0 * apq;
+                    const double h = fma(d, d, b * b);
+                    const double t = (d >= 0.0 ? b : -b) * fast_rcp_wide(fabs(d) + h * fast_rsqrt(h));
+                    c = fast_rsqrt(fma(t, t, 1.0));
+                    s = t * c;
                 }
-                __syncthreads();
-                if (lane < 12) {
-                    const double apk = G[p][lane], aqk = G[q][lane];
-                    G[p][lane] = c * apk - s * aqk;
-                    G[q][lane] = s * apk + c * aqk;
-                }
-                __syncthreads();
+                rc[p] = c;
+                rc[q] = c;
+                rs[p] = -s;
+                rs[q] = s;
+                partner[p] = q;
+                partner[q] = p;
             }
+            rotated |= __ballot(did) != 0;
+            __syncthreads();
+            double gn[3], vn[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int el = lane + 64 * t;
+                if (el < 144) {
+                    const int r = el / 12, c = el - 12 * r, pr = partner[r], pc = partner[c];
+                    const double cr = rc[r], sr = rs[r], cc = rc[c], sc = rs[c];
+                    gn[t] = cr * (cc * G[r][c] + sc * G[r][pc]) + sr * (cc * G[pr][c] + sc * G[pr][pc]);
+                    vn[t] = cc * V[r][c] + sc * V[r][pc];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int el = lane + 64 * t;
+                if (el < 144) {
+                    const int r = el / 12, c = el - 12 * r;
+                    G[r][c] = gn[t];
+                    V[r][c] = vn[t];
+                }
+            }
+            __syncthreads();
+        }
         if (!rotated) break;
     }
     __syncthreads();
@@ -525,7 +579,7 @@ int ba_resect(int64_t N, int64_t K, const int64_t *col_ptr, const int32_t *oi_by
     a.min_points = 6;
     a.C = C_out;
     a.Theta = Theta_out;
-    hipLaunchKernelGGL(k_resect, dim3((unsigned)K), dim3(64), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_resect<4>, dim3((unsigned)K), dim3(256), 0, (hipStream_t)stream, a);
     BA_HIP(hipGetLastError());
     return BA_OK;
 }

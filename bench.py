@@ -489,8 +489,8 @@ def main():
                 jtj_pass_bytes(nv_local, N_loc, K), jt,
                 measured_traffic('k_run_pass<ba::JtjOp', N_loc, K, args.track_len),
                 {'observations_per_launch': nv_local, 'timed': 'stand-alone launches, outside the timed loop',
-                 'parity': 'second-order extension without a counterpart in the reference: pinned by dense normal '
-                           'equations, not by reference outputs'})
+                 'parity': 'second-order extension without a counterpart in the reference: its blocks are pinned by '
+                           "the reference's own per-observation Jacobians (golden F11)"})
         if world == 1:
             sc8 = ba.scenes.orbit_scene(N=args.total_points, K=args.cameras, track_len=args.track_len, seed=0, part=0,
                                         parts=8)

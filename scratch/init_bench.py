@@ -1,6 +1,8 @@
 """Triangulation and resection at cfg3 size: time and bytes streamed."""
 import importlib, sys, os, numpy as np, torch
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '.'))
+if os.environ.get('BA_LIB'):
+    importlib.import_module('3d_reconstruction_amd._lib').LIB_PATH = os.path.abspath(os.environ['BA_LIB'])
 ba = importlib.import_module('3d_reconstruction_amd')
 sc = ba.scenes.orbit_scene(N=1_000_000, K=2000, track_len=10, seed=0)
 N, K, W, H = sc['N_local'], sc['K'], sc['W'], sc['H']
