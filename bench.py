@@ -349,8 +349,10 @@ def main():
     ap.add_argument('--no-lm', action='store_true', help='N = 1: skip the second-order measurements (roofline_lm)')
     ap.add_argument('--no-one-gpu-reference', action='store_true',
                     help='N > 1: skip the timing of the whole scene on one GPU')
-    ap.add_argument('--no-exchange-trial', action='store_true',
-                    help='N > 1: skip the second measurement with the node exchange kernel')
+    ap.add_argument('--exchange-trial', action='store_true',
+                    help='N > 1: a second measurement with the node exchange kernel as the carrier, in child processes '
+                         '(off by default: that kernel has never run across xGMI, and the measurement that counts must '
+                         'not share a machine with its first attempt)')
     ap.add_argument('--exchange-child', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -528,7 +530,7 @@ def main():
         dist.barrier()
 
     # ---- N > 1: the node exchange kernel as the carrier of the sums, measured by child processes
-    if world > 1 and not args.no_exchange_trial:
+    if world > 1 and args.exchange_trial:
         note('the same loop with the node exchange kernel, in child processes')
         rep = exchange_trial(args, rank, world, local_rank)
         if rank == 0:
