@@ -1078,8 +1078,9 @@ __global__ void __launch_bounds__(SCHUR_GEMM_BLOCK, NBT <= 4 ? 3 : 2) k_schur_ge
     };
     const int nbt_tile = (m + 2 + 15) / 16;     // tile rows of this tile of points
     // LPP lanes per point, lane o16 of them for the point's observation o16 (more than LPP: further trips).
-    // What a trip reads from memory is requested one trip ahead, the observation ranges it needs for that two trips
-    // ahead: with two waves per SIMD nothing else would cover the two dependent trips to memory per group of points.
+    // A trip starts with two dependent trips to memory (observation ranges, then the points' and observations' data)
+    // that only the SIMD's other waves cover: requesting them a trip ahead costs registers the accumulators need
+    // (the ranges alone: 14 spilled registers at three waves per SIMD, LM iteration 2.07 -> 2.13 ms).
     constexpr int GSTEP = PTS * (SCHUR_GEMM_BLOCK / 64);
     const int pl = lane / LPP, o16 = lane - LPP * pl;       // (pl == PTS: a lane without a point)
     struct GroupIn {
