@@ -653,6 +653,32 @@ def test_triangulation_and_resection_vs_oracle_and_round_trip(ba):
     assert np.nanmax(np.abs(Cd - Ct)) < 5e-2 and np.nanmax(np.abs(Td - Tt)) < 5e-3
 
 
+def test_triangulation_and_resection_on_long_tracks(ba, golden):
+    """The recorded scene (93 points followed through up to 196 of 327 frames, cameras that see 10 to 48 of them):
+    both forms of the triangulation kernel (a caller's list: four lanes per point; a shard's own list: two lanes) take
+    tracks of many trips, the resection kernel cameras with a few points only - against the CPU
+    restatement, which the reference's outputs pin on the small scene of golden F7."""
+    g = golden('f2_moscow_ride.npz')
+    N, K, W, H = int(g['N']), int(g['K']), int(g['W']), int(g['H'])
+    i, j, uv = g['obs_i'], g['obs_j'], g['obs_xy'] + 0.5
+    C_, Th, phi, X = g['free__final_C'], g['free__final_Theta'], float(g['free__final_phi_x']), g['free__final_X']
+    assert np.bincount(i, minlength=N).max() > 150
+    for norm in (False, True):
+        want = orc.triangulate_obs(i, j, uv, N, C_, Th, phi, W, H, norm)
+        got = ba.engine.triangulate(i, j, uv, N, C_, Th, phi, W, H, norm, DEV).cpu().numpy()
+        sh = ba.engine.Shard(i, j, uv, N, K, W, H, DEV)
+        sh.set_params(X, C_, Th, phi)
+        own = sh.triangulate(normalize=norm).cpu().numpy()
+        sh.close()
+        for have in (got, own):
+            assert np.array_equal(np.isnan(have), np.isnan(want))
+            assert np.nanmax(np.abs(have - want) / (1.0 + np.abs(want))) < 1e-9
+        Cd, Td = (t.cpu().numpy() for t in ba.engine.resect(i, j, uv, K, X, phi, W, H, norm, DEV))
+        Co, To = orc.resect_obs(i, j, uv, K, X, phi, W, H, norm, use_gram=False)
+        assert np.array_equal(np.isnan(Cd), np.isnan(Co)) and not np.isnan(Co).any()
+        assert np.nanmax(np.abs(Cd - Co) / (1.0 + np.abs(Co))) < 1e-7 and np.nanmax(np.abs(Td - To)) < 1e-7
+
+
 # ---- full-size properties (N = 1 M points, K = 2 k cameras, ~10 M observations) ---------------
 def test_shard_triangulates_its_own_list(ba, golden):
     """Shard.triangulate (the kernel on the engine's own point order, two lanes per point) gives what the
