@@ -54,6 +54,34 @@ def measured_traffic(kernel_key, points_per_gpu, cameras, track_len):
     return None
 
 
+COUNTER_FILE = os.path.join('profiles', 'r03_pmc_run_pass_counters_10M.txt')
+
+
+def pipe_shares(kernel_key, points_per_gpu, cameras, track_len):
+    """How busy the kernel keeps the vector ALU and the LDS (the pass sits near the ridge, so its HBM fraction alone
+    says little): shares of the kernel's cycles from the committed SQ counter pass of stand-alone launches on this
+    workload - a constant of that profile, like `traffic`.  Kernel cycles = SQ_BUSY_CYCLES / 32 shader engines,
+    vector ALU = SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs, LDS = SQ_LDS_IDX_ACTIVE / 256 CUs."""
+    path = os.path.join(ROOT, COUNTER_FILE)
+    if (points_per_gpu, cameras, track_len) != (1_000_000, 2000, 10) or not os.path.exists(path):
+        return None
+    c = {}
+    with open(path) as fh:
+        for line in fh:
+            if kernel_key in line:
+                parts = line.split()
+                for k, tok in enumerate(parts):
+                    if tok.startswith('SQ_') and k + 1 < len(parts):
+                        c[tok] = float(parts[k + 1])
+    need = ('SQ_BUSY_CYCLES', 'SQ_ACTIVE_INST_VALU', 'SQ_LDS_IDX_ACTIVE', 'SQ_LDS_BANK_CONFLICT')
+    if any(k not in c for k in need) or c['SQ_BUSY_CYCLES'] <= 0:
+        return None
+    cycles = c['SQ_BUSY_CYCLES'] / 32.0
+    return {'valu_busy': c['SQ_ACTIVE_INST_VALU'] * 4.0 / 1024.0 / cycles, 'lds_busy': c['SQ_LDS_IDX_ACTIVE'] / 256.0 / cycles,
+            'lds_bank_conflict_share': c['SQ_LDS_BANK_CONFLICT'] / c['SQ_LDS_IDX_ACTIVE'],
+            'source': f'{COUNTER_FILE} (rocprofv3 --pmc pass, committed; not collected by this run)'}
+
+
 def host_cpu():
     model = '?'
     try:
@@ -469,6 +497,7 @@ def main():
                 grad_pass_bytes(nv_local, N_loc, K), kern_ms,
                 measured_traffic('k_run_pass<ba::GradOp', N_loc, K, args.track_len) if fused else None,
                 {'observations_per_launch': nv_local,
+                 'pipes': pipe_shares('k_run_pass<ba::GradOp', N_loc, K, args.track_len),
                  'note': 'achieved = algorithmic bytes (24 B per observation record + X in + gX out + cameras in '
                          'and out) / kernel time; the kernel streams 8-byte records and carries the fused point '
                          'update, so the bytes it really moves are `traffic`'}),
@@ -491,6 +520,7 @@ def main():
                 jtj_pass_bytes(nv_local, N_loc, K), jt,
                 measured_traffic('k_run_pass<ba::JtjOp', N_loc, K, args.track_len),
                 {'observations_per_launch': nv_local, 'timed': 'stand-alone launches, outside the timed loop',
+                 'pipes': pipe_shares('k_run_pass<ba::JtjOp', N_loc, K, args.track_len),
                  'parity': 'second-order extension without a counterpart in the reference: its blocks are pinned by '
                            "the reference's own per-observation Jacobians (golden F11)"})
         if world == 1:
