@@ -342,14 +342,21 @@ __global__ void __launch_bounds__(64 * NW) k_resect(ResectArgs a) {
             if (lane == 0) part[wave][10 * b + k] = t;
         }
     __syncthreads();
-    if (wave != 0) return;          // waves that have ended do not count at the barriers below
+    if (wave != 0) return;
+    // From here on one wave is left.  The LDS serves a wave's instructions in order, so what its lanes hand to each
+    // other through LDS needs no workgroup barrier, only that the compiler keeps the accesses in order.
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
     if (lane < 40) {
         double t = part[0][lane];
 #pragma unroll
         for (int w = 1; w < NW; ++w) t += part[w][lane];
         part[0][lane] = t;
     }
-    __syncthreads();
+    wave_sync();
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
         const int el = lane + 64 * t;
@@ -365,7 +372,7 @@ __global__ void __launch_bounds__(64 * NW) k_resect(ResectArgs a) {
             V[r][c] = r == c ? 1.0 : 0.0;
         }
     }
-    __syncthreads();
+    wave_sync();
 
     // Jacobi iteration.  A rotation is skipped when |g_pq| <= 1e-16 sqrt(g_pp g_qq), the criterion that keeps the
     // relative accuracy of the small eigenpairs.  Round r pairs index 11 with r and (r + m) mod 11 with (r - m) mod 11,
@@ -404,7 +411,7 @@ __global__ void __launch_bounds__(64 * NW) k_resect(ResectArgs a) {
                 partner[q] = p;
             }
             rotated |= __ballot(did) != 0;
-            __syncthreads();
+            wave_sync();
             double gn[3], vn[3];
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
@@ -416,7 +423,7 @@ __global__ void __launch_bounds__(64 * NW) k_resect(ResectArgs a) {
                     vn[t] = cc * V[r][c] + sc * V[r][pc];
                 }
             }
-            __syncthreads();
+            wave_sync();
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
                 const int el = lane + 64 * t;
@@ -426,11 +433,11 @@ __global__ void __launch_bounds__(64 * NW) k_resect(ResectArgs a) {
                     V[r][c] = vn[t];
                 }
             }
-            __syncthreads();
+            wave_sync();
         }
         if (!rotated) break;
     }
-    __syncthreads();
+    wave_sync();
     if (lane != 0) return;
     double lmax = 0.0, lmin = G[0][0];
     int kmin = 0;
