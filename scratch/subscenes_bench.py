@@ -1,6 +1,8 @@
 """fit_subscenes_GD's device path at a large size: subscenes_bench.py [N] [P] [per_point]"""
 import importlib, sys, os, time, numpy as np, torch
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '.'))
+if os.environ.get('BA_LIB'):
+    importlib.import_module('3d_reconstruction_amd._lib').LIB_PATH = os.path.abspath(os.environ['BA_LIB'])
 ba = importlib.import_module('3d_reconstruction_amd')
 sub = importlib.import_module('3d_reconstruction_amd.subscenes')
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 400_000
@@ -27,6 +29,8 @@ b.record(); torch.cuda.synchronize()
 t = a.elapsed_time(b) / 50 * 1e3
 byts = n * 28 + 8 * (N + 1)
 print(f'N={N} P={P} entries={n}: eval (table + sums + pass) {t:.1f} us per call, {byts / t / 1e6:.3f} TB/s by {byts / 1e6:.1f} MB of entries', flush=True)
+if os.environ.get('SUB_EVAL_ONLY'):
+    sys.exit(0)
 t0 = time.perf_counter()
 out = ba.fit_subscenes_GD(X, 1e-2, 200, optimizer='Adam', print_step=10**9) if 'print_step' in ba.fit_subscenes_GD.__code__.co_varnames else ba.fit_subscenes_GD(X, 1e-2, 200)
 torch.cuda.synchronize()
