@@ -1478,12 +1478,12 @@ __global__ void k_row_ptr(const int32_t *__restrict__ oi, int64_t nV, int64_t N,
 }
 
 __global__ void k_max_degree(const int64_t *__restrict__ row_ptr, int64_t N, int *out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int d = 0;
-    if (i < N) d = (int)(row_ptr[i + 1] - row_ptr[i]);
+    int d = 0;      // (a few hundred atomics on the one address, not one per wave of a million points)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x)
+        d = max(d, (int)(row_ptr[i + 1] - row_ptr[i]));
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) d = max(d, __shfl_xor(d, off));
-    if ((threadIdx.x & 63) == 0) atomicMax(out, d);
+    if ((threadIdx.x & 63) == 0 && d > 0) atomicMax(out, d);
 }
 
 // solution in camera-major order -> packed [dC (3K) | dTheta (3K) | dphi]
@@ -1513,7 +1513,7 @@ int ba::ensure_row_ptr(ba_problem *p) {
     hipLaunchKernelGGL(k_row_ptr, dim3(cdiv_i(p->nV + 1, 256)), dim3(256), 0, 0, p->oi, p->nV, p->N, p->row_ptr);
     int *dmax = p->flag + 3;
     BA_HIP(hipMemset(dmax, 0, sizeof(int)));
-    hipLaunchKernelGGL(k_max_degree, dim3(cdiv_i(p->N, 256)), dim3(256), 0, 0, p->row_ptr, p->N, dmax);
+    hipLaunchKernelGGL(k_max_degree, dim3(std::min(cdiv_i(p->N, 256), 256)), dim3(256), 0, 0, p->row_ptr, p->N, dmax);
     BA_HIP(hipGetLastError());
     BA_HIP(hipMemcpy(&p->max_degree, dmax, sizeof(int), hipMemcpyDeviceToHost));
     return BA_OK;
