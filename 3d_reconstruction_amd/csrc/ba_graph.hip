@@ -79,12 +79,20 @@ __global__ void k_fill_int(int64_t n, int *__restrict__ a, int value) {
     if (v < n) a[v] = value;
 }
 
+// The list is sorted by point: the thread of a point's first observation walks the point's observations (a minimum
+// by atomics, one per observation, took 0.37 ms at ten million observations).
 __global__ void k_first_camera(int64_t nV, const int32_t *__restrict__ oi, const int32_t *__restrict__ oj, int *first,
                                int *flag) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= nV) return;
-    atomicMin(first + oi[e], oj[e]);
-    if (e > 0 && oi[e - 1] > oi[e]) atomicOr(flag, 2);      // the list is not sorted by point
+    const int i = oi[e];
+    const int before = e > 0 ? oi[e - 1] : -1;
+    if (before > i && (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2) == 0)
+        atomicOr(flag, 2);      // the list is not sorted by point (the caller gives up: what is written below is not used)
+    if (before == i) return;
+    int m = oj[e];
+    for (int64_t f = e + 1; f < nV && oi[f] == i; ++f) m = min(m, oj[f]);
+    first[i] = m;
 }
 
 __global__ void k_iota_and_sorted(int64_t n, const int *__restrict__ key, int *__restrict__ val, int *unsorted) {
