@@ -152,7 +152,8 @@ def roofline_block(kernel, algo_bytes, kern_ms, traffic, extra=None):
                               'committed; a constant of that profile, not collected by this run') if traffic else None,
            'achieved_traffic': (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None,
            'frac_physical': (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-           'algorithmic_bytes_per_launch': algo_bytes, 'avg_kernel_ms': avg_ms, 'launches_timed': len(kern_ms)}
+           'algorithmic_bytes_per_launch': algo_bytes, 'avg_kernel_ms': avg_ms,
+           'median_kernel_ms': float(np.median(kern_ms)) if len(kern_ms) else float('nan'), 'launches_timed': len(kern_ms)}
     if extra:
         out.update(extra)
     return out
@@ -252,7 +253,7 @@ def dense_cholesky_rate(ba, dev, n=30001, repeats=2):
 
 
 PREHEAT_ITERATIONS = 700
-EVENT_TIMED_LAUNCHES = 12
+EVENT_TIMED_LAUNCHES = 48
 
 
 def preheat(ba, sh, sc, iterations=PREHEAT_ITERATIONS):
